@@ -1,0 +1,16 @@
+"""ark_plonk_amd -- MI355X-native NTT + MSM hot path of the ark-plonk prover (HIP, gfx950).
+
+Host-side mirror of the reference interfaces for this path:
+  Radix2EvaluationDomain / GeneralEvaluationDomain  <- ark_poly::EvaluationDomain
+  VariableBaseMSM, CommitterKey (commit / open)     <- ark_ec::msm::VariableBaseMSM, KZG10 PC::commit/open
+All compute runs in libark_plonk_amd.so (C ABI: include/ark_plonk_amd.h); there is no CPU fallback.
+"""
+from .context import Context, default_context  # noqa: F401
+from .curves import BLS12_381, BN254, get_curve  # noqa: F401
+from .domain import GeneralEvaluationDomain, Radix2EvaluationDomain  # noqa: F401
+from .msm import CommitterKey, G1Affine, VariableBaseMSM, sum_partials  # noqa: F401
+
+__all__ = [
+    "Context", "default_context", "BLS12_381", "BN254", "get_curve", "GeneralEvaluationDomain",
+    "Radix2EvaluationDomain", "CommitterKey", "G1Affine", "VariableBaseMSM", "sum_partials",
+]

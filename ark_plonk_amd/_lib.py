@@ -1,0 +1,114 @@
+"""ctypes binding of libark_plonk_amd.so (the C ABI in include/ark_plonk_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libark_plonk_amd.so")
+
+ZK_OK = 0
+ZK_ERR_BAD_ARG = -1
+ZK_ERR_DOMAIN_TOO_LARGE = -2
+ZK_ERR_HIP = -3
+ZK_ERR_OOM = -4
+ZK_ERR_NO_DEVICE = -5
+ZK_ERR_UNSUPPORTED = -6
+
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+c_int = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_u64 = ctypes.c_uint64
+u64p = ctypes.POINTER(ctypes.c_uint64)
+u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class DomainInfo(ctypes.Structure):
+    _fields_ = [
+        ("size", c_u64),
+        ("log_size_of_group", c_u32),
+        ("reserved", c_u32),
+        ("size_inv", c_u64 * 4),
+        ("group_gen", c_u64 * 4),
+        ("group_gen_inv", c_u64 * 4),
+        ("generator", c_u64 * 4),
+        ("generator_inv", c_u64 * 4),
+    ]
+
+
+# every symbol include/ark_plonk_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "zk_strerror": (ctypes.c_char_p, [c_int]),
+    "zk_build_info": (ctypes.c_char_p, []),
+    "zk_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "zk_ctx_destroy": (None, [c_void_p]),
+    "zk_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "zk_ctx_sync": (c_int, [c_void_p]),
+    "zk_ctx_set_msm_window": (c_int, [c_void_p, c_int]),
+    "zk_profile_enable": (c_int, [c_void_p, c_int]),
+    "zk_profile_reset": (c_int, [c_void_p]),
+    "zk_profile_get": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),
+    "zk_domain_new": (c_int, [c_int, c_u64, ctypes.POINTER(DomainInfo)]),
+    "zk_ntt": (c_int, [c_void_p, c_int, c_int, c_u32, c_void_p, c_size_t, c_void_p]),
+    "zk_ntt_dev": (c_int, [c_void_p, c_int, c_int, c_u32, c_void_p, c_size_t, c_void_p]),
+    "zk_ntt_batch_dev": (c_int, [c_void_p, c_int, c_int, c_u32, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t),
+                                 ctypes.POINTER(c_void_p)]),
+    "zk_ntt_prepare": (c_int, [c_void_p, c_int, c_u32]),
+    "zk_fr_from_mont_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "zk_fr_to_mont_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "zk_msm_g1": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_srs_register": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_srs_register_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_srs_free": (None, [c_void_p]),
+    "zk_srs_len": (c_size_t, [c_void_p]),
+    "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_msm_g1_srs_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_msm_g1_srs_partial_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "zk_g1_sum_partials": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_kzg_commit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_kzg_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_kzg_open_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "zk_g1_fixed_base_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "zk_fr_mul_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "zk_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_dev_free": (c_int, [c_void_p, c_void_p]),
+    "zk_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "zk_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+}
+
+_lib = None
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code: int, where: str = ""):
+        self.code = code
+        msg = lib().zk_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__(f"{where}: {msg} (code {code})" if where else f"{msg} (code {code})")
+
+
+def lib():
+    """Load the HIP library; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m ark_plonk_amd.build` (hipcc, gfx950). "
+                "ark_plonk_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, where: str = ""):
+    if code != ZK_OK:
+        raise ZkError(code, where)

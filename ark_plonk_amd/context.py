@@ -1,0 +1,115 @@
+"""Context = one zk_ctx = one GPU (one process per GPU)."""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+_default = {}
+_default_lock = threading.Lock()
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """Owns a zk_ctx on HIP device `device`.  All product compute goes through it."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._h = ctypes.c_void_p()
+        check(lib().zk_ctx_create(int(device), ctypes.byref(self._h)), "zk_ctx_create")
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().zk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("context closed")
+        return self._h
+
+    # -- stream / sync
+    def set_stream(self, stream):
+        """stream: int/ctypes pointer (hipStream_t) or a torch.cuda.Stream; None = ctx's own."""
+        ptr = None
+        if stream is not None:
+            ptr = getattr(stream, "cuda_stream", stream)
+        check(lib().zk_ctx_set_stream(self.handle, ctypes.c_void_p(ptr)), "zk_ctx_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device))
+
+    def sync(self):
+        check(lib().zk_ctx_sync(self.handle), "zk_ctx_sync")
+
+    def set_msm_window(self, c: int):
+        check(lib().zk_ctx_set_msm_window(self.handle, int(c)), "zk_ctx_set_msm_window")
+
+    # -- profiling
+    def profile(self, on: bool = True):
+        check(lib().zk_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().zk_profile_reset(self.handle))
+
+    def profile_get(self, name: str):
+        t = ctypes.c_double()
+        n = ctypes.c_uint64()
+        check(lib().zk_profile_get(self.handle, name.encode(), ctypes.byref(t), ctypes.byref(n)))
+        return t.value, n.value
+
+
+def default_context(device: int = 0) -> Context:
+    with _default_lock:
+        ctx = _default.get(device)
+        if ctx is None:
+            ctx = Context(device)
+            _default[device] = ctx
+        return ctx
+
+
+def ptr_of(x):
+    """Device/host address of a numpy array or torch tensor."""
+    if _is_torch(x):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.ctypes.data)
+
+
+def as_host_u64(x, cols: int) -> np.ndarray:
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    if a.size % cols:
+        raise ValueError(f"array size {a.size} not a multiple of {cols} limbs")
+    return a.reshape(-1, cols)
+
+
+def check_dev_tensor(t, cols: int, device: int):
+    import torch
+    if not t.is_cuda:
+        raise ValueError("expected a CUDA/HIP tensor")
+    if t.device.index != device:
+        raise ValueError(f"tensor on device {t.device.index}, context on {device}")
+    if t.dtype not in (torch.int64, torch.uint64):
+        raise ValueError("expected an int64/uint64 limb tensor")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    if t.numel() % cols:
+        raise ValueError(f"tensor size not a multiple of {cols} limbs")
+    return t.numel() // cols

@@ -1,0 +1,492 @@
+// C ABI of the MI355X NTT + MSM hot path (include/ark_plonk_amd.h).  Thin: argument checks,
+// host<->device staging for the host-buffer entry points, ctx / SRS lifetime, profiling.
+#include "ctx.h"
+
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_last_hip[256];
+
+void zk_note_hip_error(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_last_hip, sizeof g_last_hip, "%s (%s) at %s:%d", hipGetErrorString(e), what, file, line);
+    if (getenv("ZK_VERBOSE")) fprintf(stderr, "[ark_plonk_amd] HIP error: %s\n", g_last_hip);
+}
+
+// ------------------------------------------------------------------------------------- profiling
+ProfScope::ProfScope(zk_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+    if (!c->profiling) return;
+    auto take = [&]() -> hipEvent_t {
+        if (!c->event_pool.empty()) {
+            hipEvent_t e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    };
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->prof[name].pending.emplace_back(a, b);
+}
+void zk_prof_collect(zk_ctx* c) {
+    for (auto& kv : c->prof) {
+        ProfEntry& pe = kv.second;
+        for (auto& ev : pe.pending) {
+            (void)hipEventSynchronize(ev.second);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                pe.total_ms += ms;
+                pe.launches += 1;
+            }
+            c->event_pool.push_back(ev.first);
+            c->event_pool.push_back(ev.second);
+        }
+        pe.pending.clear();
+    }
+}
+
+namespace {
+
+inline int fq_limbs64(int curve) { return curve == ZK_CURVE_BLS12_381 ? 6 : curve == ZK_CURVE_BN254 ? 4 : 0; }
+
+struct Guard {
+    zk_ctx* c;
+    std::unique_lock<std::recursive_mutex> lk;
+    int prev = -1;
+    bool ok = true;
+    explicit Guard(zk_ctx* ctx) : c(ctx), lk(ctx->mu) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) ok = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~Guard() {
+        if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    }
+};
+
+int finish_point(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    return g1_jacobian_to_affine_host(curve, xyz, out_xy, out_inf);
+}
+
+// ------------------------------------------------------------------------------------------- a1
+template <class C>
+static int domain_new(uint64_t num_coeffs, zk_domain_info* out) {
+    typedef typename C::Fr Fr;
+    uint64_t size = 1;
+    uint32_t lg = 0;
+    while (size < num_coeffs) {
+        size <<= 1;
+        ++lg;
+        if (lg > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
+    }
+    if (lg > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+    memset(out, 0, sizeof *out);
+    out->size = size;
+    out->log_size_of_group = lg;
+    Fr root;
+    for (int i = 0; i < Fr::N; ++i) root.v[i] = C::FrP::ROOT(i);
+    for (uint32_t k = lg; k < (uint32_t)C::FrP::TWO_ADICITY; ++k) root = Fr::sqr(root);
+    Fr gen = Fr::from_u32(C::FrP::GENERATOR);
+    Fr size_inv = Fr::inverse(Fr::from_u64(size));
+    Fr root_inv = Fr::inverse(root);
+    Fr gen_inv = Fr::inverse(gen);
+    memcpy(out->size_inv, size_inv.v, 32);
+    memcpy(out->group_gen, root.v, 32);
+    memcpy(out->group_gen_inv, root_inv.v, 32);
+    memcpy(out->generator, gen.v, 32);
+    memcpy(out->generator_inv, gen_inv.v, 32);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* zk_strerror(int code) {
+    switch (code) {
+    case ZK_OK: return "ok";
+    case ZK_ERR_BAD_ARG: return "bad argument";
+    case ZK_ERR_DOMAIN_TOO_LARGE: return "evaluation domain larger than the field's two-adicity";
+    case ZK_ERR_HIP: return g_last_hip[0] ? g_last_hip : "HIP runtime error";
+    case ZK_ERR_OOM: return "out of device memory";
+    case ZK_ERR_NO_DEVICE: return "no usable HIP device";
+    case ZK_ERR_UNSUPPORTED: return "size not supported";
+    default: return "unknown error";
+    }
+}
+
+const char* zk_build_info(void) { return "ark_plonk_amd gfx950 (CDNA4) hipcc; NTT+MSM hot path"; }
+
+int zk_ctx_create(int device, zk_ctx** out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZK_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return ZK_ERR_BAD_ARG;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    ZK_HIP_TRY(hipSetDevice(device));
+    zk_ctx* c = new zk_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        (void)hipSetDevice(prev);
+        return ZK_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    (void)hipSetDevice(prev);
+    *out = c;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* c) {
+    if (!c) return;
+    {
+        Guard g(c);
+        (void)hipStreamSynchronize(c->stream);
+        zk_prof_collect(c);
+        for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+        ntt_ctx_free(c);
+        DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_counts, &c->msm_offsets, &c->msm_entries, &c->msm_buckets, &c->msm_part_pt,
+                          &c->msm_part_key, &c->msm_seg, &c->msm_win, &c->msm_scalars, &c->msm_tmp};
+        for (DevBuf* b : bufs) b->release();
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
+    delete c;
+}
+
+int zk_ctx_set_stream(zk_ctx* c, void* hip_stream) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ZK_OK;
+}
+
+int zk_ctx_sync(zk_ctx* c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_ctx_set_msm_window(zk_ctx* c, int w) {
+    if (!c || w < 0 || w > 20 || w == 1) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    c->msm_window = w;
+    return ZK_OK;
+}
+
+int zk_profile_enable(zk_ctx* c, int on) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    c->profiling = on != 0;
+    return ZK_OK;
+}
+int zk_profile_reset(zk_ctx* c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    zk_prof_collect(c);
+    for (auto& kv : c->prof) {
+        kv.second.total_ms = 0;
+        kv.second.launches = 0;
+    }
+    return ZK_OK;
+}
+int zk_profile_get(zk_ctx* c, const char* name, double* total_ms, uint64_t* launches) {
+    if (!c || !name) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    zk_prof_collect(c);
+    auto it = c->prof.find(name);
+    double t = 0;
+    uint64_t n = 0;
+    if (it != c->prof.end()) {
+        t = it->second.total_ms;
+        n = it->second.launches;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = n;
+    return ZK_OK;
+}
+
+int zk_domain_new(int curve_id, uint64_t num_coeffs, zk_domain_info* out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    if (curve_id == ZK_CURVE_BLS12_381) return domain_new<CurveBls>(num_coeffs, out);
+    if (curve_id == ZK_CURVE_BN254) return domain_new<CurveBn>(num_coeffs, out);
+    return ZK_ERR_BAD_ARG;
+}
+
+// ---------------------------------------------------------------------------------------- a2-a5
+int zk_ntt_dev(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
+    if (!c || !d_out || (!d_in && in_len)) return ZK_ERR_BAD_ARG;
+    if (log_n > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
+    Guard g(c);
+    return ntt_run_dev(c, curve_id, kind, log_n, d_in, in_len, d_out);
+}
+
+int zk_ntt_batch_dev(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const void* const* d_ins,
+                     const size_t* in_lens, void* const* d_outs) {
+    if (!c || (n_polys && (!d_ins || !in_lens || !d_outs))) return ZK_ERR_BAD_ARG;
+    if (log_n > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
+    Guard g(c);
+    for (uint32_t i = 0; i < n_polys; ++i) {
+        int rc = ntt_run_dev(c, curve_id, kind, log_n, d_ins[i], in_lens[i], d_outs[i]);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+
+int zk_ntt_prepare(zk_ctx* c, int curve_id, uint32_t log_n) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    if (log_n > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
+    Guard g(c);
+    return ntt_prepare(c, curve_id, log_n);
+}
+
+int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in, size_t in_len, uint64_t* out) {
+    if (!c || !out || (!in && in_len)) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    if (log_n > 32) return ZK_ERR_DOMAIN_TOO_LARGE;
+    Guard g(c);
+    const size_t n = (size_t)1 << log_n;
+    if (in_len > n) return ZK_ERR_BAD_ARG;
+    int rc;
+    if ((rc = c->io_a.ensure((in_len ? in_len : 1) * 32))) return rc;
+    if ((rc = c->io_b.ensure(n * 32))) return rc;
+    if (in_len) ZK_HIP_TRY(hipMemcpyAsync(c->io_a.p, in, in_len * 32, hipMemcpyHostToDevice, c->stream));
+    rc = ntt_run_dev(c, curve_id, kind, log_n, c->io_a.p, in_len, c->io_b.p);
+    if (rc) return rc;
+    ZK_HIP_TRY(hipMemcpyAsync(out, c->io_b.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_fr_from_mont_dev(zk_ctx* c, int curve_id, const void* d_in, size_t n, void* d_out) {
+    if (!c || (n && (!d_in || !d_out))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return fr_convert_dev(c, curve_id, 0, d_in, n, d_out);
+}
+int zk_fr_to_mont_dev(zk_ctx* c, int curve_id, const void* d_in, size_t n, void* d_out) {
+    if (!c || (n && (!d_in || !d_out))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return fr_convert_dev(c, curve_id, 1, d_in, n, d_out);
+}
+int zk_fr_mul_dev(zk_ctx* c, int curve_id, const void* d_a, const void* d_b, size_t n, void* d_out) {
+    if (!c || (n && (!d_a || !d_b || !d_out))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return fr_mul_dev(c, curve_id, d_a, d_b, n, d_out);
+}
+
+// ------------------------------------------------------------------------------------------ MSM
+int zk_srs_register_dev(zk_ctx* c, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out) {
+    if (!c || !out || (n && !d_bases_xy)) return ZK_ERR_BAD_ARG;
+    int L = fq_limbs64(curve_id);
+    if (!L) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    zk_srs* s = new zk_srs();
+    s->ctx = c;
+    s->curve = curve_id;
+    s->n = n;
+    size_t bytes = n * 2 * L * 8;
+    if (n) {
+        hipError_t e = hipMalloc(&s->d_xy, bytes);
+        if (e != hipSuccess) {
+            delete s;
+            return ZK_ERR_OOM;
+        }
+        e = hipMemcpyAsync(s->d_xy, d_bases_xy, bytes, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(s->d_xy);
+            delete s;
+            return ZK_ERR_HIP;
+        }
+    }
+    *out = s;
+    return ZK_OK;
+}
+
+int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out) {
+    if (!c || !out || (n && !bases_xy)) return ZK_ERR_BAD_ARG;
+    int L = fq_limbs64(curve_id);
+    if (!L) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    zk_srs* s = new zk_srs();
+    s->ctx = c;
+    s->curve = curve_id;
+    s->n = n;
+    size_t bytes = n * 2 * L * 8;
+    if (n) {
+        if (hipMalloc(&s->d_xy, bytes) != hipSuccess) {
+            delete s;
+            return ZK_ERR_OOM;
+        }
+        hipError_t e = hipMemcpyAsync(s->d_xy, bases_xy, bytes, hipMemcpyHostToDevice, c->stream);
+        int rc = ZK_OK;
+        if (e == hipSuccess && inf_flags) {
+            rc = c->msm_tmp.ensure(n);
+            if (!rc) {
+                e = hipMemcpyAsync(c->msm_tmp.p, inf_flags, n, hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) rc = msm_sanitize_bases_dev(c, curve_id, s->d_xy, (const uint8_t*)c->msm_tmp.p, n);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess || rc) {
+            (void)hipFree(s->d_xy);
+            delete s;
+            return rc ? rc : ZK_ERR_HIP;
+        }
+    }
+    *out = s;
+    return ZK_OK;
+}
+
+void zk_srs_free(zk_srs* s) {
+    if (!s) return;
+    if (s->d_xy) {
+        Guard g(s->ctx);
+        (void)hipStreamSynchronize(s->ctx->stream);
+        (void)hipFree(s->d_xy);
+    }
+    delete s;
+}
+
+size_t zk_srs_len(const zk_srs* s) { return s ? s->n : 0; }
+
+static int srs_slice(zk_srs* s, size_t base_offset, size_t n, const void** d_bases) {
+    if (!s) return ZK_ERR_BAD_ARG;
+    if (base_offset > s->n || n > s->n - base_offset) return ZK_ERR_BAD_ARG;
+    int L = fq_limbs64(s->curve);
+    *d_bases = (const char*)s->d_xy + base_offset * 2 * L * 8;
+    return ZK_OK;
+}
+
+int zk_msm_g1_srs_partial_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    if (!c || !s || s->ctx != c || !out_xyz || (n && !d_scalars)) return ZK_ERR_BAD_ARG;
+    const void* d_bases = nullptr;
+    int rc = srs_slice(s, base_offset, n, &d_bases);
+    if (rc) return rc;
+    Guard g(c);
+    return msm_run_dev(c, s->curve, d_bases, d_scalars, n, out_xyz);
+}
+
+int zk_msm_g1_srs_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!out_xy) return ZK_ERR_BAD_ARG;
+    uint64_t xyz[18];
+    int rc = zk_msm_g1_srs_partial_dev(c, s, base_offset, d_scalars, n, xyz);
+    if (rc) return rc;
+    return finish_point(s->curve, xyz, out_xy, out_inf);
+}
+
+int zk_msm_g1_srs(zk_ctx* c, zk_srs* s, size_t base_offset, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->ctx != c || !out_xy || (n && !scalars)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    {
+        int rc = c->msm_scalars.ensure((n ? n : 1) * 32);
+        if (rc) return rc;
+        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->msm_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    return zk_msm_g1_srs_dev(c, s, base_offset, c->msm_scalars.p, n, out_xy, out_inf);
+}
+
+int zk_msm_g1(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, const uint64_t* scalars, size_t n,
+              uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !out_xy || (n && (!bases_xy || !scalars))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    zk_srs* s = nullptr;
+    int rc = zk_srs_register(c, curve_id, bases_xy, inf_flags, n, &s);
+    if (rc) return rc;
+    rc = zk_msm_g1_srs(c, s, 0, scalars, n, out_xy, out_inf);
+    zk_srs_free(s);
+    return rc;
+}
+
+int zk_g1_sum_partials(int curve_id, const uint64_t* partials_xyz, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!out_xy || (count && !partials_xyz)) return ZK_ERR_BAD_ARG;
+    return g1_sum_partials_host(curve_id, partials_xyz, count, out_xy, out_inf);
+}
+
+// ------------------------------------------------------------------------------------ KZG commit
+int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->ctx != c || !out_xy || (n && !d_coeffs_mont)) return ZK_ERR_BAD_ARG;
+    if (n > s->n) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    {
+        int rc = c->msm_scalars.ensure((n ? n : 1) * 32);
+        if (rc) return rc;
+        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont, n, c->msm_scalars.p);
+        if (rc) return rc;
+    }
+    return zk_msm_g1_srs_dev(c, s, 0, c->msm_scalars.p, n, out_xy, out_inf);
+}
+
+int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->ctx != c || !out_xy || (n && !coeffs_mont)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    {
+        int rc = c->io_a.ensure((n ? n : 1) * 32);
+        if (rc) return rc;
+        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->io_a.p, coeffs_mont, n * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    return zk_kzg_commit_dev(c, s, c->io_a.p, n, out_xy, out_inf);
+}
+
+int zk_kzg_open_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
+                    const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->ctx != c || !out_xy || !z_mont || !challenge_mont || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
+    void* d_w = nullptr;
+    size_t wlen = 0;
+    Guard g(c);
+    {
+        int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
+        if (rc) return rc;
+    }
+    if (wlen > s->n) return ZK_ERR_BAD_ARG;
+    return zk_msm_g1_srs_dev(c, s, 0, d_w, wlen, out_xy, out_inf);
+}
+
+// ------------------------------------------------------------------------------------- utilities
+int zk_g1_fixed_base_batch_dev(zk_ctx* c, int curve_id, const void* d_scalars, size_t n, void* d_out_xy) {
+    if (!c || (n && (!d_scalars || !d_out_xy))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return msm_fixed_base_dev(c, curve_id, d_scalars, n, d_out_xy);
+}
+
+int zk_dev_alloc(zk_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    *d_ptr = nullptr;
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return ZK_ERR_OOM;
+    return ZK_OK;
+}
+int zk_dev_free(zk_ctx* c, void* d_ptr) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (d_ptr) ZK_HIP_TRY(hipFree(d_ptr));
+    return ZK_OK;
+}
+int zk_dev_upload(zk_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !h_src))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (bytes) ZK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+int zk_dev_download(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    if (!c || (bytes && (!h_dst || !d_src))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (bytes) ZK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+}  // extern "C"

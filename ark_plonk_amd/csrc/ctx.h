@@ -1,0 +1,152 @@
+// Internal context shared by the NTT / MSM translation units.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <utility>
+
+#include "../../include/ark_plonk_amd.h"
+#include "curve_params.h"
+#include "ec.cuh"
+
+typedef Fp<FrBls12_381Params> FrBls;
+typedef Fp<FqBls12_381Params> FqBls;
+typedef Fp<FrBn254Params> FrBn;
+typedef Fp<FqBn254Params> FqBn;
+
+struct CurveBls {
+    typedef FrBls Fr;
+    typedef FqBls Fq;
+    typedef FrBls12_381Params FrP;
+    typedef FqBls12_381Params FqP;
+    static constexpr int ID = ZK_CURVE_BLS12_381;
+};
+struct CurveBn {
+    typedef FrBn Fr;
+    typedef FqBn Fq;
+    typedef FrBn254Params FrP;
+    typedef FqBn254Params FqP;
+    static constexpr int ID = ZK_CURVE_BN254;
+};
+
+#define ZK_HIP_TRY(expr)                                  \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) {                           \
+            zk_note_hip_error(_e, #expr, __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP; \
+        }                                                 \
+    } while (0)
+
+void zk_note_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+// device buffer that grows on demand and is reused across calls (no hipMalloc in steady state)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return ZK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return ZK_ERR_OOM;
+        }
+        cap = want;
+        return ZK_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ProfEntry {
+    double total_ms = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+// one NTT plan = twiddle tables of one (curve, log_n, direction)
+struct NttPlan {
+    int curve = 0;
+    uint32_t log_n = 0;
+    bool inverse = false;
+    int n_pass = 0;
+    int s[4] = {0, 0, 0, 0};                 // pass radix exponents, sum = log_n
+    void* tw_inner[4] = {nullptr, nullptr, nullptr, nullptr};  // omega_{2^s}^j, j < 2^s/2  (shared, not owned)
+    void* tw_pass[4] = {nullptr, nullptr, nullptr, nullptr};   // inter-pass tables (owned)
+    ~NttPlan() {
+        for (int i = 0; i < 4; ++i)
+            if (tw_pass[i]) (void)hipFree(tw_pass[i]);
+    }
+};
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::recursive_mutex mu;
+    int msm_window = 0;  // 0 = auto
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+
+    // NTT state
+    std::map<uint64_t, NttPlan*> plans;          // key = curve<<40 | inverse<<32 | log_n
+    std::map<uint64_t, void*> inner_tw;          // key = curve<<40 | inverse<<32 | s
+    DevBuf ntt_work;                             // N-element scratch between passes
+    DevBuf coset_pow[2];                         // per curve: g^j
+    DevBuf coset_inv_pow[2];                     // per curve: g^-j
+    size_t coset_len[2] = {0, 0};
+    size_t coset_inv_len[2] = {0, 0};
+    DevBuf io_a, io_b;                           // staging for the host-buffer entry points
+
+    // MSM state
+    DevBuf msm_counts, msm_offsets, msm_entries, msm_buckets, msm_part_pt, msm_part_key;
+    DevBuf msm_seg, msm_win, msm_scalars, msm_tmp;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+struct zk_srs {
+    zk_ctx* ctx = nullptr;
+    int curve = 0;
+    size_t n = 0;
+    void* d_xy = nullptr;   // n x 2L limbs, Montgomery; infinity encoded as x = y = 0
+};
+
+// profiling helpers (ctx mutex held by caller)
+struct ProfScope {
+    zk_ctx* c;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(zk_ctx* ctx, const char* nm);
+    ~ProfScope();
+};
+void zk_prof_collect(zk_ctx* c);
+
+// implemented in ntt.hip / msm.hip
+int ntt_run_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out);
+int ntt_prepare(zk_ctx* c, int curve, uint32_t log_n);
+void ntt_ctx_free(zk_ctx* c);
+int fr_convert_dev(zk_ctx* c, int curve, int to_mont, const void* d_in, size_t n, void* d_out);
+int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, void* out);
+
+// MSM over device bases/scalars; writes per-window sums back to host and combines there.
+// out_xyz: Jacobian (X,Y,Z) 3L u64 limbs on host.
+int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);
+int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy);
+int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_inf, size_t n);
+int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
+int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
+                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);

@@ -1,0 +1,564 @@
+// Pippenger (bucket method) multi-scalar multiplication over G1 for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI, ark_ec 0.3 `VariableBaseMSM::multi_scalar_mul` as called by the
+// reference at plonk-core/src/commitment.rs:45,83 and through every `PC::commit` / `PC::open`
+// (proof_system/prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,582-591,606,609-618).
+//
+// Pipeline (all on the ctx stream; no host round trip until the W window sums are read back):
+//   1. msm_count      signed c-bit digits of every scalar -> per-(window,bucket) histogram
+//   2. msm_scan       exclusive scan of the histogram -> bucket offsets (+ scatter cursors)
+//   3. msm_scatter    counting-sort the (point, sign) references by (window, bucket)
+//   4. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
+//                     additions (8M+2S, no inversion); runs that cross a chunk edge are emitted
+//                     as partials (load-balanced regardless of the scalar distribution)
+//   5. msm_combine    joins the chunk-edge partials of each bucket
+//   6. msm_seg_reduce per-window segmented running-sum reduction (sum_j j*B_j), level 1
+//   7. msm_win_finish per-window LDS suffix-scan + tree reduction -> W window sums
+//   host: Horner over the W window sums (W*c doublings) and affine normalisation.
+// The group sum is order-independent, so the non-deterministic order inside a bucket (atomic
+// cursors) does not change the (canonical, affine) result.
+// Algorithmic bytes per MSM: N * (32 + 2*Fq bytes); the kernel is integer-VALU bound.
+#include "ctx.h"
+
+namespace {
+
+template <class Fq>
+ZK_D Fq ld_fq(const uint4* q) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < Fq::N / 4; ++i) {
+        uint4 a = q[i];
+        r.v[4 * i + 0] = a.x; r.v[4 * i + 1] = a.y; r.v[4 * i + 2] = a.z; r.v[4 * i + 3] = a.w;
+    }
+    return r;
+}
+template <class Fq>
+ZK_D void st_fq(uint4* q, const Fq& r) {
+#pragma unroll
+    for (int i = 0; i < Fq::N / 4; ++i) q[i] = make_uint4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
+}
+template <class Fq>
+ZK_D Affine<Fq> ld_affine(const void* bases, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(bases) + idx * (2 * Fq::N / 4);
+    Affine<Fq> p;
+    p.x = ld_fq<Fq>(q);
+    p.y = ld_fq<Fq>(q + Fq::N / 4);
+    return p;
+}
+template <class Fq>
+ZK_D void st_affine(void* bases, uint64_t idx, const Affine<Fq>& p) {
+    uint4* q = reinterpret_cast<uint4*>(bases) + idx * (2 * Fq::N / 4);
+    st_fq<Fq>(q, p.x);
+    st_fq<Fq>(q + Fq::N / 4, p.y);
+}
+template <class Fq>
+ZK_D XYZZ<Fq> ld_xyzz(const void* arr, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(arr) + idx * (4 * Fq::N / 4);
+    XYZZ<Fq> p;
+    p.x = ld_fq<Fq>(q);
+    p.y = ld_fq<Fq>(q + Fq::N / 4);
+    p.zz = ld_fq<Fq>(q + 2 * (Fq::N / 4));
+    p.zzz = ld_fq<Fq>(q + 3 * (Fq::N / 4));
+    return p;
+}
+template <class Fq>
+ZK_D void st_xyzz(void* arr, uint64_t idx, const XYZZ<Fq>& p) {
+    uint4* q = reinterpret_cast<uint4*>(arr) + idx * (4 * Fq::N / 4);
+    st_fq<Fq>(q, p.x);
+    st_fq<Fq>(q + Fq::N / 4, p.y);
+    st_fq<Fq>(q + 2 * (Fq::N / 4), p.zz);
+    st_fq<Fq>(q + 3 * (Fq::N / 4), p.zzz);
+}
+
+struct MsmGeom {
+    uint32_t c;        // window bits
+    uint32_t W;        // windows
+    uint32_t B;        // buckets per window = 2^(c-1)
+    uint32_t nb;       // W * B
+    uint32_t logG;     // level-1 segment = 2^logG buckets
+    uint32_t ns;       // segments per window
+    uint32_t logq;     // level-2: 2^logq segments per lane
+};
+
+// c-bit field of a canonical scalar (8 x u32 limbs in global memory) at bit position pos
+ZK_D uint32_t scalar_bits(const uint32_t* s, uint32_t pos, uint32_t c) {
+    uint32_t limb = pos >> 5, off = pos & 31;
+    uint64_t lo = limb < 8 ? s[limb] : 0u;
+    uint64_t hi = (limb + 1) < 8 ? s[limb + 1] : 0u;
+    uint64_t v = ((hi << 32) | lo) >> off;
+    return (uint32_t)v & ((1u << c) - 1u);
+}
+
+// Passes over the signed digits of scalar i.  MODE 0: histogram, MODE 1: scatter.
+template <int MODE>
+__global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, uint32_t* counts_or_cursor, uint32_t* entries) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = scalars + 8 * i;
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (g.c - 1);
+    for (uint32_t w = 0; w < g.W; ++w) {
+        uint32_t raw = scalar_bits(s, w * g.c, g.c) + carry;
+        uint32_t neg = raw > half ? 1u : 0u;
+        uint32_t mag = neg ? (1u << g.c) - raw : raw;
+        carry = neg;
+        if (mag == 0) continue;
+        uint32_t bucket = w * g.B + (mag - 1);
+        if (MODE == 0) {
+            atomicAdd(&counts_or_cursor[bucket], 1u);
+        } else {
+            uint32_t pos = atomicAdd(&counts_or_cursor[bucket], 1u);
+            entries[pos] = (uint32_t)i | (neg << 31);
+        }
+    }
+}
+
+// single-workgroup exclusive scan: offsets[0..n] and cursor[0..n)
+__global__ void msm_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, uint32_t* cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    const uint32_t chunk = (n + T - 1) / T;
+    const uint32_t b = t * chunk, e = min(n, b + chunk);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;  // exclusive prefix of this chunk
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t cnt = counts[i];
+        offsets[i] = run;
+        cursor[i] = run;
+        run += cnt;
+    }
+    if (t == T - 1) offsets[n] = part[T - 1];
+}
+
+template <class Fq>
+ZK_D bool affine_is_null(const Affine<Fq>& p) { return p.x.is_zero() && p.y.is_zero(); }
+
+// Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
+template <class Fq>
+__global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
+                               void* buckets, void* part_pt, int32_t* part_key, uint32_t L, uint32_t n_lanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lanes) return;
+    const uint32_t E = offsets[nb];
+    const uint64_t e0 = (uint64_t)t * L;
+    if (e0 >= E) {
+        part_key[2 * t] = -1;
+        part_key[2 * t + 1] = -1;
+        return;
+    }
+    const uint32_t e1 = (uint32_t)min((uint64_t)E, e0 + L);
+    // largest b with offsets[b] <= e0
+    uint32_t lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= (uint32_t)e0) lo = mid; else hi = mid - 1;
+    }
+    uint32_t b = lo;
+    uint32_t bend = offsets[b + 1];
+    const bool head_partial = offsets[b] < (uint32_t)e0;
+    bool first_run = true;
+    int32_t key0 = -1;
+    XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+    for (uint32_t e = (uint32_t)e0; e < e1; ++e) {
+        if (e == bend) {
+            if (first_run && head_partial) {
+                st_xyzz<Fq>(part_pt, 2ull * t, acc);
+                key0 = (int32_t)b;
+            } else {
+                st_xyzz<Fq>(buckets, b, acc);
+            }
+            first_run = false;
+            acc = XYZZ<Fq>::infinity();
+            do {
+                ++b;
+                bend = offsets[b + 1];
+            } while (bend <= e);
+        }
+        const uint32_t ref = entries[e];
+        Affine<Fq> p = ld_affine<Fq>(bases, ref & 0x7fffffffu);
+        if (ref >> 31) p.y = Fq::neg(p.y);
+        if (!affine_is_null(p)) acc = XYZZ<Fq>::madd(acc, p);
+    }
+    const bool tail_complete = (e1 == bend);
+    int32_t key1 = -1;
+    if (first_run) {
+        if (head_partial || !tail_complete) {
+            st_xyzz<Fq>(part_pt, 2ull * t, acc);
+            key0 = (int32_t)b;
+        } else {
+            st_xyzz<Fq>(buckets, b, acc);
+        }
+    } else {
+        if (tail_complete) {
+            st_xyzz<Fq>(buckets, b, acc);
+        } else {
+            st_xyzz<Fq>(part_pt, 2ull * t + 1, acc);
+            key1 = (int32_t)b;
+        }
+    }
+    part_key[2 * t] = key0;
+    part_key[2 * t + 1] = key1;
+}
+
+// one lane per partial slot; the first slot of each key sums the slots that follow with that key
+template <class Fq>
+__global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const int32_t* part_key, uint32_t n_slots, void* buckets) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const int32_t k = part_key[s];
+    if (k < 0) return;
+    int64_t p = (int64_t)s - 1;
+    while (p >= 0 && part_key[p] < 0) --p;
+    if (p >= 0 && part_key[p] == k) return;
+    XYZZ<Fq> acc = ld_xyzz<Fq>(part_pt, s);
+    for (uint32_t q = s + 1; q < n_slots; ++q) {
+        const int32_t kq = part_key[q];
+        if (kq < 0) continue;
+        if (kq != k) break;
+        acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, q));
+    }
+    st_xyzz<Fq>(buckets, (uint32_t)k, acc);
+}
+
+// level 1 of the per-window reduction: segment s of window w covers buckets [s*G, (s+1)*G)
+//   run = sum B_i ; acc = sum (i+1) * B_i   (i local index)
+template <class Fq>
+__global__ void __launch_bounds__(128) msm_seg_reduce(const void* buckets, const uint32_t* offsets, MsmGeom g, void* seg_run, void* seg_acc) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= g.W * g.ns) return;
+    const uint32_t w = id / g.ns, s = id % g.ns;
+    const uint32_t G = 1u << g.logG;
+    XYZZ<Fq> run = XYZZ<Fq>::infinity(), acc = XYZZ<Fq>::infinity();
+    for (int i = (int)G - 1; i >= 0; --i) {
+        const uint32_t bi = w * g.B + s * G + (uint32_t)i;
+        if (offsets[bi + 1] != offsets[bi]) run = XYZZ<Fq>::add(run, ld_xyzz<Fq>(buckets, bi));
+        acc = XYZZ<Fq>::add(acc, run);
+    }
+    st_xyzz<Fq>(seg_run, id, run);
+    st_xyzz<Fq>(seg_acc, id, acc);
+}
+
+template <class Fq>
+ZK_D XYZZ<Fq> lds_ld(const uint4* sh, uint32_t u) {
+    return ld_xyzz<Fq>(sh, u);
+}
+
+// level 2: one 256-lane workgroup per window.
+//   S_w = sum_s acc_s + G * sum_s s * run_s
+template <class Fq>
+__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, void* win_out) {
+    extern __shared__ uint4 sh[];
+    const uint32_t w = blockIdx.x, u = threadIdx.x;
+    const uint32_t q = 1u << g.logq;
+    typedef XYZZ<Fq> P;
+    P A = P::infinity(), V = P::infinity(), tsum = P::infinity(), R = P::infinity();
+    for (int v = (int)q - 1; v >= 0; --v) {
+        const uint32_t s = u * q + (uint32_t)v;
+        P x = P::infinity();
+        if (s < g.ns) {
+            x = ld_xyzz<Fq>(seg_run, (uint64_t)w * g.ns + s);
+            A = P::add(A, ld_xyzz<Fq>(seg_acc, (uint64_t)w * g.ns + s));
+        }
+        if (v >= 1) {
+            tsum = P::add(tsum, x);
+            V = P::add(V, tsum);
+        } else {
+            R = P::add(tsum, x);
+        }
+    }
+    // Y = A + G * V
+    for (uint32_t k = 0; k < g.logG; ++k) V = P::dbl(V);
+    P Y = P::add(A, V);
+    // suffix sums Q_u = sum_{u' >= u} R_u'  (Hillis-Steele in LDS)
+    st_xyzz<Fq>(sh, u, R);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        __syncthreads();
+        P o = P::infinity();
+        if (u + d < 256) o = lds_ld<Fq>(sh, u + d);
+        __syncthreads();
+        R = P::add(R, o);
+        st_xyzz<Fq>(sh, u, R);
+    }
+    // Z = Y + (G*q) * Q_u   (u >= 1)
+    P Z = Y;
+    if (u >= 1) {
+        P Qm = R;
+        for (uint32_t k = 0; k < g.logG + g.logq; ++k) Qm = P::dbl(Qm);
+        Z = P::add(Z, Qm);
+    }
+    __syncthreads();
+    st_xyzz<Fq>(sh, u, Z);
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        __syncthreads();
+        if (u < d) {
+            Z = P::add(Z, lds_ld<Fq>(sh, u + d));
+            st_xyzz<Fq>(sh, u, Z);
+        }
+    }
+    if (u == 0) st_xyzz<Fq>(win_out, w, Z);
+}
+
+// out[i] = scalars[i] * G  (double-and-add from the top bit; per-lane Fermat inversion to affine)
+template <class Cv>
+__global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, uint64_t n, void* out_xy) {
+    typedef typename Cv::Fq Fq;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<Fq> G;
+#pragma unroll
+    for (int k = 0; k < Fq::N; ++k) { G.x.v[k] = Cv::FqP::GX(k); G.y.v[k] = Cv::FqP::GY(k); }
+    const uint32_t* s = scalars + 8 * i;
+    XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+    for (int limb = 7; limb >= 0; --limb) {
+        const uint32_t word = s[limb];
+        for (int b = 31; b >= 0; --b) {
+            acc = XYZZ<Fq>::dbl(acc);
+            if ((word >> b) & 1u) acc = XYZZ<Fq>::madd(acc, G);
+        }
+    }
+    Affine<Fq> o;
+    acc.to_affine(o);  // infinity -> (0,0), the device encoding of "no point"
+    st_affine<Fq>(out_xy, i, o);
+}
+
+// zero the coordinates of flagged-infinity bases (device encoding of infinity is x = y = 0)
+__global__ void sanitize_bases(void* xy, const uint8_t* inf, uint64_t n, uint32_t u4_per_point) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !inf[i]) return;
+    uint4* q = reinterpret_cast<uint4*>(xy) + i * u4_per_point;
+    for (uint32_t k = 0; k < u4_per_point; ++k) q[k] = make_uint4(0, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------- host side
+uint32_t ilog2_floor(uint64_t x) {
+    uint32_t r = 0;
+    while (x >>= 1) ++r;
+    return r;
+}
+
+MsmGeom make_geom(uint64_t n, int bits, int c_override) {
+    MsmGeom g;
+    uint32_t c;
+    if (c_override > 0) {
+        c = (uint32_t)c_override;
+    } else {
+        uint32_t lg = ilog2_floor(n ? n : 1);
+        c = lg > 4 ? lg - 4 : 0;
+        if (c < 3) c = 3;
+        if (c > 16) c = 16;
+    }
+    if (c < 2) c = 2;
+    if (c > 20) c = 20;
+    g.c = c;
+    g.W = (uint32_t)bits / c + 1;
+    g.B = 1u << (c - 1);
+    g.nb = g.W * g.B;
+    g.logG = c - 1 < 4 ? c - 1 : 4;
+    g.ns = g.B >> g.logG;
+    uint32_t per = (g.ns + 255) / 256;
+    g.logq = 0;
+    while ((1u << g.logq) < per) ++g.logq;
+    return g;
+}
+
+constexpr uint32_t CHUNK_L = 32;
+
+template <class Cv>
+int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    typedef typename Cv::Fq Fq;
+    typedef XYZZ<Fq> P;
+    constexpr int L64 = Fq::N / 2;
+    if (n == 0) {
+        memset(out_xyz, 0, sizeof(uint64_t) * 3 * L64);
+        return ZK_OK;
+    }
+    if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+    MsmGeom g = make_geom(n, Cv::FrP::BITS, c->msm_window);
+    const uint64_t e_max = (uint64_t)n * g.W;
+    if (e_max >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;
+    const uint32_t n_lanes = (uint32_t)((e_max + CHUNK_L - 1) / CHUNK_L);
+    int rc;
+    if ((rc = c->msm_counts.ensure((size_t)g.nb * 4))) return rc;
+    if ((rc = c->msm_offsets.ensure((size_t)(g.nb + 1) * 4 * 2))) return rc;
+    if ((rc = c->msm_entries.ensure((size_t)e_max * 4))) return rc;
+    if ((rc = c->msm_buckets.ensure((size_t)g.nb * sizeof(P)))) return rc;
+    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * sizeof(P)))) return rc;
+    if ((rc = c->msm_part_key.ensure((size_t)n_lanes * 2 * 4))) return rc;
+    if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * sizeof(P)))) return rc;
+    if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(P)))) return rc;
+    uint32_t* counts = (uint32_t*)c->msm_counts.p;
+    uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
+    uint32_t* cursor = offsets + (g.nb + 1);
+    uint32_t* entries = (uint32_t*)c->msm_entries.p;
+    void* seg_run = c->msm_seg.p;
+    void* seg_acc = (char*)c->msm_seg.p + (size_t)g.W * g.ns * sizeof(P);
+    hipStream_t st = c->stream;
+
+    {
+        ProfScope ps(c, "msm_sort");
+        ZK_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)g.nb * 4, st));
+        const int T = 256;
+        unsigned blocks = (unsigned)((n + T - 1) / T);
+        hipLaunchKernelGGL(msm_digits<0>, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, counts, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, st, counts, g.nb, offsets, cursor);
+        hipLaunchKernelGGL(msm_digits<1>, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, cursor, entries);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "msm_accumulate");
+        const int T = 128;
+        unsigned blocks = (n_lanes + T - 1) / T;
+        hipLaunchKernelGGL(msm_accumulate<Fq>, dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
+                           c->msm_part_pt.p, (int32_t*)c->msm_part_key.p, CHUNK_L, n_lanes);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "msm_reduce");
+        const int T = 128;
+        unsigned blocks = (2 * n_lanes + T - 1) / T;
+        hipLaunchKernelGGL(msm_combine<Fq>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, (const int32_t*)c->msm_part_key.p, 2 * n_lanes,
+                           c->msm_buckets.p);
+        unsigned sblocks = (g.W * g.ns + T - 1) / T;
+        hipLaunchKernelGGL(msm_seg_reduce<Fq>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
+        size_t shmem = 256 * sizeof(P);
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish<Fq>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, c->msm_win.p);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    // window sums -> host, Horner (high window first), Jacobian out
+    std::vector<P> win(g.W);
+    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)g.W * sizeof(P), hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipStreamSynchronize(st));
+    P total = P::infinity();
+    for (int w = (int)g.W - 1; w >= 0; --w) {
+        for (uint32_t k = 0; k < g.c; ++k) total = P::dbl(total);
+        total = P::add(total, win[w]);
+    }
+    // XYZZ -> Jacobian (X*ZZ, Y*ZZZ, ZZ):  x = X/ZZ = X*ZZ/ZZ^2, y = Y/ZZZ = Y*ZZZ/ZZ^3
+    Fq X = Fq::zero(), Y = Fq::zero(), Z = Fq::zero();
+    if (!total.is_inf()) {
+        X = Fq::mul(total.x, total.zz);
+        Y = Fq::mul(total.y, total.zzz);
+        Z = total.zz;
+    } else {
+        X = Fq::one();
+        Y = Fq::one();
+    }
+    memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
+    return ZK_OK;
+}
+
+template <class Fq>
+int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    constexpr int L64 = Fq::N / 2;
+    Fq X, Y, Z;
+    memcpy(X.v, xyz, sizeof(uint64_t) * L64);
+    memcpy(Y.v, xyz + L64, sizeof(uint64_t) * L64);
+    memcpy(Z.v, xyz + 2 * L64, sizeof(uint64_t) * L64);
+    if (Z.is_zero()) {
+        // GroupAffine::zero() = (0, 1, infinity = true)
+        Fq zero = Fq::zero(), one = Fq::one();
+        memcpy(out_xy, zero.v, sizeof(uint64_t) * L64);
+        memcpy(out_xy + L64, one.v, sizeof(uint64_t) * L64);
+        if (out_inf) *out_inf = 1;
+        return ZK_OK;
+    }
+    Fq zi = Fq::inverse(Z);
+    Fq zi2 = Fq::sqr(zi);
+    Fq x = Fq::mul(X, zi2);
+    Fq y = Fq::mul(Y, Fq::mul(zi2, zi));
+    memcpy(out_xy, x.v, sizeof(uint64_t) * L64);
+    memcpy(out_xy + L64, y.v, sizeof(uint64_t) * L64);
+    if (out_inf) *out_inf = 0;
+    return ZK_OK;
+}
+
+// Jacobian (X, Y, Z) -> XYZZ (X, Y, Z^2, Z^3)
+template <class Fq>
+XYZZ<Fq> jac_to_xyzz(const uint64_t* xyz) {
+    constexpr int L64 = Fq::N / 2;
+    XYZZ<Fq> p;
+    Fq Z;
+    memcpy(p.x.v, xyz, sizeof(uint64_t) * L64);
+    memcpy(p.y.v, xyz + L64, sizeof(uint64_t) * L64);
+    memcpy(Z.v, xyz + 2 * L64, sizeof(uint64_t) * L64);
+    p.zz = Fq::sqr(Z);
+    p.zzz = Fq::mul(p.zz, Z);
+    return p;
+}
+
+template <class Fq>
+int sum_partials(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    constexpr int L64 = Fq::N / 2;
+    XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+    for (size_t i = 0; i < count; ++i) acc = XYZZ<Fq>::add(acc, jac_to_xyzz<Fq>(partials + i * 3 * L64));
+    Affine<Fq> a;
+    bool fin = acc.to_affine(a);
+    if (!fin) {
+        Fq one = Fq::one();
+        memset(out_xy, 0, sizeof(uint64_t) * L64);
+        memcpy(out_xy + L64, one.v, sizeof(uint64_t) * L64);
+        if (out_inf) *out_inf = 1;
+        return ZK_OK;
+    }
+    memcpy(out_xy, a.x.v, sizeof(uint64_t) * L64);
+    memcpy(out_xy + L64, a.y.v, sizeof(uint64_t) * L64);
+    if (out_inf) *out_inf = 0;
+    return ZK_OK;
+}
+
+}  // namespace
+
+int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    if (curve == ZK_CURVE_BLS12_381) return msm_run<CurveBls>(c, d_bases_xy, d_scalars, n, out_xyz);
+    if (curve == ZK_CURVE_BN254) return msm_run<CurveBn>(c, d_bases_xy, d_scalars, n, out_xyz);
+    return ZK_ERR_BAD_ARG;
+}
+
+int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy) {
+    if (n == 0) return ZK_OK;
+    const int T = 128;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    if (curve == ZK_CURVE_BLS12_381)
+        hipLaunchKernelGGL(g1_fixed_base<CurveBls>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
+    else if (curve == ZK_CURVE_BN254)
+        hipLaunchKernelGGL(g1_fixed_base<CurveBn>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
+    else
+        return ZK_ERR_BAD_ARG;
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_inf, size_t n) {
+    if (n == 0 || !d_inf) return ZK_OK;
+    uint32_t u4 = curve == ZK_CURVE_BLS12_381 ? 6 : 4;
+    const int T = 256;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    hipLaunchKernelGGL(sanitize_bases, dim3(blocks), dim3(T), 0, c->stream, d_xy, d_inf, (uint64_t)n, u4);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    if (curve == ZK_CURVE_BLS12_381) return jac_to_affine<FqBls>(xyz, out_xy, out_inf);
+    if (curve == ZK_CURVE_BN254) return jac_to_affine<FqBn>(xyz, out_xy, out_inf);
+    return ZK_ERR_BAD_ARG;
+}
+
+int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (curve == ZK_CURVE_BLS12_381) return sum_partials<FqBls>(partials, count, out_xy, out_inf);
+    if (curve == ZK_CURVE_BN254) return sum_partials<FqBn>(partials, count, out_xy, out_inf);
+    return ZK_ERR_BAD_ARG;
+}

@@ -1,0 +1,654 @@
+// Radix-2 NTT / iNTT / coset-NTT over the scalar field for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI, ark_poly 0.3 Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}
+// _in_place as called by the reference at plonk-core/src/proof_system/prover.rs:196-203,240-242,
+// 281-283,302-305, quotient_poly.rs:72-120,175-177,205,294,325, permutation/mod.rs:671-674,751,800.
+//
+// Algorithm (not ark's): a multi-pass Cooley-Tukey decomposition N = 2^s1 * 2^s2 (* 2^s3).  Each
+// pass loads a tile of 2^s rows x C columns, runs the 2^s-point DIF transform with 8 elements per
+// lane held in VGPRs (three radix-2 stages per LDS exchange), multiplies by the inter-pass twiddle
+// w_M^(col*k) read from a precomputed table laid out like the data (coalesced), and stores in
+// place.  The last pass gathers R adjacent output digits per workgroup so the natural-order store
+// is R*32 B contiguous (digit reversal costs no extra pass).  Inner twiddles w_L^j are staged in
+// LDS.  Zero-extension (in_len < N), the coset pre-scale g^j, the 1/N scale and the coset
+// post-scale g^-j are fused into the first / last pass.  HBM-side the transform is
+// 2 * N * 32 B algorithmic bytes; the kernel is integer-VALU bound (Montgomery products).
+#include "ctx.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+template <class Fr>
+ZK_D Fr ld_fr(const void* base, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <class Fr>
+ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+ZK_D uint32_t lds_pad(uint32_t slot) { return slot + ((slot >> 4) << 1); }
+
+template <class Fr>
+ZK_D void lds_put(uint4* lo, uint4* hi, uint32_t slot, const Fr& r) {
+    uint32_t p = lds_pad(slot);
+    lo[p] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    hi[p] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+template <class Fr>
+ZK_D Fr lds_get(const uint4* lo, const uint4* hi, uint32_t slot) {
+    uint32_t p = lds_pad(slot);
+    uint4 a = lo[p], b = hi[p];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+
+struct NttPassArgs {
+    const void* in;
+    void* out;
+    const void* tw_inner;   // L/2 entries w_L^j (or inverse)
+    const void* tw_pass;    // inter-pass table [k][col], nullptr on the last pass
+    const void* pre_mul;    // g^j table (first pass of coset_fft) or nullptr
+    const void* post_mul;   // g^-j table (last pass of coset_ifft) or nullptr
+    uint32_t scale[8];      // 1/N (single-pass inverse only)
+    int has_scale;
+    uint64_t in_len;        // valid elements of `in` (first pass); N otherwise
+    uint32_t log_n;
+    uint32_t logc;          // log2 of tile columns (non-final) / gathered blocks (final)
+    uint32_t log_m;         // non-final: log2 of the row stride M
+    uint32_t log_mprev;     // non-final: log2 of the block this pass transforms (M * L)
+    uint32_t s1;            // final: size (bits) of the most significant digit of the block index
+};
+
+__host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x) >> (32 - bits);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+#endif
+}
+
+// One window of up to three DIF stages on the 8 registers of a lane.
+//   B0   : lowest row bit covered by the window; element e <-> row bits [B0, B0+3)
+//   NST  : number of stages performed (row bits B0+NST-1 .. B0), 1..3
+template <class Fr, int S, int B0, int NST>
+ZK_D void dif_window(Fr (&x)[8], uint32_t v, const uint4* tw_lo, const uint4* tw_hi) {
+    const uint32_t vlow = v & ((1u << B0) - 1u);
+#pragma unroll
+    for (int lb = NST - 1; lb >= 0; --lb) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int beta = B0 + lb;                 // row bit paired by this stage
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (e & (1 << lb)) continue;
+            const int eo = e | (1 << lb);
+            // twiddle exponent: (row mod 2^beta) * 2^(S-1-beta)
+            const uint32_t rowlow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
+            const uint32_t j = rowlow << (S - 1 - beta);
+            Fr a = x[e], b = x[eo];
+            x[e] = Fr::add(a, b);
+            Fr d = Fr::sub(a, b);
+            uint4 wl = tw_lo[j], wh = tw_hi[j];
+            Fr w;
+            w.v[0] = wl.x; w.v[1] = wl.y; w.v[2] = wl.z; w.v[3] = wl.w;
+            w.v[4] = wh.x; w.v[5] = wh.y; w.v[6] = wh.z; w.v[7] = wh.w;
+            x[eo] = Fr::mul(d, w);
+        }
+    }
+}
+
+template <int B0>
+ZK_D uint32_t window_row(uint32_t v, uint32_t e) {
+    return ((v >> B0) << (B0 + 3)) | (e << B0) | (v & ((1u << B0) - 1u));
+}
+
+// Run all DIF stages of a 2^S-point transform.  On entry x[e] holds row e*(L/8)+v (window
+// B0 = S-3); on exit x[e] holds position row = 8*v+e of the bit-reversed-order result.
+// SLOT(row) maps a row of this lane's column to an LDS slot.
+template <class Fr, int S, int REM, class SlotFn>
+ZK_D void dif_all(Fr (&x)[8], uint32_t v, uint4* d_lo, uint4* d_hi, const uint4* tw_lo, const uint4* tw_hi, SlotFn slot) {
+    if constexpr (REM >= 3) {
+        constexpr int B0 = REM - 3;
+        dif_window<Fr, S, B0, 3>(x, v, tw_lo, tw_hi);
+        if constexpr (B0 > 0) {
+            constexpr int NB0 = (B0 >= 3) ? B0 - 3 : 0;
+            // exchange: write rows of this window, read rows of the next
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds_put<Fr>(d_lo, d_hi, slot(window_row<B0>(v, e)), x[e]);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = lds_get<Fr>(d_lo, d_hi, slot(window_row<NB0>(v, e)));
+            dif_all<Fr, S, B0, SlotFn>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
+        }
+    } else if constexpr (REM > 0) {
+        dif_window<Fr, S, 0, REM>(x, v, tw_lo, tw_hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------- non-final pass
+template <class Fr, int S>
+__global__ void ntt_pass_mid(NttPassArgs a) {
+    constexpr uint32_t L = 1u << S;
+    extern __shared__ uint4 smem[];
+    const uint32_t logc = a.logc;
+    const uint32_t C = 1u << logc;
+    const uint32_t nslots = lds_pad(L * C) + 2;
+    uint4* d_lo = smem;
+    uint4* d_hi = smem + nslots;
+    uint4* tw_lo = smem + 2 * nslots;
+    uint4* tw_hi = tw_lo + L / 2;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t T = blockDim.x;
+    for (uint32_t j = tid; j < L / 2; j += T) {
+        const uint4* q = reinterpret_cast<const uint4*>(a.tw_inner) + 2 * j;
+        tw_lo[j] = q[0];
+        tw_hi[j] = q[1];
+    }
+    const uint32_t c = tid & (C - 1);
+    const uint32_t v = tid >> logc;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t lcg = a.log_m - logc;                    // log2(column groups per block)
+    const uint64_t blk = tile >> lcg;
+    const uint64_t cg = tile & ((1ull << lcg) - 1);
+    const uint64_t col = (cg << logc) + c;
+    const uint64_t base = (blk << a.log_mprev) + col;
+
+    Fr x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t row = (uint64_t)e * (L / 8) + v;
+        const uint64_t idx = base + (row << a.log_m);
+        if (idx < a.in_len) {
+            x[e] = ld_fr<Fr>(a.in, idx);
+            if (a.pre_mul) x[e] = Fr::mul(x[e], ld_fr<Fr>(a.pre_mul, idx));
+        } else {
+            x[e] = Fr::zero();
+        }
+    }
+    __syncthreads();  // inner twiddles staged
+    auto slot = [=](uint32_t row) -> uint32_t { return (row << logc) | c; };
+    dif_all<Fr, S, S>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
+
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t row = (v << 3) | e;
+        const uint64_t k = bitrev32(row, S);
+        Fr w = ld_fr<Fr>(a.tw_pass, (k << a.log_m) + col);
+        st_fr<Fr>(a.out, base + (k << a.log_m), Fr::mul(x[e], w));
+    }
+}
+
+// -------------------------------------------------------------------------------------- final pass
+template <class Fr, int S>
+__global__ void ntt_pass_final(NttPassArgs a) {
+    constexpr uint32_t L = 1u << S;
+    extern __shared__ uint4 smem[];
+    const uint32_t logc = a.logc;
+    const uint32_t C = 1u << logc;
+    const uint32_t nslots = lds_pad(L * C) + 2;
+    uint4* d_lo = smem;
+    uint4* d_hi = smem + nslots;
+    uint4* tw_lo = smem + 2 * nslots;
+    uint4* tw_hi = tw_lo + L / 2;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t T = blockDim.x;
+    for (uint32_t j = tid; j < L / 2; j += T) {
+        const uint4* q = reinterpret_cast<const uint4*>(a.tw_inner) + 2 * j;
+        tw_lo[j] = q[0];
+        tw_hi[j] = q[1];
+    }
+    // block index digits: b = k1 * 2^log_rest + rho ; this tile gathers C consecutive k1
+    const uint32_t log_nb = a.log_n - S;
+    const uint32_t log_rest = log_nb - a.s1;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t lg = a.s1 - logc;
+    const uint64_t rho = tile >> lg;
+    const uint64_t g = tile & ((1ull << lg) - 1);
+
+    // load mapping: lanes run along the (contiguous) row axis
+    const uint32_t v = tid & (L / 8 - 1);
+    const uint32_t c = tid >> (S - 3);
+    const uint64_t k1 = (g << logc) + c;
+    const uint64_t b = (k1 << log_rest) | rho;
+    Fr x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t row = (uint64_t)e * (L / 8) + v;
+        const uint64_t idx = (b << S) + row;
+        if (idx < a.in_len) {
+            x[e] = ld_fr<Fr>(a.in, idx);
+            if (a.pre_mul) x[e] = Fr::mul(x[e], ld_fr<Fr>(a.pre_mul, idx));
+        } else {
+            x[e] = Fr::zero();
+        }
+    }
+    __syncthreads();
+    auto slot = [=](uint32_t row) -> uint32_t { return (c << S) | row; };
+    dif_all<Fr, S, S>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
+
+    // transpose through LDS so that stores run along the gathered-digit axis
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put<Fr>(d_lo, d_hi, slot((v << 3) | e), x[e]);
+    __syncthreads();
+    const uint32_t c2 = tid & (C - 1);
+    const uint32_t j2 = tid >> logc;
+    const uint64_t k1o = (g << logc) + c2;
+    const uint64_t obase = k1o + (rho << a.s1);   // digit-reversed block index
+    Fr sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sc.v[i] = a.scale[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t k = j2 + (uint32_t)i * (L / 8);
+        const uint32_t row = bitrev32(k, S);
+        Fr y = lds_get<Fr>(d_lo, d_hi, (c2 << S) | row);
+        const uint64_t oidx = obase + ((uint64_t)k << log_nb);
+        if (a.has_scale) y = Fr::mul(y, sc);
+        if (a.post_mul) y = Fr::mul(y, ld_fr<Fr>(a.post_mul, oidx));
+        st_fr<Fr>(a.out, oidx, y);
+    }
+}
+
+// tiny transforms (N = 1, 2, 4): one lane, straight from the definition
+template <class Fr>
+__global__ void ntt_tiny(NttPassArgs a, Fr w /* w_N */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n = 1u << a.log_n;
+    Fr x[4], y[4];
+    for (uint32_t i = 0; i < n; ++i) {
+        x[i] = i < a.in_len ? ld_fr<Fr>(a.in, i) : Fr::zero();
+        if (a.pre_mul && i < a.in_len) x[i] = Fr::mul(x[i], ld_fr<Fr>(a.pre_mul, i));
+    }
+    Fr sc;
+    for (int i = 0; i < 8; ++i) sc.v[i] = a.scale[i];
+    Fr wi = Fr::one();  // w^i
+    for (uint32_t i = 0; i < n; ++i) {
+        Fr acc = Fr::zero();
+        Fr wij = Fr::one();
+        for (uint32_t j = 0; j < n; ++j) {
+            acc = Fr::add(acc, Fr::mul(x[j], wij));
+            wij = Fr::mul(wij, wi);
+        }
+        if (a.has_scale) acc = Fr::mul(acc, sc);
+        if (a.post_mul) acc = Fr::mul(acc, ld_fr<Fr>(a.post_mul, i));
+        y[i] = acc;
+        wi = Fr::mul(wi, w);
+    }
+    for (uint32_t i = 0; i < n; ++i) st_fr<Fr>(a.out, i, y[i]);
+}
+
+// ------------------------------------------------------------------------------------ table builders
+template <class Fr>
+struct PowBits {
+    Fr p[32];  // base^(2^b)
+};
+// mode 0: out[i] = mul * base^i
+// mode 1: out[i] = mul * base^((col * k) mod 2^log_mprev), i = k * M + col, M = 2^log_m
+template <class Fr>
+__global__ void gen_pow_table(void* out, uint64_t n, PowBits<Fr> pb, Fr mul, int mode, uint32_t log_m, uint32_t log_mprev) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t e = i;
+    if (mode == 1) {
+        uint64_t col = i & ((1ull << log_m) - 1);
+        uint64_t k = i >> log_m;
+        e = (col * k) & ((1ull << log_mprev) - 1);
+    }
+    Fr r = mul;
+    for (int b = 0; b < 32; ++b) {
+        if ((e >> b) & 1ull) r = Fr::mul(r, pb.p[b]);
+    }
+    st_fr<Fr>(out, i, r);
+}
+
+template <class Fr>
+__global__ void fr_convert_kernel(const void* in, void* out, uint64_t n, int to_mont) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = ld_fr<Fr>(in, i);
+    st_fr<Fr>(out, i, to_mont ? Fr::to_mont(x) : Fr::from_mont(x));
+}
+template <class Fr>
+__global__ void fr_mul_kernel(const void* a, const void* b, void* out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_fr<Fr>(out, i, Fr::mul(ld_fr<Fr>(a, i), ld_fr<Fr>(b, i)));
+}
+
+// ------------------------------------------------------------------------------------ host side
+template <class C>
+typename C::Fr root_of_unity_host(uint32_t log_n) {
+    typedef typename C::Fr Fr;
+    Fr r;
+    for (int i = 0; i < Fr::N; ++i) r.v[i] = C::FrP::ROOT(i);
+    for (uint32_t k = log_n; k < (uint32_t)C::FrP::TWO_ADICITY; ++k) r = Fr::sqr(r);
+    return r;
+}
+
+template <class Fr>
+PowBits<Fr> make_powbits(Fr base) {
+    PowBits<Fr> pb;
+    Fr cur = base;
+    for (int b = 0; b < 32; ++b) {
+        pb.p[b] = cur;
+        cur = Fr::sqr(cur);
+    }
+    return pb;
+}
+
+template <class Fr>
+int launch_pow_table(zk_ctx* c, void* out, uint64_t n, Fr base, Fr mul, int mode, uint32_t log_m, uint32_t log_mprev) {
+    if (n == 0) return ZK_OK;
+    PowBits<Fr> pb = make_powbits(base);
+    const int T = 256;
+    uint64_t blocks = (n + T - 1) / T;
+    hipLaunchKernelGGL(gen_pow_table<Fr>, dim3((unsigned)blocks), dim3(T), 0, c->stream, out, n, pb, mul, mode, log_m, log_mprev);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// pass decomposition: every pass radix in [3, 10] (single pass for log_n <= 10)
+void decompose(uint32_t log_n, int& n_pass, int s[4]) {
+    s[0] = s[1] = s[2] = s[3] = 0;
+    if (log_n <= 10) {
+        n_pass = 1;
+        s[0] = (int)log_n;
+        return;
+    }
+    n_pass = (int)((log_n + 9) / 10);
+    int base = (int)log_n / n_pass, extra = (int)log_n % n_pass;
+    for (int i = 0; i < n_pass; ++i) s[i] = base + (i < extra ? 1 : 0);
+}
+
+template <class C>
+int get_inner_tw(zk_ctx* c, int s, bool inverse, void** out) {
+    typedef typename C::Fr Fr;
+    uint64_t key = ((uint64_t)C::ID << 40) | ((uint64_t)(inverse ? 1 : 0) << 32) | (uint64_t)s;
+    auto it = c->inner_tw.find(key);
+    if (it != c->inner_tw.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    uint64_t cnt = s >= 1 ? (1ull << (s - 1)) : 1;
+    void* p = nullptr;
+    ZK_HIP_TRY(hipMalloc(&p, cnt * sizeof(Fr)));
+    Fr w = root_of_unity_host<C>((uint32_t)s);
+    if (inverse) w = Fr::inverse(w);
+    int rc = launch_pow_table<Fr>(c, p, cnt, w, Fr::one(), 0, 0, 0);
+    if (rc) return rc;
+    c->inner_tw[key] = p;
+    *out = p;
+    return ZK_OK;
+}
+
+template <class C>
+int get_plan(zk_ctx* c, uint32_t log_n, bool inverse, NttPlan** out) {
+    typedef typename C::Fr Fr;
+    uint64_t key = ((uint64_t)C::ID << 40) | ((uint64_t)(inverse ? 1 : 0) << 32) | log_n;
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    NttPlan* pl = new NttPlan();
+    pl->curve = C::ID;
+    pl->log_n = log_n;
+    pl->inverse = inverse;
+    decompose(log_n, pl->n_pass, pl->s);
+    Fr n_inv = Fr::inverse(Fr::from_u64(1ull << log_n));
+    uint32_t log_mprev = log_n;
+    for (int p = 0; p < pl->n_pass; ++p) {
+        if (log_n >= 3) {
+            int rc = get_inner_tw<C>(c, pl->s[p], inverse, &pl->tw_inner[p]);
+            if (rc) { delete pl; return rc; }
+        }
+        if (p + 1 < pl->n_pass) {
+            uint32_t log_m = log_mprev - (uint32_t)pl->s[p];
+            uint64_t cnt = 1ull << log_mprev;
+            hipError_t e = hipMalloc(&pl->tw_pass[p], cnt * sizeof(Fr));
+            if (e != hipSuccess) { delete pl; return ZK_ERR_OOM; }
+            Fr w = root_of_unity_host<C>(log_mprev);
+            if (inverse) w = Fr::inverse(w);
+            // 1/N is folded into the first inter-pass table of an inverse transform
+            Fr mul = (inverse && p == 0) ? n_inv : Fr::one();
+            int rc = launch_pow_table<Fr>(c, pl->tw_pass[p], cnt, w, mul, 1, log_m, log_mprev);
+            if (rc) { delete pl; return rc; }
+            log_mprev = log_m;
+        }
+    }
+    c->plans[key] = pl;
+    *out = pl;
+    return ZK_OK;
+}
+
+template <class C>
+int ensure_coset(zk_ctx* c, bool inv, uint64_t len, void** out) {
+    typedef typename C::Fr Fr;
+    DevBuf& buf = inv ? c->coset_inv_pow[C::ID] : c->coset_pow[C::ID];
+    size_t& have = inv ? c->coset_inv_len[C::ID] : c->coset_len[C::ID];
+    if (have < len) {
+        // tables are referenced by in-flight kernels of this stream only; growing reallocates,
+        // so drain the stream first
+        ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+        uint64_t want = 1;
+        while (want < len) want <<= 1;
+        int rc = buf.ensure(want * sizeof(Fr));
+        if (rc) return rc;
+        Fr g = Fr::from_u32(C::FrP::GENERATOR);
+        if (inv) g = Fr::inverse(g);
+        rc = launch_pow_table<Fr>(c, buf.p, want, g, Fr::one(), 0, 0, 0);
+        if (rc) return rc;
+        have = want;
+    }
+    *out = buf.p;
+    return ZK_OK;
+}
+
+template <class Fr, int S>
+int launch_pass(zk_ctx* c, bool final_pass, const NttPassArgs& a, uint64_t n_tiles, uint32_t threads) {
+    constexpr uint32_t L = 1u << S;
+    uint32_t Cc = 1u << a.logc;
+    uint32_t nslots = (L * Cc + (((L * Cc) >> 4) << 1)) + 2;
+    size_t shmem = (size_t)(2 * nslots + L) * sizeof(uint4);
+    ProfScope ps(c, "ntt_pass");
+    if (final_pass) {
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_final<Fr, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((ntt_pass_final<Fr, S>), dim3((unsigned)n_tiles), dim3(threads), shmem, c->stream, a);
+    } else {
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_mid<Fr, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((ntt_pass_mid<Fr, S>), dim3((unsigned)n_tiles), dim3(threads), shmem, c->stream, a);
+    }
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class Fr>
+int dispatch_pass(zk_ctx* c, int s, bool final_pass, const NttPassArgs& a, uint64_t n_tiles, uint32_t threads) {
+    switch (s) {
+    case 3: return launch_pass<Fr, 3>(c, final_pass, a, n_tiles, threads);
+    case 4: return launch_pass<Fr, 4>(c, final_pass, a, n_tiles, threads);
+    case 5: return launch_pass<Fr, 5>(c, final_pass, a, n_tiles, threads);
+    case 6: return launch_pass<Fr, 6>(c, final_pass, a, n_tiles, threads);
+    case 7: return launch_pass<Fr, 7>(c, final_pass, a, n_tiles, threads);
+    case 8: return launch_pass<Fr, 8>(c, final_pass, a, n_tiles, threads);
+    case 9: return launch_pass<Fr, 9>(c, final_pass, a, n_tiles, threads);
+    case 10: return launch_pass<Fr, 10>(c, final_pass, a, n_tiles, threads);
+    default: return ZK_ERR_UNSUPPORTED;
+    }
+}
+
+// tile elements per workgroup: 2^11 (64 KiB of data + padding -> two workgroups per CU)
+constexpr uint32_t LOG_TILE = 11;
+
+template <class C>
+int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
+    typedef typename C::Fr Fr;
+    if (log_n > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+    if (log_n > 30) return ZK_ERR_UNSUPPORTED;
+    const uint64_t N = 1ull << log_n;
+    if (in_len > N) return ZK_ERR_BAD_ARG;
+    const bool inverse = (kind == ZK_NTT_IFFT || kind == ZK_NTT_COSET_IFFT);
+    void* pre = nullptr;
+    void* post = nullptr;
+    int rc;
+    if (kind == ZK_NTT_COSET_FFT && in_len > 0) {
+        rc = ensure_coset<C>(c, false, in_len, &pre);
+        if (rc) return rc;
+    }
+    if (kind == ZK_NTT_COSET_IFFT) {
+        rc = ensure_coset<C>(c, true, N, &post);
+        if (rc) return rc;
+    }
+    Fr n_inv = Fr::inverse(Fr::from_u64(N));
+
+    NttPassArgs a;
+    memset(&a, 0, sizeof a);
+    a.log_n = log_n;
+    if (log_n < 3) {
+        a.in = d_in; a.out = d_out; a.in_len = in_len; a.pre_mul = pre; a.post_mul = post;
+        a.has_scale = inverse ? 1 : 0;
+        for (int i = 0; i < 8; ++i) a.scale[i] = n_inv.v[i];
+        Fr w = root_of_unity_host<C>(log_n);
+        if (inverse) w = Fr::inverse(w);
+        ProfScope ps(c, "ntt_pass");
+        hipLaunchKernelGGL(ntt_tiny<Fr>, dim3(1), dim3(64), 0, c->stream, a, w);
+        ZK_HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
+    NttPlan* pl = nullptr;
+    rc = get_plan<C>(c, log_n, inverse, &pl);
+    if (rc) return rc;
+    if (pl->n_pass > 3) return ZK_ERR_UNSUPPORTED;
+    void* work = nullptr;
+    if (pl->n_pass > 1) {
+        rc = c->ntt_work.ensure(N * sizeof(Fr));
+        if (rc) return rc;
+        work = c->ntt_work.p;
+    }
+    uint32_t log_mprev = log_n;
+    for (int p = 0; p < pl->n_pass; ++p) {
+        const int s = pl->s[p];
+        const bool last = (p + 1 == pl->n_pass);
+        memset(&a, 0, sizeof a);
+        a.log_n = log_n;
+        a.in = (p == 0) ? d_in : work;
+        a.out = last ? d_out : work;
+        a.in_len = (p == 0) ? in_len : N;
+        a.tw_inner = pl->tw_inner[p];
+        a.pre_mul = (p == 0) ? pre : nullptr;
+        uint64_t n_tiles;
+        uint32_t threads;
+        if (!last) {
+            uint32_t log_m = log_mprev - (uint32_t)s;
+            uint32_t logc = LOG_TILE > (uint32_t)s ? LOG_TILE - (uint32_t)s : 0;
+            if (logc > log_m) logc = log_m;
+            a.logc = logc;
+            a.log_m = log_m;
+            a.log_mprev = log_mprev;
+            a.tw_pass = pl->tw_pass[p];
+            n_tiles = N >> ((uint32_t)s + logc);
+            threads = 1u << ((uint32_t)s + logc - 3);
+            log_mprev = log_m;
+        } else {
+            uint32_t s1 = (pl->n_pass > 1) ? (uint32_t)pl->s[0] : 0;
+            uint32_t logc = LOG_TILE > (uint32_t)s ? LOG_TILE - (uint32_t)s : 0;
+            if (logc > 3) logc = 3;   // 8 x 32 B = 256 B contiguous store segments are enough
+            if (logc > s1) logc = s1;
+            a.logc = logc;
+            a.s1 = s1;
+            a.post_mul = post;
+            // the 1/N factor rides on the first inter-pass table when there is one
+            a.has_scale = (inverse && pl->n_pass == 1) ? 1 : 0;
+            for (int i = 0; i < 8; ++i) a.scale[i] = n_inv.v[i];
+            n_tiles = N >> ((uint32_t)s + logc);
+            threads = 1u << ((uint32_t)s + logc - 3);
+        }
+        rc = dispatch_pass<Fr>(c, s, last, a, n_tiles, threads);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+
+}  // namespace
+
+int ntt_run_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
+    if (kind < 0 || kind > 3) return ZK_ERR_BAD_ARG;
+    if (curve == ZK_CURVE_BLS12_381) return ntt_run<CurveBls>(c, kind, log_n, d_in, in_len, d_out);
+    if (curve == ZK_CURVE_BN254) return ntt_run<CurveBn>(c, kind, log_n, d_in, in_len, d_out);
+    return ZK_ERR_BAD_ARG;
+}
+
+int ntt_prepare(zk_ctx* c, int curve, uint32_t log_n) {
+    NttPlan* pl;
+    if (log_n < 3) return ZK_OK;
+    for (int inv = 0; inv < 2; ++inv) {
+        int rc;
+        if (curve == ZK_CURVE_BLS12_381) {
+            if (log_n > 30 || log_n > (uint32_t)FrBls12_381Params::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+            rc = get_plan<CurveBls>(c, log_n, inv != 0, &pl);
+        } else if (curve == ZK_CURVE_BN254) {
+            if (log_n > (uint32_t)FrBn254Params::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+            rc = get_plan<CurveBn>(c, log_n, inv != 0, &pl);
+        } else {
+            return ZK_ERR_BAD_ARG;
+        }
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+
+void ntt_ctx_free(zk_ctx* c) {
+    for (auto& kv : c->plans) delete kv.second;
+    c->plans.clear();
+    for (auto& kv : c->inner_tw) (void)hipFree(kv.second);
+    c->inner_tw.clear();
+    c->ntt_work.release();
+    for (int i = 0; i < 2; ++i) {
+        c->coset_pow[i].release();
+        c->coset_inv_pow[i].release();
+    }
+}
+
+int fr_convert_dev(zk_ctx* c, int curve, int to_mont, const void* d_in, size_t n, void* d_out) {
+    if (n == 0) return ZK_OK;
+    const int T = 256;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    if (curve == ZK_CURVE_BLS12_381)
+        hipLaunchKernelGGL(fr_convert_kernel<FrBls>, dim3(blocks), dim3(T), 0, c->stream, d_in, d_out, (uint64_t)n, to_mont);
+    else if (curve == ZK_CURVE_BN254)
+        hipLaunchKernelGGL(fr_convert_kernel<FrBn>, dim3(blocks), dim3(T), 0, c->stream, d_in, d_out, (uint64_t)n, to_mont);
+    else
+        return ZK_ERR_BAD_ARG;
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, void* out) {
+    if (n == 0) return ZK_OK;
+    const int T = 256;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    if (curve == ZK_CURVE_BLS12_381)
+        hipLaunchKernelGGL(fr_mul_kernel<FrBls>, dim3(blocks), dim3(T), 0, c->stream, a, b, out, (uint64_t)n);
+    else if (curve == ZK_CURVE_BN254)
+        hipLaunchKernelGGL(fr_mul_kernel<FrBn>, dim3(blocks), dim3(T), 0, c->stream, a, b, out, (uint64_t)n);
+    else
+        return ZK_ERR_BAD_ARG;
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}

@@ -1,0 +1,189 @@
+"""Host mirror of `ark_ec::msm::VariableBaseMSM` and of the KZG10 commit/open glue.
+
+Mirrors:
+  VariableBaseMSM::multi_scalar_mul(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective
+      (plonk-core/src/commitment.rs:45,83)  -- here returned already `.into()` affine
+  PolynomialCommitment::commit / open of SonicKZG10 without hiding or degree bounds
+      (proof_system/prover.rs:213,289-291,...,582-591) via `CommitterKey` (device-resident powers_of_g)
+Bases: (n, 2L) uint64 limbs x||y Montgomery (L = 6 BLS12-381, 4 BN254) + optional infinity flags.
+Scalars: (n, 4) uint64 canonical limbs (`into_repr`).  Truncates to the shorter slice like the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ._lib import check, lib
+from .context import Context, _is_torch, as_host_u64, check_dev_tensor, default_context, ptr_of
+from .curves import get_curve
+
+
+class G1Affine:
+    """(x, y, infinity) with x, y Montgomery limbs -- the fields of ark's GroupAffine."""
+
+    __slots__ = ("x", "y", "infinity", "curve")
+
+    def __init__(self, x, y, infinity, curve):
+        self.x, self.y, self.infinity, self.curve = x, y, bool(infinity), curve
+
+    def __eq__(self, o):
+        return (isinstance(o, G1Affine) and self.infinity == o.infinity and np.array_equal(self.x, o.x)
+                and np.array_equal(self.y, o.y))
+
+    def __repr__(self):
+        return f"G1Affine(inf={self.infinity}, x={[hex(int(v)) for v in self.x]}, y={[hex(int(v)) for v in self.y]})"
+
+    def xy(self) -> np.ndarray:
+        return np.concatenate([self.x, self.y])
+
+
+def _point(out_xy, out_inf, cv) -> G1Affine:
+    L = cv.fq_limbs
+    return G1Affine(out_xy[:L].copy(), out_xy[L:].copy(), int(out_inf[0]) != 0, cv.name)
+
+
+class CommitterKey:
+    """Device-resident `powers_of_g` (what `PC::trim` hands the prover; circuit.rs:236,276)."""
+
+    def __init__(self, powers_of_g, curve="bls12_381", ctx: Context | None = None, infinity=None):
+        self.curve = get_curve(curve)
+        L = self.curve.fq_limbs
+        self._h = ctypes.c_void_p()
+        if _is_torch(powers_of_g):
+            self.ctx = ctx or default_context(powers_of_g.device.index)
+            n = check_dev_tensor(powers_of_g, 2 * L, self.ctx.device)
+            if infinity is not None:
+                raise ValueError("infinity flags are only accepted with host arrays")
+            self.ctx.use_torch_stream()
+            check(lib().zk_srs_register_dev(self.ctx.handle, self.curve.curve_id, ptr_of(powers_of_g), n, ctypes.byref(self._h)),
+                  "zk_srs_register_dev")
+        else:
+            self.ctx = ctx or default_context(0)
+            a = as_host_u64(powers_of_g, 2 * L)
+            n = a.shape[0]
+            inf = None
+            if infinity is not None:
+                inf = np.ascontiguousarray(infinity, dtype=np.uint8)
+                if inf.shape[0] != n:
+                    raise ValueError("infinity flags length mismatch")
+            check(lib().zk_srs_register(self.ctx.handle, self.curve.curve_id, ptr_of(a), None if inf is None else ptr_of(inf), n,
+                                        ctypes.byref(self._h)), "zk_srs_register")
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().zk_srs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- MSM over powers[base_offset : base_offset + len(scalars)]
+    def msm(self, scalars, base_offset: int = 0) -> G1Affine:
+        L = self.curve.fq_limbs
+        out = np.zeros(2 * L, dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        if _is_torch(scalars):
+            n = check_dev_tensor(scalars, 4, self.ctx.device)
+            self.ctx.use_torch_stream()
+            check(lib().zk_msm_g1_srs_dev(self.ctx.handle, self._h, base_offset, ptr_of(scalars), n, ptr_of(out), ptr_of(inf)),
+                  "zk_msm_g1_srs_dev")
+        else:
+            s = as_host_u64(scalars, 4)
+            check(lib().zk_msm_g1_srs(self.ctx.handle, self._h, base_offset, ptr_of(s), s.shape[0], ptr_of(out), ptr_of(inf)),
+                  "zk_msm_g1_srs")
+        return _point(out, inf, self.curve)
+
+    def msm_partial(self, scalars, base_offset: int = 0) -> np.ndarray:
+        """This rank's Jacobian partial (3L limbs) for the multi-GPU all-gather."""
+        L = self.curve.fq_limbs
+        out = np.zeros(3 * L, dtype=np.uint64)
+        n = check_dev_tensor(scalars, 4, self.ctx.device)
+        self.ctx.use_torch_stream()
+        check(lib().zk_msm_g1_srs_partial_dev(self.ctx.handle, self._h, base_offset, ptr_of(scalars), n, ptr_of(out)),
+              "zk_msm_g1_srs_partial_dev")
+        return out
+
+    # -- KZG10::commit(powers, polynomial, hiding_bound = None)
+    def commit(self, coeffs_mont) -> G1Affine:
+        L = self.curve.fq_limbs
+        out = np.zeros(2 * L, dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        if _is_torch(coeffs_mont):
+            n = check_dev_tensor(coeffs_mont, 4, self.ctx.device)
+            self.ctx.use_torch_stream()
+            check(lib().zk_kzg_commit_dev(self.ctx.handle, self._h, ptr_of(coeffs_mont), n, ptr_of(out), ptr_of(inf)), "zk_kzg_commit_dev")
+        else:
+            a = as_host_u64(coeffs_mont, 4)
+            check(lib().zk_kzg_commit(self.ctx.handle, self._h, ptr_of(a), a.shape[0], ptr_of(out), ptr_of(inf)), "zk_kzg_commit")
+        return _point(out, inf, self.curve)
+
+    # -- PC::open(ck, polys, comms, point, opening_challenge, rands, None)
+    def open(self, polys, point_mont, challenge_mont) -> G1Affine:
+        L = self.curve.fq_limbs
+        out = np.zeros(2 * L, dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        k = len(polys)
+        ptrs = (ctypes.c_void_p * k)()
+        lens = (ctypes.c_size_t * k)()
+        for i, p in enumerate(polys):
+            lens[i] = check_dev_tensor(p, 4, self.ctx.device)
+            ptrs[i] = p.data_ptr()
+        z = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
+        ch = np.ascontiguousarray(challenge_mont, dtype=np.uint64).reshape(4)
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_open_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(z), ptr_of(ch), ptr_of(out), ptr_of(inf)),
+              "zk_kzg_open_dev")
+        return _point(out, inf, self.curve)
+
+
+class VariableBaseMSM:
+    """`ark_ec::msm::VariableBaseMSM`."""
+
+    @staticmethod
+    def multi_scalar_mul(bases, scalars, curve="bls12_381", infinity=None, ctx: Context | None = None) -> G1Affine:
+        cv = get_curve(curve)
+        L = cv.fq_limbs
+        if _is_torch(bases) or _is_torch(scalars):
+            if not (_is_torch(bases) and _is_torch(scalars)):
+                raise ValueError("bases and scalars must both be device tensors or both host arrays")
+            ctx = ctx or default_context(bases.device.index)
+            nb = check_dev_tensor(bases, 2 * L, ctx.device)
+            ns = check_dev_tensor(scalars, 4, ctx.device)
+            n = min(nb, ns)
+            ck = CommitterKey(bases.view(-1)[: n * 2 * L].view(n, 2 * L), cv, ctx)
+            try:
+                return ck.msm(scalars.view(-1)[: n * 4].view(n, 4))
+            finally:
+                ck.close()
+        ctx = ctx or default_context(0)
+        b = as_host_u64(bases, 2 * L)
+        s = as_host_u64(scalars, 4)
+        n = min(b.shape[0], s.shape[0])
+        b, s = b[:n], s[:n]
+        inf = None
+        if infinity is not None:
+            inf = np.ascontiguousarray(infinity, dtype=np.uint8)[:n]
+        out = np.zeros(2 * L, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        check(lib().zk_msm_g1(ctx.handle, cv.curve_id, ptr_of(b), None if inf is None else ptr_of(inf), ptr_of(s), n,
+                              ptr_of(out), ptr_of(oinf)), "zk_msm_g1")
+        return _point(out, oinf, cv)
+
+
+def sum_partials(partials, curve="bls12_381") -> G1Affine:
+    """Combine the all-gathered Jacobian partials of a sharded MSM (host, tiny)."""
+    cv = get_curve(curve)
+    L = cv.fq_limbs
+    p = as_host_u64(partials, 3 * L)
+    out = np.zeros(2 * L, dtype=np.uint64)
+    inf = np.zeros(1, dtype=np.uint8)
+    check(lib().zk_g1_sum_partials(cv.curve_id, ptr_of(p), p.shape[0], ptr_of(out), ptr_of(inf)), "zk_g1_sum_partials")
+    return _point(out, inf, cv)

@@ -1,0 +1,161 @@
+/* ark_plonk_amd.h -- C ABI of the MI355X-native NTT + MSM prover hot path.
+ *
+ * Drop-in boundary for heliaxdev/ark-plonk's proof-generation inner loop.
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference tree) and, where the arithmetic lives in a crates.io dependency, the crate item the
+ * reference calls there.  Plain pointers and sizes only; no torch / HIP types in signatures
+ * (a HIP stream is passed as an opaque void*).
+ *
+ * Data formats (identical bytes to arkworks 0.3 in-memory values):
+ *   Fr element  : 4 x uint64 little-endian limbs, Montgomery form (value * 2^256 mod r), < r.
+ *   Fr scalar   : 4 x uint64 little-endian limbs, canonical integer (PrimeField::into_repr), < r.
+ *   Fq element  : L x uint64 limbs (L = 6 BLS12-381, 4 BN254), Montgomery form (R = 2^(64L)).
+ *   G1 affine   : x || y (2L limbs, packed); infinity carried in a separate uint8 flag array
+ *                 (arkworks' GroupAffine is not repr(C): the shim copies x, y, infinity).
+ *   Output point: affine x || y Montgomery; infinity is (0, 1) + flag 1, as GroupAffine::zero().
+ *
+ * Ownership: the caller owns every buffer; nothing is retained after return except the device
+ * copy held by a zk_srs handle.  Errors: 0 = success, negative = failure (never aborts, never
+ * throws).  Threading: calls on one ctx are serialised internally; one HIP stream per ctx.
+ * One ctx drives one GPU (one process per GPU; multi-GPU MSM = one ctx per rank + an
+ * all-gather of zk_msm_g1_*_partial outputs).
+ */
+#ifndef ARK_PLONK_AMD_H
+#define ARK_PLONK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_srs zk_srs;
+
+/* curve ids */
+#define ZK_CURVE_BLS12_381 0
+#define ZK_CURVE_BN254 1
+
+/* transform kinds == ark_poly::EvaluationDomain methods */
+#define ZK_NTT_FFT 0        /* EvaluationDomain::fft        (permutation/mod.rs:671-674)            */
+#define ZK_NTT_IFFT 1       /* EvaluationDomain::ifft       (prover.rs:196-203,240-242,281-283,302-305) */
+#define ZK_NTT_COSET_FFT 2  /* EvaluationDomain::coset_fft  (quotient_poly.rs:72-120,205,294)       */
+#define ZK_NTT_COSET_IFFT 3 /* EvaluationDomain::coset_ifft (quotient_poly.rs:175-177)              */
+
+/* error codes */
+#define ZK_OK 0
+#define ZK_ERR_BAD_ARG (-1)
+#define ZK_ERR_DOMAIN_TOO_LARGE (-2) /* log_n > two-adicity: plonk-core/src/error.rs:14-21 InvalidEvalDomainSize */
+#define ZK_ERR_HIP (-3)
+#define ZK_ERR_OOM (-4)
+#define ZK_ERR_NO_DEVICE (-5)
+#define ZK_ERR_UNSUPPORTED (-6)
+
+const char* zk_strerror(int code);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* Create a context on HIP device `device` (one process per GPU). */
+int zk_ctx_create(int device, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+/* Run all work of this ctx on an existing HIP stream (hipStream_t as void*; NULL = ctx's own). */
+int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
+/* Block until all queued work of this ctx is complete. */
+int zk_ctx_sync(zk_ctx* ctx);
+/* Override the MSM window size c (0 = automatic). Test/tuning hook. */
+int zk_ctx_set_msm_window(zk_ctx* ctx, int c);
+
+/* Per-kernel HIP-event timing (bench.py roofline leg). When enabled every launch of the hot
+ * kernels is bracketed by hipEventRecord on the ctx stream. */
+int zk_profile_enable(zk_ctx* ctx, int on);
+int zk_profile_reset(zk_ctx* ctx);
+/* name: "ntt_pass", "msm_accumulate", "msm_sort", "msm_reduce", ...; returns total ms and launch count */
+int zk_profile_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+
+/* ---- a1: GeneralEvaluationDomain::new + EvaluationDomainExt (util.rs:24-88) ------------------- */
+typedef struct zk_domain_info {
+    uint64_t size;               /* 2^log_n                                   */
+    uint32_t log_size_of_group;  /* EvaluationDomainExt::log_size_of_group    */
+    uint32_t reserved;
+    uint64_t size_inv[4];        /* ::size_inv        (Montgomery)            */
+    uint64_t group_gen[4];       /* ::group_gen                               */
+    uint64_t group_gen_inv[4];   /* ::group_gen_inv                           */
+    uint64_t generator[4];       /* F::multiplicative_generator() (coset g)   */
+    uint64_t generator_inv[4];   /* ::generator_inv                           */
+} zk_domain_info;
+/* Replaces GeneralEvaluationDomain::<F>::new(num_coeffs) (prover.rs:169-173,
+ * quotient_poly.rs:64-69): size = next_power_of_two(num_coeffs). */
+int zk_domain_new(int curve_id, uint64_t num_coeffs, zk_domain_info* out);
+
+/* ---- a2-a5: NTT ------------------------------------------------------------------------------ */
+/* Host-buffer transform.  in: in_len (<= 2^log_n) Montgomery Fr elements, zero-extended;
+ * out: 2^log_n elements, natural order.  in == out allowed.
+ * Replaces ark_poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place. */
+int zk_ntt(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, const uint64_t* in, size_t in_len, uint64_t* out);
+/* Same with device-resident buffers (async on the ctx stream).  d_in == d_out allowed. */
+int zk_ntt_dev(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out);
+/* n_polys transforms of one kind/size sharing a plan (the 13 coset_fft of quotient_poly.rs:72-120). */
+int zk_ntt_batch_dev(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, uint32_t n_polys,
+                     const void* const* d_ins, const size_t* in_lens, void* const* d_outs);
+/* Pre-build (and keep) the twiddle plan for (curve, log_n); otherwise built on first use. */
+int zk_ntt_prepare(zk_ctx* ctx, int curve_id, uint32_t log_n);
+
+/* Fr Montgomery <-> canonical on device (PrimeField::into_repr / from_repr; commitment.rs:37-40). */
+int zk_fr_from_mont_dev(zk_ctx* ctx, int curve_id, const void* d_in, size_t n, void* d_out);
+int zk_fr_to_mont_dev(zk_ctx* ctx, int curve_id, const void* d_in, size_t n, void* d_out);
+
+/* ---- a6/a8: MSM ------------------------------------------------------------------------------ */
+/* Replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) (commitment.rs:45,83)
+ * followed by `.into()` affine.  n = min(len) pairs; inf_flags may be NULL. */
+int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags,
+              const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
+/* Device-resident SRS (CommitterKey::powers_of_g after PC::trim, circuit.rs:236,276). */
+int zk_srs_register(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out);
+int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out);
+void zk_srs_free(zk_srs* srs);
+size_t zk_srs_len(const zk_srs* srs);
+
+/* MSM over srs[base_offset .. base_offset+n) with host / device canonical scalars. */
+int zk_msm_g1_srs(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const uint64_t* scalars, size_t n,
+                  uint64_t* out_xy, uint8_t* out_inf);
+int zk_msm_g1_srs_dev(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const void* d_scalars, size_t n,
+                      uint64_t* out_xy, uint8_t* out_inf);
+/* Multi-GPU leg: this rank's partial sum as a projective (X, Y, Z) Jacobian triple, 3L limbs,
+ * Montgomery (Z = 0 for infinity) -- the 144-byte message all-gathered over RCCL. */
+int zk_msm_g1_srs_partial_dev(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const void* d_scalars, size_t n,
+                              uint64_t* out_xyz);
+/* Host: sum `count` Jacobian partials (count x 3L limbs) and normalise to affine. */
+int zk_g1_sum_partials(int curve_id, const uint64_t* partials_xyz, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- a6: KZG10 commit (PC::commit, prover.rs:213,289-291,312-317,361-363,387-389,459-469) ----- */
+/* d_coeffs_mont: n Montgomery Fr coefficients on device.  into_repr + MSM over
+ * srs[0..n) (leading zero coefficients contribute nothing, as kzg10::commit's stripping). */
+int zk_kzg_commit_dev(zk_ctx* ctx, zk_srs* srs, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
+/* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).
+ * polys: n_polys device pointers to Montgomery coefficient vectors of lens[k] elements. */
+int zk_kzg_open_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
+                    const uint64_t* z_mont, const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- utilities (synthetic SRS for tests/bench; stands in for PC::setup, out of scope) --------- */
+/* out[i] = scalars[i] * G1 generator, affine Montgomery, device buffers. */
+int zk_g1_fixed_base_batch_dev(zk_ctx* ctx, int curve_id, const void* d_scalars, size_t n, void* d_out_xy);
+/* out[i] = a[i] * b[i] (Montgomery Fr, device) -- pointwise helper for property tests. */
+int zk_fr_mul_dev(zk_ctx* ctx, int curve_id, const void* d_a, const void* d_b, size_t n, void* d_out);
+
+/* Device memory helpers so a non-torch host (the Rust shim, C++ host layer) needs no HIP headers. */
+int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr);
+int zk_dev_free(zk_ctx* ctx, void* d_ptr);
+int zk_dev_upload(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int zk_dev_download(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* Library build info: returns "gfx950" etc. */
+const char* zk_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARK_PLONK_AMD_H */

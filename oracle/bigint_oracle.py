@@ -1,0 +1,319 @@
+"""TEST INFRASTRUCTURE ONLY -- definitional big-integer oracle for the NTT + MSM hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product path (ark_plonk_amd/) never imports anything under oracle/.
+
+PARITY UNPINNED BY THE REFERENCE: heliaxdev/ark-plonk holds no golden vectors, KATs or
+fixtures for this path (every reference test draws from OsRng) and
+the arithmetic lives in crates.io dependencies that are absent from /root/reference:
+ark-poly 0.3.0, ark-ec 0.3.0, ark-ff 0.3.0, ark-bls12-381 0.3.0, ark-poly-commit 0.3.0
+(plonk-core/Cargo.toml:51-58; no Cargo.lock).  This file restates the *published
+mathematical definitions* those crates implement; because the outputs at the kernel
+boundary are canonical (a reduced Montgomery residue / a normalised affine point has one
+representation), any correct implementation is bit-identical with arkworks.
+
+What is restated, and the reference call site each function stands behind:
+  * ntt(kind, ...)    -- ark_poly::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}
+                         as called from plonk-core/src/proof_system/prover.rs:196-203,
+                         quotient_poly.rs:72-120,175-177, permutation/mod.rs:671-674,751.
+  * msm(...)          -- ark_ec::msm::VariableBaseMSM::multi_scalar_mul as called from
+                         plonk-core/src/commitment.rs:45 and every PC::commit
+                         (prover.rs:213,289-291,...).
+  * kzg_commit/open   -- ark_poly_commit::kzg10::KZG10::{commit,open} semantics
+                         (leading-zero stripping, into_repr, witness polynomial division),
+                         called from prover.rs:213 and prover.rs:582-591.
+External anchors used to pin constants (tests/test_oracle.py):
+  * TWO_ADIC_ROOT_OF_UNITY of ark-bls12-381 Fr (decimal constant quoted in SURVEY.md 8a).
+  * [2]G1 x-coordinate of BLS12-381 (the published compressed encoding a572cbea...f0f4e).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    curve_id: int
+    r: int            # scalar field modulus
+    q: int            # base field modulus
+    fr_limbs: int     # 64-bit limbs of Fr
+    fq_limbs: int     # 64-bit limbs of Fq
+    two_adicity: int
+    fr_generator: int  # multiplicative generator of Fr (coset shift, ark FftParameters::GENERATOR)
+    b: int            # y^2 = x^3 + b
+    gx: int
+    gy: int
+
+    @property
+    def fr_R(self):
+        return 1 << (64 * self.fr_limbs)
+
+    @property
+    def fq_R(self):
+        return 1 << (64 * self.fq_limbs)
+
+    def root_of_unity(self, log_n: int) -> int:
+        """ark FftParameters::TWO_ADIC_ROOT_OF_UNITY ^ (2^(two_adicity-log_n))."""
+        if log_n > self.two_adicity:
+            raise ValueError("log_n exceeds two-adicity")
+        root = pow(self.fr_generator, (self.r - 1) >> self.two_adicity, self.r)
+        return pow(root, 1 << (self.two_adicity - log_n), self.r)
+
+
+BLS12_381 = Curve(
+    name="bls12_381", curve_id=0,
+    r=0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+    q=0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+    fr_limbs=4, fq_limbs=6, two_adicity=32, fr_generator=7, b=4,
+    gx=0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+    gy=0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1,
+)
+
+BN254 = Curve(
+    name="bn254", curve_id=1,
+    r=21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    q=21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    fr_limbs=4, fq_limbs=4, two_adicity=28, fr_generator=5, b=3, gx=1, gy=2,
+)
+
+CURVES = {0: BLS12_381, 1: BN254, "bls12_381": BLS12_381, "bn254": BN254}
+
+KIND_FFT, KIND_IFFT, KIND_COSET_FFT, KIND_COSET_IFFT = 0, 1, 2, 3
+
+
+# ----------------------------------------------------------------------------- field helpers
+def to_mont(x: int, p: int, R: int) -> int:
+    return (x * R) % p
+
+
+def from_mont(x: int, p: int, R: int) -> int:
+    return (x * pow(R, -1, p)) % p
+
+
+def int_to_limbs(x: int, n: int) -> list:
+    return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def limbs_to_int(limbs) -> int:
+    v = 0
+    for i, l in enumerate(limbs):
+        v |= int(l) << (64 * i)
+    return v
+
+
+# ----------------------------------------------------------------------------- NTT (definition)
+def _dft_pow2(a: list, w: int, p: int) -> list:
+    """Recursive radix-2 DFT: out[i] = sum_j a[j] w^(ij) mod p. len(a) a power of two."""
+    n = len(a)
+    if n == 1:
+        return [a[0] % p]
+    w2 = w * w % p
+    ev = _dft_pow2(a[0::2], w2, p)
+    od = _dft_pow2(a[1::2], w2, p)
+    out = [0] * n
+    t = 1
+    h = n // 2
+    for i in range(h):
+        x = od[i] * t % p
+        out[i] = (ev[i] + x) % p
+        out[i + h] = (ev[i] - x) % p
+        t = t * w % p
+    return out
+
+
+def dft_naive(a: list, w: int, p: int) -> list:
+    """O(N^2) DFT straight from the definition (used to pin _dft_pow2 at tiny sizes)."""
+    n = len(a)
+    return [sum(a[j] * pow(w, i * j, p) for j in range(n)) % p for i in range(n)]
+
+
+def ntt(curve: Curve, kind: int, log_n: int, values: list) -> list:
+    """Canonical-integer (non-Montgomery) semantics of ark_poly 0.3 Radix2EvaluationDomain.
+
+    fft        : e[i] = sum_j a[j] w^(ij)                (input zero-extended to N)
+    ifft       : a[j] = N^-1 sum_i e[i] w^(-ij)
+    coset_fft  : e[i] = sum_j a[j] (g w^i)^j,  g = Fr::multiplicative_generator
+    coset_ifft : a[j] = g^-j N^-1 sum_i e[i] w^(-ij)
+    """
+    p = curve.r
+    n = 1 << log_n
+    if len(values) > n:
+        raise ValueError("input longer than domain")
+    a = [v % p for v in values] + [0] * (n - len(values))
+    w = curve.root_of_unity(log_n)
+    g = curve.fr_generator
+    if kind == KIND_FFT:
+        return _dft_pow2(a, w, p)
+    if kind == KIND_COSET_FFT:
+        gj = 1
+        b = []
+        for v in a:
+            b.append(v * gj % p)
+            gj = gj * g % p
+        return _dft_pow2(b, w, p)
+    winv = pow(w, -1, p)
+    ninv = pow(n, -1, p)
+    out = [v * ninv % p for v in _dft_pow2(a, winv, p)]
+    if kind == KIND_IFFT:
+        return out
+    if kind == KIND_COSET_IFFT:
+        ginv = pow(g, -1, p)
+        gj = 1
+        res = []
+        for v in out:
+            res.append(v * gj % p)
+            gj = gj * ginv % p
+        return res
+    raise ValueError("bad kind")
+
+
+def horner(coeffs: list, x: int, p: int) -> int:
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % p
+    return acc
+
+
+# ----------------------------------------------------------------------------- G1 (affine, definition)
+INF = None  # point at infinity
+
+
+def ec_add(curve: Curve, P, Q):
+    q = curve.q
+    if P is INF:
+        return Q
+    if Q is INF:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % q == 0:
+            return INF
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, q) % q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, q) % q
+    x3 = (lam * lam - x1 - x2) % q
+    y3 = (lam * (x1 - x3) - y1) % q
+    return (x3, y3)
+
+
+def ec_neg(curve: Curve, P):
+    if P is INF:
+        return INF
+    return (P[0], (-P[1]) % curve.q)
+
+
+def ec_mul(curve: Curve, k: int, P):
+    """double-and-add, MSB first."""
+    R = INF
+    if k < 0:
+        k, P = -k, ec_neg(curve, P)
+    for bit in bin(k)[2:] if k else "":
+        R = ec_add(curve, R, R)
+        if bit == "1":
+            R = ec_add(curve, R, P)
+    return R
+
+
+def on_curve(curve: Curve, P) -> bool:
+    if P is INF:
+        return True
+    x, y = P
+    return (y * y - x * x * x - curve.b) % curve.q == 0
+
+
+def msm(curve: Curve, bases: list, scalars: list):
+    """sum_i scalars[i] * bases[i] over min(len) pairs (ark truncates to the shorter slice)."""
+    acc = INF
+    for P, s in zip(bases, scalars):
+        acc = ec_add(curve, acc, ec_mul(curve, s % curve.r if s >= curve.r else s, P))
+    return acc
+
+
+def srs_powers(curve: Curve, tau: int, n: int) -> list:
+    """powers_of_g[i] = tau^i * G  (KZG10 setup shape, ark-poly-commit 0.3 kzg10::setup)."""
+    out = []
+    G = (curve.gx, curve.gy)
+    t = 1
+    for _ in range(n):
+        out.append(ec_mul(curve, t, G))
+        t = t * tau % curve.r
+    return out
+
+
+# ----------------------------------------------------------------------------- KZG10 commit / open semantics
+def kzg_commit(curve: Curve, powers: list, coeffs: list):
+    """ark-poly-commit 0.3 KZG10::commit with hiding_bound=None:
+    skip leading (low-degree) zero coefficients, canonical scalars, MSM over powers[lz..]."""
+    lz = 0
+    while lz < len(coeffs) and coeffs[lz] % curve.r == 0:
+        lz += 1
+    return msm(curve, powers[lz:], [c % curve.r for c in coeffs[lz:]])
+
+
+def kzg_witness_poly(curve: Curve, coeffs: list, z: int) -> list:
+    """(p(X) - p(z)) / (X - z) by synthetic division (KZG10::compute_witness_polynomial)."""
+    p = curve.r
+    n = len(coeffs)
+    if n <= 1:
+        return []
+    w = [0] * (n - 1)
+    acc = 0
+    for i in range(n - 1, 0, -1):
+        acc = (coeffs[i] + acc * z) % p
+        w[i - 1] = acc
+    return w
+
+
+def kzg_open(curve: Curve, powers: list, polys: list, z: int, challenge: int):
+    """PC::open for SonicKZG10 without degree bounds / hiding: p = sum_k chi^k p_k;
+    witness = (p - p(z))/(X - z); proof.w = commit(witness)."""
+    p = curve.r
+    m = max(len(c) for c in polys)
+    comb = [0] * m
+    chi = 1
+    for c in polys:
+        for i, v in enumerate(c):
+            comb[i] = (comb[i] + chi * v) % p
+        chi = chi * challenge % p
+    return kzg_commit(curve, powers, kzg_witness_poly(curve, comb, z))
+
+
+# ----------------------------------------------------------------------------- window rule (for add counting)
+def ark_window_size(n: int) -> int:
+    """ark-ec 0.3 variable_base.rs: c = 3 if n < 32 else ln_without_floats(n) + 2,
+    ln_without_floats(a) = log2(a) * 69 / 100 with log2 = ceil(log2)."""
+    if n < 32:
+        return 3
+    lg = (n - 1).bit_length()
+    return lg * 69 // 100 + 2
+
+
+def ark_msm_adds(n: int, scalar_bits: int = 255) -> int:
+    """Reference-equivalent G1 additions: W*N + 2*W*(2^c - 1)."""
+    c = ark_window_size(n)
+    w = -(-scalar_bits // c)
+    return w * n + 2 * w * ((1 << c) - 1)
+
+
+# ----------------------------------------------------------------------------- seeded inputs
+def splitmix64(state: int):
+    state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return state, z ^ (z >> 31)
+
+
+def seeded_scalars(curve: Curve, seed: int, n: int) -> list:
+    """n field elements: 4 splitmix64 words (little-endian limbs) reduced mod r."""
+    st = seed & 0xFFFFFFFFFFFFFFFF
+    out = []
+    for _ in range(n):
+        v = 0
+        for k in range(4):
+            st, z = splitmix64(st)
+            v |= z << (64 * k)
+        out.append(v % curve.r)
+    return out

@@ -1,0 +1,171 @@
+"""GPU parity: the HIP Pippenger MSM (through the C ABI) against the golden vectors, the CPU oracle
+and the KZG identity MSM(s, tau^i G) = (sum s_i tau^i) G at the benchmark sizes.  Bit-exact."""
+import numpy as np
+import pytest
+
+import ark_plonk_amd as zk
+from ark_plonk_amd import _lib
+from oracle import bigint_oracle as bo
+
+pytestmark = pytest.mark.gpu
+
+CASES = ("repeat", "cancel", "onebucket", "infbase", "zeros", "ones", "mixed", "maxscalar")
+
+
+def assert_point(got, exp_xy, exp_inf, cid, tag=""):
+    L = bo.CURVES[cid].fq_limbs
+    assert got.infinity == bool(exp_inf), tag
+    assert np.array_equal(got.x, exp_xy[:L]) and np.array_equal(got.y, exp_xy[L:]), tag
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("window", [0, 3, 5, 8, 13])
+def test_golden_srs(cid, window, golden, ctx):
+    g = golden[cid]
+    ctx.set_msm_window(window)
+    try:
+        for n in (1, 2, 31, 32, 33, 1024):
+            got = zk.VariableBaseMSM.multi_scalar_mul(g["srs_1024"][:n], g[f"msm_srs_{n}_scalars"], cid, ctx=ctx)
+            assert_point(got, g[f"msm_srs_{n}_out"], g[f"msm_srs_{n}_inf"][0], cid, f"n={n} c={window}")
+    finally:
+        ctx.set_msm_window(0)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("window", [0, 2, 4, 16])
+def test_golden_edge_cases(cid, window, golden, ctx):
+    g = golden[cid]
+    ctx.set_msm_window(window)
+    try:
+        for name in CASES:
+            got = zk.VariableBaseMSM.multi_scalar_mul(g[f"msm_case_{name}_bases"], g[f"msm_case_{name}_scalars"], cid,
+                                                      infinity=g[f"msm_case_{name}_inf"], ctx=ctx)
+            assert_point(got, g[f"msm_case_{name}_out"], g[f"msm_case_{name}_outinf"][0], cid, f"{name} c={window}")
+    finally:
+        ctx.set_msm_window(0)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_truncates_to_shorter_and_empty(cid, golden, ctx):
+    g = golden[cid]
+    # VariableBaseMSM truncates to min(len(bases), len(scalars))
+    got = zk.VariableBaseMSM.multi_scalar_mul(g["srs_1024"][:40], g["msm_srs_33_scalars"], cid, ctx=ctx)
+    assert_point(got, g["msm_srs_33_out"], 0, cid)
+    got = zk.VariableBaseMSM.multi_scalar_mul(g["srs_1024"][:31], g["msm_srs_1024_scalars"][:31], cid, ctx=ctx)
+    exp = zk.VariableBaseMSM.multi_scalar_mul(g["srs_1024"][:31], g["msm_srs_1024_scalars"], cid, ctx=ctx)
+    assert got == exp
+    empty = zk.VariableBaseMSM.multi_scalar_mul(np.zeros((0, 2 * bo.CURVES[cid].fq_limbs), dtype=np.uint64),
+                                                np.zeros((0, 4), dtype=np.uint64), cid, ctx=ctx)
+    assert empty.infinity
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_fixed_base_srs_generator_matches_oracle(cid, golden, ctx):
+    """The synthetic-SRS utility (scalars[i] * G on device) reproduces the oracle's tau^i G."""
+    import torch
+    g = golden[cid]
+    cv = bo.CURVES[cid]
+    tau = int(g["srs_tau"][0][0])
+    n = 256
+    sc = zk.curves.ints_to_limbs([pow(tau, i, cv.r) for i in range(n)], 4)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_sc.data_ptr(), n, out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), g["srs_1024"][:n])
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 12), (0, 16), (1, 14)])
+def test_vs_cpu_oracle_medium(cid, log_n, ctx, oracle_cpu):
+    import torch
+    cv = bo.CURVES[cid]
+    n = 1 << log_n
+    rng = np.random.default_rng(77 + log_n)
+    # bases: k_i * G for random 64-bit k_i, generated on the GPU by the fixed-base utility
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    ks[:, 0] = rng.integers(1, 1 << 62, size=n, dtype=np.uint64)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_k.data_ptr(), n, bases.data_ptr()))
+    scal = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    scal[:, 3] &= np.uint64((1 << 60) - 1)
+    scal[5] = 0
+    scal[6] = (1, 0, 0, 0)
+    scal[7] = scal[8]
+    d_s = torch.from_numpy(scal.view(np.int64)).cuda()
+    got = zk.VariableBaseMSM.multi_scalar_mul(bases, d_s, cid, ctx=ctx)
+    exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases.cpu().numpy().view(np.uint64), scal)
+    assert_point(got, exp_xy, exp_inf, cid)
+
+
+def _kzg_identity(cid, log_n, ctx, skew=False):
+    """MSM(s, tau^i G) == (sum_i s_i tau^i mod r) G : O(N) big-int work, valid at any size."""
+    import torch
+    cv = bo.CURVES[cid]
+    n = 1 << log_n
+    tau = 0x7A5C0DE
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * tau % cv.r
+    sc_tau = zk.curves.ints_to_limbs(pw, 4)
+    d_tau = torch.from_numpy(sc_tau.view(np.int64)).cuda()
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_tau.data_ptr(), n, bases.data_ptr()))
+    rng = np.random.default_rng(log_n)
+    scal = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    scal[:, 3] &= np.uint64((1 << 61) - 1)
+    if skew:
+        # the benchmark circuit's wire values: a few small constants repeated (composer.rs:493-548)
+        small = zk.curves.ints_to_limbs([6, 7, cv.r - 20, 1], 4)
+        scal[: 3 * n // 4] = np.tile(small, (3 * n // 16, 1))
+    s_int = zk.curves.limbs_to_ints(scal)
+    acc = 0
+    for s, p in zip(s_int, pw):
+        acc += s * p
+    acc %= cv.r
+    exp = bo.ec_mul(cv, acc, (cv.gx, cv.gy))
+    ck = zk.CommitterKey(bases, cid, ctx)
+    got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
+    ck.close()
+    assert not got.infinity
+    assert zk.curves.fq_from_mont(cid, got.x.reshape(1, -1))[0] == exp[0]
+    assert zk.curves.fq_from_mont(cid, got.y.reshape(1, -1))[0] == exp[1]
+
+
+def test_kzg_identity_2_18_bn254(ctx):
+    _kzg_identity(1, 18, ctx)
+
+
+def test_kzg_identity_2_20(ctx):
+    _kzg_identity(0, 20, ctx)
+
+
+def test_kzg_identity_2_20_skewed_scalars(ctx):
+    _kzg_identity(0, 20, ctx, skew=True)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_kzg_commit_golden(cid, golden, ctx):
+    g = golden[cid]
+    ck = zk.CommitterKey(g["srs_1024"], cid, ctx)
+    for k in range(4):
+        got = ck.commit(g[f"kzg_poly_{k}"])
+        assert_point(got, g[f"kzg_commit_{k}"], 0, cid, f"poly {k}")
+    ck.close()
+
+
+def test_sharded_msm_partials_match_single(golden, ctx):
+    """Multi-GPU shape on one card: two point-shards -> Jacobian partials -> zk_g1_sum_partials."""
+    import torch
+    cid = 0
+    g = golden[cid]
+    n = 1024
+    ck = zk.CommitterKey(g["srs_1024"], cid, ctx)
+    sc = torch.from_numpy(g["msm_srs_1024_scalars"].view(np.int64)).cuda()
+    parts = [ck.msm_partial(sc[:600], 0), ck.msm_partial(sc[600:], 600)]
+    got = zk.sum_partials(np.stack(parts), cid)
+    assert_point(got, g["msm_srs_1024_out"], 0, cid)
+    ck.close()

@@ -1,0 +1,113 @@
+"""CPU suite: pins the oracle (C++ restatement of the ark 0.3 algorithms) against the definitional
+big-int oracle, the committed golden vectors and the external constants."""
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as bo
+
+
+def test_external_constants():
+    cv = bo.BLS12_381
+    # ark-bls12-381 0.3 Fr::TWO_ADIC_ROOT_OF_UNITY (decimal)
+    assert cv.root_of_unity(32) == 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    # [2]G1 of BLS12-381: x-coordinate of the published compressed encoding a572cbea...f0f4e
+    g2 = bo.ec_add(cv, (cv.gx, cv.gy), (cv.gx, cv.gy))
+    assert g2[0] == 0x0572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e
+    assert bo.on_curve(cv, g2)
+    # Montgomery R of Fr
+    assert (1 << 256) % cv.r == 0x1824b159acc5056f998c4fefecbc4ff55884b7fa0003480200000001fffffffe
+    for c in (bo.BLS12_381, bo.BN254):
+        assert bo.on_curve(c, (c.gx, c.gy))
+        w = c.root_of_unity(c.two_adicity)
+        assert pow(w, 1 << c.two_adicity, c.r) == 1 and pow(w, 1 << (c.two_adicity - 1), c.r) != 1
+        assert bo.ec_mul(c, c.r, (c.gx, c.gy)) is None  # generator has order r
+
+
+def test_ark_window_rule_and_add_counts():
+    # SURVEY.md appendix table
+    assert bo.ark_window_size(1 << 10) == 8 and bo.ark_window_size(1 << 20) == 15 and bo.ark_window_size(1 << 22) == 17
+    assert bo.ark_window_size(31) == 3 and bo.ark_window_size(1 << 18) == 14
+    assert bo.ark_msm_adds(1 << 20) == 18939870
+    assert bo.ark_msm_adds(1 << 22) == 66846690
+    assert bo.ark_msm_adds(1 << 18, 254) == 5603290
+    assert bo.ark_msm_adds(1 << 10) == 49088
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_dft_recursive_matches_definition(cid):
+    cv = bo.CURVES[cid]
+    for log_n in (0, 1, 2, 3, 5):
+        vals = bo.seeded_scalars(cv, 11 + log_n, 1 << log_n)
+        w = cv.root_of_unity(log_n)
+        assert bo.dft_naive(vals, w, cv.r) == bo.ntt(cv, bo.KIND_FFT, log_n, vals)
+        ev = bo.ntt(cv, bo.KIND_COSET_FFT, log_n, vals)
+        for i in (0, (1 << log_n) - 1):
+            assert ev[i] == bo.horner(vals, cv.fr_generator * pow(w, i, cv.r) % cv.r, cv.r)
+        assert bo.ntt(cv, bo.KIND_IFFT, log_n, bo.ntt(cv, bo.KIND_FFT, log_n, vals)) == vals
+        assert bo.ntt(cv, bo.KIND_COSET_IFFT, log_n, ev) == vals
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_cpu_oracle_ntt_matches_golden(cid, golden, oracle_cpu):
+    g = golden[cid]
+    keys = [k[:-3] for k in g.files if k.startswith("ntt_") and k.endswith("_in")]
+    assert len(keys) == 6 * 5 * 4
+    for key in keys:
+        _, log_n, _, kind = key.split("_")
+        got = oracle_cpu.ntt(cid, int(kind), int(log_n), g[key + "_in"])
+        assert np.array_equal(got, g[key + "_out"]), key
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_cpu_oracle_msm_matches_golden(cid, golden, oracle_cpu):
+    g = golden[cid]
+    srs = g["srs_1024"]
+    tau = int(g["srs_tau"][0][0])
+    assert np.array_equal(oracle_cpu.srs_powers(cid, tau, 64), srs[:64])
+    for n in (1, 2, 31, 32, 33, 1024):
+        out, inf = oracle_cpu.msm_g1(cid, srs[:n], g[f"msm_srs_{n}_scalars"])
+        assert np.array_equal(out, g[f"msm_srs_{n}_out"]) and inf == int(g[f"msm_srs_{n}_inf"][0]), n
+    for name in ("repeat", "cancel", "onebucket", "infbase", "zeros", "ones", "mixed", "maxscalar"):
+        out, inf = oracle_cpu.msm_g1(cid, g[f"msm_case_{name}_bases"], g[f"msm_case_{name}_scalars"], inf=g[f"msm_case_{name}_inf"])
+        assert inf == int(g[f"msm_case_{name}_outinf"][0]), name
+        assert np.array_equal(out, g[f"msm_case_{name}_out"]), name
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_cpu_oracle_kzg_matches_golden(cid, golden, oracle_cpu):
+    g = golden[cid]
+    srs = g["srs_1024"]
+    for k in range(4):
+        out, inf = oracle_cpu.kzg_commit(cid, srs, g[f"kzg_poly_{k}"])
+        assert inf == 0 and np.array_equal(out, g[f"kzg_commit_{k}"])
+    # open: RLC with Fr ops of the oracle, witness by synthetic division, commit
+    polys = [g[f"kzg_poly_{k}"] for k in range(4)]
+    m = max(p.shape[0] for p in polys)
+    comb = np.zeros((m, 4), dtype=np.uint64)
+    chi_pow = oracle_cpu.convert(cid, "fr", True, np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    for p in polys:
+        term = oracle_cpu.fr_op(cid, "mul", p, np.repeat(chi_pow, p.shape[0], axis=0))
+        comb[: p.shape[0]] = oracle_cpu.fr_op(cid, "add", comb[: p.shape[0]], term)
+        chi_pow = oracle_cpu.fr_op(cid, "mul", chi_pow, g["kzg_chi"].reshape(1, 4))
+    w = oracle_cpu.kzg_witness(cid, comb, g["kzg_z"])
+    out, inf = oracle_cpu.kzg_commit(cid, srs, w)
+    assert inf == int(g["kzg_open_inf"][0]) and np.array_equal(out, g["kzg_open"])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_cpu_oracle_medium_properties(cid, oracle_cpu):
+    """2^12 round trips + Horner spot checks of the C++ restatement (too big for the big-int DFT)."""
+    cv = bo.CURVES[cid]
+    log_n = 12
+    n = 1 << log_n
+    vals = bo.seeded_scalars(cv, 0xABC + cid, n // 4)
+    vm = oracle_cpu.convert(cid, "fr", True, oracle_cpu.ints_to_limbs(vals, 4))
+    ev = oracle_cpu.ntt(cid, bo.KIND_COSET_FFT, log_n, vm)
+    back = oracle_cpu.ntt(cid, bo.KIND_COSET_IFFT, log_n, ev)
+    assert np.array_equal(back[: n // 4], vm) and not back[n // 4:].any()
+    evi = oracle_cpu.limbs_to_ints(oracle_cpu.convert(cid, "fr", False, ev))
+    w = cv.root_of_unity(log_n)
+    for i in (0, 1, 777, n - 1):
+        assert evi[i] == bo.horner(vals, cv.fr_generator * pow(w, i, cv.r) % cv.r, cv.r)
+    ev2 = oracle_cpu.ntt(cid, bo.KIND_FFT, log_n, vm)
+    assert np.array_equal(oracle_cpu.ntt(cid, bo.KIND_IFFT, log_n, ev2)[: n // 4], vm)

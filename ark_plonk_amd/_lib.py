@@ -47,6 +47,7 @@ SYMBOLS = {
     "zk_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "zk_ctx_destroy": (None, [c_void_p]),
     "zk_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "zk_ctx_use_own_stream": (c_int, [c_void_p]),
     "zk_ctx_sync": (c_int, [c_void_p]),
     "zk_ctx_set_msm_window": (c_int, [c_void_p, c_int]),
     "zk_profile_enable": (c_int, [c_void_p, c_int]),
@@ -100,6 +101,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m ark_plonk_amd.build` (hipcc, gfx950). "
                 "ark_plonk_amd has no CPU fallback."
             )
+        # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP
+        # runtimes in one process leave the second without devices, so when torch is installed let
+        # it load its runtime first; our library then binds to the copy already in the process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -1,18 +1,42 @@
-"""Build the gfx950 shared library (hipcc, in-tree).  `python -m ark_plonk_amd.build`."""
+"""Build the gfx950 shared library (hipcc, in-tree).  `python -m ark_plonk_amd.build [--force]`.
+
+The heavy kernels are compiled as separate objects -- one per (curve, NTT radix exponent) and one MSM
+object per curve -- so a full build parallelises over the host cores and an edit rebuilds only what
+it touches.
+"""
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libark_plonk_amd.so")
-SOURCES = ["api.hip", "ntt.hip", "msm.hip", "kzg.hip"]
-HEADERS = ["ctx.h", "field.cuh", "ec.cuh", "curve_params.h", "zk_common.h", "../../include/ark_plonk_amd.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+FIELD_HDRS = ["field.cuh", "curve_params.h", "zk_common.h"]
+HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]
+
+
+def jobs():
+    """(object name, source, extra defines, header deps)"""
+    out = [
+        ("api.o", "api.hip", [], HOST_HDRS),
+        ("kzg.o", "kzg.hip", [], HOST_HDRS),
+        ("ntt.o", "ntt.hip", [], HOST_HDRS + ["ntt_pass.cuh"]),
+        ("ntt_pass_table.o", "ntt_pass_table.hip", [], []),
+        ("msm_dispatch.o", "msm_dispatch.hip", [], HOST_HDRS),
+    ]
+    for c in (0, 1):
+        out.append((f"msm_c{c}.o", "msm.hip", [f"-DZK_CURVE_SEL={c}"], HOST_HDRS))
+        for s in range(3, 11):
+            out.append((f"ntt_pass_c{c}_s{s}.o", "ntt_pass_inst.hip", [f"-DZK_CURVE_SEL={c}", f"-DZK_NTT_S={s}"],
+                        FIELD_HDRS + ["ntt_pass.cuh"]))
+    return out
 
 
 def _stale(target: str, deps) -> bool:
@@ -22,26 +46,37 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+def build(force: bool = False, verbose: bool = False, workers: int | None = None) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    todo = []
     objs = []
-    procs = []
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    for obj, src, defs, hdrs in jobs():
+        o = os.path.join(OBJ, obj)
+        objs.append(o)
+        deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in hdrs]
+        if force or _stale(o, deps):
+            todo.append([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", o])
+    # heaviest first (large S, MSM) so the tail of the build is short
+    todo.sort(key=lambda c: (0 if "msm.hip" in " ".join(c) else 1, -int(next((d.split("=")[1] for d in c if d.startswith("-DZK_NTT_S=")), 0))))
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stderr[-4000:])
+        return r.stderr
+
+    if todo:
+        n = workers or min(len(todo), max(1, (os.cpu_count() or 4)))
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            for err in ex.map(run, todo):
+                if verbose and err.strip():
+                    print(err, file=sys.stderr)
+    if force or todo or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd[:6]), "...", flush=True)
         subprocess.check_call(cmd)
     return LIB
 

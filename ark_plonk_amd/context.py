@@ -47,11 +47,17 @@ class Context:
 
     # -- stream / sync
     def set_stream(self, stream):
-        """stream: int/ctypes pointer (hipStream_t) or a torch.cuda.Stream; None = ctx's own."""
-        ptr = None
-        if stream is not None:
-            ptr = getattr(stream, "cuda_stream", stream)
+        """stream: hipStream_t as int (0 = HIP's default stream) or a torch.cuda.Stream;
+        None = back to the ctx's own stream."""
+        if stream is None:
+            check(lib().zk_ctx_use_own_stream(self.handle), "zk_ctx_use_own_stream")
+            self._stream_ptr = None
+            return
+        ptr = int(getattr(stream, "cuda_stream", stream))
+        if getattr(self, "_stream_ptr", None) == ptr:
+            return
         check(lib().zk_ctx_set_stream(self.handle, ctypes.c_void_p(ptr)), "zk_ctx_set_stream")
+        self._stream_ptr = ptr
 
     def use_torch_stream(self):
         import torch

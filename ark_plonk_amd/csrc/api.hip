@@ -166,7 +166,15 @@ int zk_ctx_set_stream(zk_ctx* c, void* hip_stream) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;
+    return ZK_OK;
+}
+
+int zk_ctx_use_own_stream(zk_ctx* c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return ZK_OK;
 }
 

@@ -521,26 +521,37 @@ int sum_partials(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8
 
 }  // namespace
 
-int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz) {
-    if (curve == ZK_CURVE_BLS12_381) return msm_run<CurveBls>(c, d_bases_xy, d_scalars, n, out_xyz);
-    if (curve == ZK_CURVE_BN254) return msm_run<CurveBn>(c, d_bases_xy, d_scalars, n, out_xyz);
-    return ZK_ERR_BAD_ARG;
+// Built once per curve (-DZK_CURVE_SEL=<0|1>); msm_dispatch.hip dispatches on the curve id.
+#if ZK_CURVE_SEL == 0
+typedef CurveBls CurveSel;
+#define ZK_SYM(name) name##_c0
+#else
+typedef CurveBn CurveSel;
+#define ZK_SYM(name) name##_c1
+#endif
+
+int ZK_SYM(msm_run_dev)(zk_ctx* c, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    return msm_run<CurveSel>(c, d_bases_xy, d_scalars, n, out_xyz);
 }
 
-int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy) {
+int ZK_SYM(msm_fixed_base_dev)(zk_ctx* c, const void* d_scalars, size_t n, void* d_out_xy) {
     if (n == 0) return ZK_OK;
     const int T = 128;
     unsigned blocks = (unsigned)((n + T - 1) / T);
-    if (curve == ZK_CURVE_BLS12_381)
-        hipLaunchKernelGGL(g1_fixed_base<CurveBls>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
-    else if (curve == ZK_CURVE_BN254)
-        hipLaunchKernelGGL(g1_fixed_base<CurveBn>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
-    else
-        return ZK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(g1_fixed_base<CurveSel>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
 
+int ZK_SYM(g1_jacobian_to_affine_host)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    return jac_to_affine<CurveSel::Fq>(xyz, out_xy, out_inf);
+}
+
+int ZK_SYM(g1_sum_partials_host)(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    return sum_partials<CurveSel::Fq>(partials, count, out_xy, out_inf);
+}
+
+#if ZK_CURVE_SEL == 0
 int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_inf, size_t n) {
     if (n == 0 || !d_inf) return ZK_OK;
     uint32_t u4 = curve == ZK_CURVE_BLS12_381 ? 6 : 4;
@@ -550,15 +561,4 @@ int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_in
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
-
-int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
-    if (curve == ZK_CURVE_BLS12_381) return jac_to_affine<FqBls>(xyz, out_xy, out_inf);
-    if (curve == ZK_CURVE_BN254) return jac_to_affine<FqBn>(xyz, out_xy, out_inf);
-    return ZK_ERR_BAD_ARG;
-}
-
-int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
-    if (curve == ZK_CURVE_BLS12_381) return sum_partials<FqBls>(partials, count, out_xy, out_inf);
-    if (curve == ZK_CURVE_BN254) return sum_partials<FqBn>(partials, count, out_xy, out_inf);
-    return ZK_ERR_BAD_ARG;
-}
+#endif

@@ -1,0 +1,31 @@
+// Curve dispatch for the per-curve MSM objects (msm.hip built with -DZK_CURVE_SEL=0/1).
+#include "ctx.h"
+
+#define DECLS(sfx)                                                                                                    \
+    int msm_run_dev##sfx(zk_ctx* c, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);       \
+    int msm_fixed_base_dev##sfx(zk_ctx* c, const void* d_scalars, size_t n, void* d_out_xy);                           \
+    int g1_jacobian_to_affine_host##sfx(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);                      \
+    int g1_sum_partials_host##sfx(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+DECLS(_c0)
+DECLS(_c1)
+
+int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    if (curve == ZK_CURVE_BLS12_381) return msm_run_dev_c0(c, d_bases_xy, d_scalars, n, out_xyz);
+    if (curve == ZK_CURVE_BN254) return msm_run_dev_c1(c, d_bases_xy, d_scalars, n, out_xyz);
+    return ZK_ERR_BAD_ARG;
+}
+int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy) {
+    if (curve == ZK_CURVE_BLS12_381) return msm_fixed_base_dev_c0(c, d_scalars, n, d_out_xy);
+    if (curve == ZK_CURVE_BN254) return msm_fixed_base_dev_c1(c, d_scalars, n, d_out_xy);
+    return ZK_ERR_BAD_ARG;
+}
+int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    if (curve == ZK_CURVE_BLS12_381) return g1_jacobian_to_affine_host_c0(xyz, out_xy, out_inf);
+    if (curve == ZK_CURVE_BN254) return g1_jacobian_to_affine_host_c1(xyz, out_xy, out_inf);
+    return ZK_ERR_BAD_ARG;
+}
+int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (curve == ZK_CURVE_BLS12_381) return g1_sum_partials_host_c0(partials, count, out_xy, out_inf);
+    if (curve == ZK_CURVE_BN254) return g1_sum_partials_host_c1(partials, count, out_xy, out_inf);
+    return ZK_ERR_BAD_ARG;
+}

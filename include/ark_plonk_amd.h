@@ -58,8 +58,11 @@ const char* zk_strerror(int code);
 /* Create a context on HIP device `device` (one process per GPU). */
 int zk_ctx_create(int device, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
-/* Run all work of this ctx on an existing HIP stream (hipStream_t as void*; NULL = ctx's own). */
+/* Run all work of this ctx on an existing HIP stream (hipStream_t as void*).  NULL is HIP's
+ * default (null) stream -- e.g. torch's default stream -- not "none". */
 int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
+/* Go back to the ctx's own non-blocking stream (the state after zk_ctx_create). */
+int zk_ctx_use_own_stream(zk_ctx* ctx);
 /* Block until all queued work of this ctx is complete. */
 int zk_ctx_sync(zk_ctx* ctx);
 /* Override the MSM window size c (0 = automatic). Test/tuning hook. */

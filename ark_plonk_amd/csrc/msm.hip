@@ -145,16 +145,12 @@ ZK_D bool affine_is_null(const Affine<Fq>& p) { return p.x.is_zero() && p.y.is_z
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
 template <class Fq>
 __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
-                               void* buckets, void* part_pt, int32_t* part_key, uint32_t L, uint32_t n_lanes) {
+                               void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
     const uint32_t E = offsets[nb];
     const uint64_t e0 = (uint64_t)t * L;
-    if (e0 >= E) {
-        part_key[2 * t] = -1;
-        part_key[2 * t + 1] = -1;
-        return;
-    }
+    if (e0 >= E) return;
     const uint32_t e1 = (uint32_t)min((uint64_t)E, e0 + L);
     // largest b with offsets[b] <= e0
     uint32_t lo = 0, hi = nb - 1;
@@ -166,13 +162,11 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     uint32_t bend = offsets[b + 1];
     const bool head_partial = offsets[b] < (uint32_t)e0;
     bool first_run = true;
-    int32_t key0 = -1;
     XYZZ<Fq> acc = XYZZ<Fq>::infinity();
     for (uint32_t e = (uint32_t)e0; e < e1; ++e) {
         if (e == bend) {
             if (first_run && head_partial) {
                 st_xyzz<Fq>(part_pt, 2ull * t, acc);
-                key0 = (int32_t)b;
             } else {
                 st_xyzz<Fq>(buckets, b, acc);
             }
@@ -188,45 +182,112 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
         if (ref >> 31) p.y = Fq::neg(p.y);
         if (!affine_is_null(p)) acc = XYZZ<Fq>::madd(acc, p);
     }
+    // Slot convention (msm_combine relies on it): a run that is the FIRST run of its chunk and is
+    // not a whole bucket goes to slot 2t, a trailing incomplete run that is not the first goes to 2t+1.
     const bool tail_complete = (e1 == bend);
-    int32_t key1 = -1;
     if (first_run) {
-        if (head_partial || !tail_complete) {
-            st_xyzz<Fq>(part_pt, 2ull * t, acc);
-            key0 = (int32_t)b;
-        } else {
-            st_xyzz<Fq>(buckets, b, acc);
-        }
+        if (head_partial || !tail_complete) st_xyzz<Fq>(part_pt, 2ull * t, acc);
+        else st_xyzz<Fq>(buckets, b, acc);
     } else {
-        if (tail_complete) {
-            st_xyzz<Fq>(buckets, b, acc);
-        } else {
-            st_xyzz<Fq>(part_pt, 2ull * t + 1, acc);
-            key1 = (int32_t)b;
-        }
+        if (tail_complete) st_xyzz<Fq>(buckets, b, acc);
+        else st_xyzz<Fq>(part_pt, 2ull * t + 1, acc);
     }
-    part_key[2 * t] = key0;
-    part_key[2 * t + 1] = key1;
 }
 
-// one lane per partial slot; the first slot of each key sums the slots that follow with that key
+constexpr uint32_t COMBINE_SMALL = 8;      // buckets spanning <= this many chunks: summed by one lane
+constexpr uint32_t COMBINE_MEDIUM = 2048;  // <= this many: one wavefront per bucket; above: one workgroup
+
 template <class Fq>
-__global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const int32_t* part_key, uint32_t n_slots, void* buckets) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots) return;
-    const int32_t k = part_key[s];
-    if (k < 0) return;
-    int64_t p = (int64_t)s - 1;
-    while (p >= 0 && part_key[p] < 0) --p;
-    if (p >= 0 && part_key[p] == k) return;
-    XYZZ<Fq> acc = ld_xyzz<Fq>(part_pt, s);
-    for (uint32_t q = s + 1; q < n_slots; ++q) {
-        const int32_t kq = part_key[q];
-        if (kq < 0) continue;
-        if (kq != k) break;
-        acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, q));
+ZK_D uint64_t partial_slot(uint32_t t, uint32_t ta, uint32_t s, uint32_t L) {
+    return (t == ta && (s % L) != 0) ? 2ull * t + 1 : 2ull * t;
+}
+
+// butterfly-free wave reduction: lane 0 ends with the sum of all 64 lanes (order irrelevant: abelian group)
+template <class Fq>
+ZK_D XYZZ<Fq> wave_sum(XYZZ<Fq> acc) {
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        XYZZ<Fq> o;
+#pragma unroll
+        for (int i = 0; i < Fq::N; ++i) {
+            o.x.v[i] = __shfl_down(acc.x.v[i], d, 64);
+            o.y.v[i] = __shfl_down(acc.y.v[i], d, 64);
+            o.zz.v[i] = __shfl_down(acc.zz.v[i], d, 64);
+            o.zzz.v[i] = __shfl_down(acc.zzz.v[i], d, 64);
+        }
+        acc = XYZZ<Fq>::add(acc, o);
     }
-    st_xyzz<Fq>(buckets, (uint32_t)k, acc);
+    return acc;
+}
+
+// One lane per bucket: a bucket whose entries span p >= 2 chunks has exactly p partials at slots
+// known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued for the
+// wavefront-per-bucket / workgroup-per-bucket kernels below.
+// queues: q[0] = medium count, q[1] = large count, q[2 ..] medium ids (grow up), q[.. 2+nb) large ids (grow down)
+template <class Fq>
+__global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L, void* buckets,
+                                                    uint32_t* q) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    if (e == s) return;
+    const uint32_t ta = s / L, tb = (e - 1) / L;
+    if (ta == tb) return;  // whole bucket inside one chunk: already complete
+    const uint32_t p = tb - ta + 1;
+    if (p > COMBINE_MEDIUM) {
+        q[2 + nb - 1 - atomicAdd(&q[1], 1u)] = b;
+        return;
+    }
+    if (p > COMBINE_SMALL) {
+        q[2 + atomicAdd(&q[0], 1u)] = b;
+        return;
+    }
+    XYZZ<Fq> acc = ld_xyzz<Fq>(part_pt, partial_slot<Fq>(ta, ta, s, L));
+    for (uint32_t t = ta + 1; t <= tb; ++t) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, 2ull * t));
+    st_xyzz<Fq>(buckets, b, acc);
+}
+
+// medium buckets: one wavefront per bucket, lanes stride over its partials, shuffle tree
+template <class Fq>
+__global__ void __launch_bounds__(256) msm_combine_wave(const void* part_pt, const uint32_t* offsets, uint32_t L, void* buckets,
+                                                         const uint32_t* q) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nm = q[0];
+    for (uint32_t h = wave; h < nm; h += n_waves) {
+        const uint32_t b = q[2 + h];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t ta = s / L, tb = (e - 1) / L;
+        XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+        for (uint32_t t = ta + lane; t <= tb; t += 64) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, partial_slot<Fq>(t, ta, s, L)));
+        acc = wave_sum<Fq>(acc);
+        if (lane == 0) st_xyzz<Fq>(buckets, b, acc);
+    }
+}
+
+// large buckets (heavily skewed scalars): one 256-lane workgroup per bucket
+template <class Fq>
+__global__ void __launch_bounds__(256) msm_combine_block(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L,
+                                                          void* buckets, const uint32_t* q) {
+    extern __shared__ uint4 sh[];
+    const uint32_t u = threadIdx.x;
+    const uint32_t nl = q[1];
+    for (uint32_t h = blockIdx.x; h < nl; h += gridDim.x) {
+        const uint32_t b = q[2 + nb - 1 - h];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t ta = s / L, tb = (e - 1) / L;
+        XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+        for (uint32_t t = ta + u; t <= tb; t += 256) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, partial_slot<Fq>(t, ta, s, L)));
+        acc = wave_sum<Fq>(acc);
+        __syncthreads();
+        if ((u & 63) == 0) st_xyzz<Fq>(sh, u >> 6, acc);
+        __syncthreads();
+        if (u == 0) {
+            for (uint32_t w = 1; w < 4; ++w) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(sh, w));
+            st_xyzz<Fq>(buckets, b, acc);
+        }
+    }
 }
 
 // level 1 of the per-window reduction: segment s of window w covers buckets [s*G, (s+1)*G)
@@ -392,7 +453,7 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
     if ((rc = c->msm_entries.ensure((size_t)e_max * 4))) return rc;
     if ((rc = c->msm_buckets.ensure((size_t)g.nb * sizeof(P)))) return rc;
     if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * sizeof(P)))) return rc;
-    if ((rc = c->msm_part_key.ensure((size_t)n_lanes * 2 * 4))) return rc;
+    if ((rc = c->msm_part_key.ensure((size_t)(g.nb + 2) * 4))) return rc;   // combine queues: [n_medium, n_large, ids...]
     if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * sizeof(P)))) return rc;
     if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(P)))) return rc;
     uint32_t* counts = (uint32_t*)c->msm_counts.p;
@@ -418,15 +479,19 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         const int T = 128;
         unsigned blocks = (n_lanes + T - 1) / T;
         hipLaunchKernelGGL(msm_accumulate<Fq>, dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
-                           c->msm_part_pt.p, (int32_t*)c->msm_part_key.p, CHUNK_L, n_lanes);
+                           c->msm_part_pt.p, CHUNK_L, n_lanes);
         ZK_HIP_TRY(hipGetLastError());
     }
     {
         ProfScope ps(c, "msm_reduce");
         const int T = 128;
-        unsigned blocks = (2 * n_lanes + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<Fq>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, (const int32_t*)c->msm_part_key.p, 2 * n_lanes,
-                           c->msm_buckets.p);
+        uint32_t* q = (uint32_t*)c->msm_part_key.p;
+        ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
+        unsigned blocks = (g.nb + T - 1) / T;
+        hipLaunchKernelGGL(msm_combine<Fq>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_wave<Fq>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<Fq>, dim3(256), dim3(256), 4 * sizeof(P), st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
+                           c->msm_buckets.p, q);
         unsigned sblocks = (g.W * g.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<Fq>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
         size_t shmem = 256 * sizeof(P);

@@ -1,0 +1,132 @@
+"""The hot-path call schedule of one `Prover::prove_with_preprocessed` (plonk-core/src/proof_system/
+prover.rs:163-638), replayed through the C ABI on device-resident data.
+
+Only the transforms and commitments are reproduced -- the same kinds, sizes and order the reference
+issues them: 13 ifft(n) + 4 fft(n) + 13 coset_fft(4n) + 1 coset_ifft(4n) and 29 MSMs
+of ~n points.  The serial CPU glue between them (transcript, grand products, quotient evaluation,
+linearisation) is out of scope, so polynomial *values* here are synthetic;
+what is preserved is which buffers feed which call and their lengths, e.g. the coset_fft inputs have
+n coefficients zero-extended to 4n (quotient_poly.rs:72-120) and the openings are MSMs of n-1.
+
+Multi-GPU (one process per GPU): every MSM is sharded by points over the ranks -- rank g owns
+SRS[g*n/G, (g+1)*n/G) -- and combined by an all-gather of the 3L-limb Jacobian partials (RCCL over
+xGMI); the NTTs are replicated per rank (they stay single-GPU, BASELINE.json north_star).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .curves import get_curve
+from .domain import Radix2EvaluationDomain
+from .msm import CommitterKey, sum_partials
+
+
+class ProofSchedule:
+    def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
+                 dist=None, seed: int = 0x5EED0000):
+        import torch
+        self.torch = torch
+        self.cv = get_curve(curve)
+        self.log_n = log_n
+        self.n = 1 << log_n
+        self.ctx = ctx
+        self.ck = ck
+        self.rank, self.world, self.dist = rank, world, dist
+        self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
+        self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
+        dev = torch.device("cuda", ctx.device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        n = self.n
+
+        def rnd(rows):
+            # uniform 254-bit residues (< r for both curves' 4-limb Fr): valid Montgomery elements
+            t = torch.randint(0, 1 << 62, (rows, 4), dtype=torch.int64, device=dev, generator=g)
+            return t
+
+        # 17 distinct polynomials of the proof: w_l w_r w_o w_4 | f h1 h2 | z z2 | t1..t4 | lin table | 2 witnesses
+        self.evals = [rnd(n) for _ in range(4)]          # wire evaluations (prover.rs:188-192)
+        self.aux_evals = [rnd(n) for _ in range(9)]      # table, f, h1, h2, z, z2, pi, l1, l1*alpha^2 evaluation vectors
+        self.sigma = [rnd(n) for _ in range(4)]          # sigma polynomials (coefficients, from the prover key)
+        self.coef = [torch.empty((n, 4), dtype=torch.int64, device=dev) for _ in range(13)]
+        self.ev4n = torch.empty((4 * n, 4), dtype=torch.int64, device=dev)
+        self.quot = rnd(4 * n)                            # quotient evaluations over the coset
+        self.scratch_n = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        # shard of the SRS this rank owns
+        self.lo = rank * n // world
+        self.hi = (rank + 1) * n // world
+        self.points = []
+
+    # -- one commitment = into_repr + MSM over this rank's shard (+ all-gather when world > 1)
+    def _commit(self, coeffs, length=None):
+        length = self.n if length is None else length
+        lo, hi = self.lo, min(self.hi, length)
+        if self.world == 1:
+            return self.ck.commit(coeffs[:length])
+        torch = self.torch
+        from ._lib import check, lib
+        from .context import ptr_of
+        sc = self.scratch_n[: max(hi - lo, 0)]
+        if hi > lo:
+            self.ctx.use_torch_stream()
+            check(lib().zk_fr_from_mont_dev(self.ctx.handle, self.cv.curve_id, ptr_of(coeffs[lo:hi]), hi - lo, ptr_of(sc)))
+            part = self.ck.msm_partial(sc, 0)
+        else:
+            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)
+            part[0] = part[self.cv.fq_limbs] = 1
+        mine = torch.from_numpy(part.view(np.int64)).to(coeffs.device)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine)
+        allp = torch.stack(gathered).cpu().numpy().view(np.uint64)
+        return sum_partials(allp, self.cv.curve_id)
+
+    def run_once(self):
+        """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
+        d, d4, n = self.dom_n, self.dom_4n, self.n
+        out = []
+        c = self.coef
+        # Round 1: 4 ifft + 4 commits (prover.rs:196-203, 213)
+        for i in range(4):
+            c[i] = d.ifft(self.evals[i])
+        for i in range(4):
+            out.append(self._commit(c[i]))
+        # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
+        c[4] = d.ifft(self.aux_evals[0])          # table_poly
+        c[5] = d.ifft(self.aux_evals[1])          # f_poly
+        out.append(self._commit(c[5]))
+        c[6] = d.ifft(self.aux_evals[2])          # h1
+        c[7] = d.ifft(self.aux_evals[3])          # h2
+        out.append(self._commit(c[6]))
+        out.append(self._commit(c[7]))
+        # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
+        for i in range(4):
+            d.fft(self.sigma[i])
+        c[8] = d.ifft(self.aux_evals[4])          # z
+        out.append(self._commit(c[8]))
+        c[9] = d.ifft(self.aux_evals[5])          # z2
+        out.append(self._commit(c[9]))
+        c[10] = d.ifft(self.aux_evals[6])         # pi
+        # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
+        c[11] = d.ifft(self.aux_evals[7])         # l1
+        for poly in (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10]):
+            d4._run(2, poly, out=self.ev4n)       # coset_fft, n coefficients zero-extended to 4n
+        c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
+        d4._run(2, c[12], out=self.ev4n)
+        t = d4.coset_ifft(self.quot)              # quotient polynomial, 4n coefficients
+        for i in range(4):                        # t_1..t_4 (prover.rs:455-469)
+            out.append(self._commit(t[i * n:(i + 1) * n]))
+        # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618)
+        for poly in (c[5], c[6], c[7], c[8], c[9], c[4], c[11]):
+            out.append(self._commit(poly))
+        out.append(self._commit(c[12], n - 1))    # witness of the aggregate opening: n-1 coefficients
+        for poly in (c[8], c[0], c[1], c[3], c[6], c[9], c[4]):
+            out.append(self._commit(poly))
+        out.append(self._commit(c[10], n - 1))
+        assert len(out) == 29
+        return out
+
+    # work counters for the report
+    def ntt_bytes(self) -> int:
+        return 17 * 2 * 32 * self.n + 14 * 2 * 32 * 4 * self.n
+
+    def msm_count(self) -> int:
+        return 29

@@ -294,60 +294,21 @@ int zk_fr_mul_dev(zk_ctx* c, int curve_id, const void* d_a, const void* d_b, siz
 }
 
 // ------------------------------------------------------------------------------------------ MSM
-int zk_srs_register_dev(zk_ctx* c, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out) {
-    if (!c || !out || (n && !d_bases_xy)) return ZK_ERR_BAD_ARG;
-    int L = fq_limbs64(curve_id);
-    if (!L) return ZK_ERR_BAD_ARG;
-    Guard g(c);
+// shared tail of the two registration entry points: d_sat = arkworks-layout points on the device
+static int srs_build(zk_ctx* c, int curve_id, const void* d_sat, const uint8_t* d_inf, size_t n, zk_srs** out) {
     zk_srs* s = new zk_srs();
     s->ctx = c;
     s->curve = curve_id;
     s->n = n;
-    size_t bytes = n * 2 * L * 8;
+    s->point_bytes = msm_point_bytes(curve_id);
     if (n) {
-        hipError_t e = hipMalloc(&s->d_xy, bytes);
-        if (e != hipSuccess) {
+        if (hipMalloc(&s->d_xy, n * s->point_bytes) != hipSuccess) {
             delete s;
             return ZK_ERR_OOM;
         }
-        e = hipMemcpyAsync(s->d_xy, d_bases_xy, bytes, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            (void)hipFree(s->d_xy);
-            delete s;
-            return ZK_ERR_HIP;
-        }
-    }
-    *out = s;
-    return ZK_OK;
-}
-
-int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out) {
-    if (!c || !out || (n && !bases_xy)) return ZK_ERR_BAD_ARG;
-    int L = fq_limbs64(curve_id);
-    if (!L) return ZK_ERR_BAD_ARG;
-    Guard g(c);
-    zk_srs* s = new zk_srs();
-    s->ctx = c;
-    s->curve = curve_id;
-    s->n = n;
-    size_t bytes = n * 2 * L * 8;
-    if (n) {
-        if (hipMalloc(&s->d_xy, bytes) != hipSuccess) {
-            delete s;
-            return ZK_ERR_OOM;
-        }
-        hipError_t e = hipMemcpyAsync(s->d_xy, bases_xy, bytes, hipMemcpyHostToDevice, c->stream);
-        int rc = ZK_OK;
-        if (e == hipSuccess && inf_flags) {
-            rc = c->msm_tmp.ensure(n);
-            if (!rc) {
-                e = hipMemcpyAsync(c->msm_tmp.p, inf_flags, n, hipMemcpyHostToDevice, c->stream);
-                if (e == hipSuccess) rc = msm_sanitize_bases_dev(c, curve_id, s->d_xy, (const uint8_t*)c->msm_tmp.p, n);
-            }
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess || rc) {
+        int rc = msm_convert_bases_dev(c, curve_id, d_sat, d_inf, n, s->d_xy);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (rc || e != hipSuccess) {
             (void)hipFree(s->d_xy);
             delete s;
             return rc ? rc : ZK_ERR_HIP;
@@ -355,6 +316,34 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
     }
     *out = s;
     return ZK_OK;
+}
+
+int zk_srs_register_dev(zk_ctx* c, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out) {
+    if (!c || !out || (n && !d_bases_xy)) return ZK_ERR_BAD_ARG;
+    if (!fq_limbs64(curve_id)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return srs_build(c, curve_id, d_bases_xy, nullptr, n, out);
+}
+
+int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out) {
+    if (!c || !out || (n && !bases_xy)) return ZK_ERR_BAD_ARG;
+    int L = fq_limbs64(curve_id);
+    if (!L) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    const size_t bytes = n * 2 * L * 8;
+    int rc = c->io_b.ensure(bytes ? bytes : 1);
+    if (rc) return rc;
+    const uint8_t* d_inf = nullptr;
+    if (n) {
+        ZK_HIP_TRY(hipMemcpyAsync(c->io_b.p, bases_xy, bytes, hipMemcpyHostToDevice, c->stream));
+        if (inf_flags) {
+            rc = c->msm_tmp.ensure(n);
+            if (rc) return rc;
+            ZK_HIP_TRY(hipMemcpyAsync(c->msm_tmp.p, inf_flags, n, hipMemcpyHostToDevice, c->stream));
+            d_inf = (const uint8_t*)c->msm_tmp.p;
+        }
+    }
+    return srs_build(c, curve_id, c->io_b.p, d_inf, n, out);
 }
 
 void zk_srs_free(zk_srs* s) {
@@ -372,8 +361,7 @@ size_t zk_srs_len(const zk_srs* s) { return s ? s->n : 0; }
 static int srs_slice(zk_srs* s, size_t base_offset, size_t n, const void** d_bases) {
     if (!s) return ZK_ERR_BAD_ARG;
     if (base_offset > s->n || n > s->n - base_offset) return ZK_ERR_BAD_ARG;
-    int L = fq_limbs64(s->curve);
-    *d_bases = (const char*)s->d_xy + base_offset * 2 * L * 8;
+    *d_bases = (const char*)s->d_xy + base_offset * s->point_bytes;
     return ZK_OK;
 }
 

@@ -12,6 +12,7 @@
 #include "../../include/ark_plonk_amd.h"
 #include "curve_params.h"
 #include "ec.cuh"
+#include "ecu.cuh"
 
 typedef Fp<FrBls12_381Params> FrBls;
 typedef Fp<FqBls12_381Params> FqBls;
@@ -23,6 +24,8 @@ struct CurveBls {
     typedef FqBls Fq;
     typedef FrBls12_381Params FrP;
     typedef FqBls12_381Params FqP;
+    typedef Fu<FqBls12_381UParams> FqU;   // device hot-path representation (29-bit limbs)
+    typedef Fu<FrBls12_381UParams> FrU;
     static constexpr int ID = ZK_CURVE_BLS12_381;
 };
 struct CurveBn {
@@ -30,6 +33,8 @@ struct CurveBn {
     typedef FqBn Fq;
     typedef FrBn254Params FrP;
     typedef FqBn254Params FqP;
+    typedef Fu<FqBn254UParams> FqU;
+    typedef Fu<FrBn254UParams> FrU;
     static constexpr int ID = ZK_CURVE_BN254;
 };
 
@@ -121,7 +126,9 @@ struct zk_srs {
     zk_ctx* ctx = nullptr;
     int curve = 0;
     size_t n = 0;
-    void* d_xy = nullptr;   // n x 2L limbs, Montgomery; infinity encoded as x = y = 0
+    void* d_xy = nullptr;   // n points in the device-internal form (2 x Fu, 29-bit limbs, padded to 16 B);
+                            // "no point" (infinity) is all-zero limbs
+    size_t point_bytes = 0;
 };
 
 // profiling helpers (ctx mutex held by caller)
@@ -145,7 +152,9 @@ int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, voi
 // out_xyz: Jacobian (X,Y,Z) 3L u64 limbs on host.
 int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);
 int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy);
-int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_inf, size_t n);
+// arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
+int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal);
+size_t msm_point_bytes(int curve);
 int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,

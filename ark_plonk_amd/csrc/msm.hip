@@ -5,16 +5,19 @@
 // (proof_system/prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,582-591,606,609-618).
 //
 // Pipeline (all on the ctx stream; no host round trip until the W window sums are read back):
-//   1. msm_count      signed c-bit digits of every scalar -> per-(window,bucket) histogram
+//   1. msm_digits<0>  signed c-bit digits of every scalar -> per-(window,bucket) histogram
 //   2. msm_scan       exclusive scan of the histogram -> bucket offsets (+ scatter cursors)
-//   3. msm_scatter    counting-sort the (point, sign) references by (window, bucket)
+//   3. msm_digits<1>  counting-sort the (point, sign) references by (window, bucket)
 //   4. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
 //                     additions (8M+2S, no inversion); runs that cross a chunk edge are emitted
 //                     as partials (load-balanced regardless of the scalar distribution)
-//   5. msm_combine    joins the chunk-edge partials of each bucket
+//   5. msm_combine*   joins the chunk-edge partials of each bucket: lane / wavefront (shuffle tree) /
+//                     workgroup per bucket by size class
 //   6. msm_seg_reduce per-window segmented running-sum reduction (sum_j j*B_j), level 1
-//   7. msm_win_finish per-window LDS suffix-scan + tree reduction -> W window sums
+//   7. msm_win_finish per-window LDS suffix-scan + tree reduction -> W window sums (arkworks layout)
 //   host: Horner over the W window sums (W*c doublings) and affine normalisation.
+// Device arithmetic is the unsaturated 29-bit-limb Montgomery field of fieldu.cuh with the lazy XYZZ
+// group law of ecu.cuh; bases are converted once, at SRS registration, into that form.
 // The group sum is order-independent, so the non-deterministic order inside a bucket (atomic
 // cursors) does not change the (canonical, affine) result.
 // Algorithmic bytes per MSM: N * (32 + 2*Fq bytes); the kernel is integer-VALU bound.
@@ -22,52 +25,62 @@
 
 namespace {
 
-template <class Fq>
-ZK_D Fq ld_fq(const uint4* q) {
-    Fq r;
+// ---- device storage of an Fu: NL limbs padded to a multiple of 4 words (16-byte vector access)
+template <class F>
+struct Store {
+    static constexpr int U4 = (F::NL + 3) / 4;      // uint4 per field element
+    static constexpr int WORDS = 4 * U4;
+};
+template <class F>
+ZK_D F ld_fu(const uint4* q) {
+    F r;
 #pragma unroll
-    for (int i = 0; i < Fq::N / 4; ++i) {
+    for (int i = 0; i < Store<F>::U4; ++i) {
         uint4 a = q[i];
-        r.v[4 * i + 0] = a.x; r.v[4 * i + 1] = a.y; r.v[4 * i + 2] = a.z; r.v[4 * i + 3] = a.w;
+        if (4 * i + 0 < F::NL) r.v[4 * i + 0] = a.x;
+        if (4 * i + 1 < F::NL) r.v[4 * i + 1] = a.y;
+        if (4 * i + 2 < F::NL) r.v[4 * i + 2] = a.z;
+        if (4 * i + 3 < F::NL) r.v[4 * i + 3] = a.w;
     }
     return r;
 }
-template <class Fq>
-ZK_D void st_fq(uint4* q, const Fq& r) {
+template <class F>
+ZK_D void st_fu(uint4* q, const F& r) {
 #pragma unroll
-    for (int i = 0; i < Fq::N / 4; ++i) q[i] = make_uint4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
+    for (int i = 0; i < Store<F>::U4; ++i) {
+        uint4 a;
+        a.x = 4 * i + 0 < F::NL ? r.v[4 * i + 0] : 0u;
+        a.y = 4 * i + 1 < F::NL ? r.v[4 * i + 1] : 0u;
+        a.z = 4 * i + 2 < F::NL ? r.v[4 * i + 2] : 0u;
+        a.w = 4 * i + 3 < F::NL ? r.v[4 * i + 3] : 0u;
+        q[i] = a;
+    }
 }
-template <class Fq>
-ZK_D Affine<Fq> ld_affine(const void* bases, uint64_t idx) {
-    const uint4* q = reinterpret_cast<const uint4*>(bases) + idx * (2 * Fq::N / 4);
-    Affine<Fq> p;
-    p.x = ld_fq<Fq>(q);
-    p.y = ld_fq<Fq>(q + Fq::N / 4);
+template <class F>
+ZK_D AffineU<F> ld_affine(const void* bases, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(bases) + idx * (2 * Store<F>::U4);
+    AffineU<F> p;
+    p.x = ld_fu<F>(q);
+    p.y = ld_fu<F>(q + Store<F>::U4);
     return p;
 }
-template <class Fq>
-ZK_D void st_affine(void* bases, uint64_t idx, const Affine<Fq>& p) {
-    uint4* q = reinterpret_cast<uint4*>(bases) + idx * (2 * Fq::N / 4);
-    st_fq<Fq>(q, p.x);
-    st_fq<Fq>(q + Fq::N / 4, p.y);
-}
-template <class Fq>
-ZK_D XYZZ<Fq> ld_xyzz(const void* arr, uint64_t idx) {
-    const uint4* q = reinterpret_cast<const uint4*>(arr) + idx * (4 * Fq::N / 4);
-    XYZZ<Fq> p;
-    p.x = ld_fq<Fq>(q);
-    p.y = ld_fq<Fq>(q + Fq::N / 4);
-    p.zz = ld_fq<Fq>(q + 2 * (Fq::N / 4));
-    p.zzz = ld_fq<Fq>(q + 3 * (Fq::N / 4));
+template <class F>
+ZK_D XYZZu<F> ld_xyzz(const void* arr, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(arr) + idx * (4 * Store<F>::U4);
+    XYZZu<F> p;
+    p.x = ld_fu<F>(q);
+    p.y = ld_fu<F>(q + Store<F>::U4);
+    p.zz = ld_fu<F>(q + 2 * Store<F>::U4);
+    p.zzz = ld_fu<F>(q + 3 * Store<F>::U4);
     return p;
 }
-template <class Fq>
-ZK_D void st_xyzz(void* arr, uint64_t idx, const XYZZ<Fq>& p) {
-    uint4* q = reinterpret_cast<uint4*>(arr) + idx * (4 * Fq::N / 4);
-    st_fq<Fq>(q, p.x);
-    st_fq<Fq>(q + Fq::N / 4, p.y);
-    st_fq<Fq>(q + 2 * (Fq::N / 4), p.zz);
-    st_fq<Fq>(q + 3 * (Fq::N / 4), p.zzz);
+template <class F>
+ZK_D void st_xyzz(void* arr, uint64_t idx, const XYZZu<F>& p) {
+    uint4* q = reinterpret_cast<uint4*>(arr) + idx * (4 * Store<F>::U4);
+    st_fu<F>(q, p.x);
+    st_fu<F>(q + Store<F>::U4, p.y);
+    st_fu<F>(q + 2 * Store<F>::U4, p.zz);
+    st_fu<F>(q + 3 * Store<F>::U4, p.zzz);
 }
 
 struct MsmGeom {
@@ -139,13 +152,10 @@ __global__ void msm_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, 
     if (t == T - 1) offsets[n] = part[T - 1];
 }
 
-template <class Fq>
-ZK_D bool affine_is_null(const Affine<Fq>& p) { return p.x.is_zero() && p.y.is_zero(); }
-
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
-template <class Fq>
+template <class F>
 __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
-                               void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes) {
+                                                       void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
     const uint32_t E = offsets[nb];
@@ -162,69 +172,65 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     uint32_t bend = offsets[b + 1];
     const bool head_partial = offsets[b] < (uint32_t)e0;
     bool first_run = true;
-    XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+    XYZZu<F> acc = XYZZu<F>::infinity();
     for (uint32_t e = (uint32_t)e0; e < e1; ++e) {
         if (e == bend) {
-            if (first_run && head_partial) {
-                st_xyzz<Fq>(part_pt, 2ull * t, acc);
-            } else {
-                st_xyzz<Fq>(buckets, b, acc);
-            }
+            if (first_run && head_partial) st_xyzz<F>(part_pt, 2ull * t, acc);
+            else st_xyzz<F>(buckets, b, acc);
             first_run = false;
-            acc = XYZZ<Fq>::infinity();
+            acc = XYZZu<F>::infinity();
             do {
                 ++b;
                 bend = offsets[b + 1];
             } while (bend <= e);
         }
         const uint32_t ref = entries[e];
-        Affine<Fq> p = ld_affine<Fq>(bases, ref & 0x7fffffffu);
-        if (ref >> 31) p.y = Fq::neg(p.y);
-        if (!affine_is_null(p)) acc = XYZZ<Fq>::madd(acc, p);
+        AffineU<F> p = ld_affine<F>(bases, ref & 0x7fffffffu);
+        if (p.is_null()) continue;
+        if (ref >> 31) p.y = F::neg_canonical(p.y);
+        acc = XYZZu<F>::madd(acc, p);
     }
     // Slot convention (msm_combine relies on it): a run that is the FIRST run of its chunk and is
     // not a whole bucket goes to slot 2t, a trailing incomplete run that is not the first goes to 2t+1.
     const bool tail_complete = (e1 == bend);
     if (first_run) {
-        if (head_partial || !tail_complete) st_xyzz<Fq>(part_pt, 2ull * t, acc);
-        else st_xyzz<Fq>(buckets, b, acc);
+        if (head_partial || !tail_complete) st_xyzz<F>(part_pt, 2ull * t, acc);
+        else st_xyzz<F>(buckets, b, acc);
     } else {
-        if (tail_complete) st_xyzz<Fq>(buckets, b, acc);
-        else st_xyzz<Fq>(part_pt, 2ull * t + 1, acc);
+        if (tail_complete) st_xyzz<F>(buckets, b, acc);
+        else st_xyzz<F>(part_pt, 2ull * t + 1, acc);
     }
 }
 
 constexpr uint32_t COMBINE_SMALL = 8;      // buckets spanning <= this many chunks: summed by one lane
 constexpr uint32_t COMBINE_MEDIUM = 2048;  // <= this many: one wavefront per bucket; above: one workgroup
 
-template <class Fq>
 ZK_D uint64_t partial_slot(uint32_t t, uint32_t ta, uint32_t s, uint32_t L) {
     return (t == ta && (s % L) != 0) ? 2ull * t + 1 : 2ull * t;
 }
 
-// butterfly-free wave reduction: lane 0 ends with the sum of all 64 lanes (order irrelevant: abelian group)
-template <class Fq>
-ZK_D XYZZ<Fq> wave_sum(XYZZ<Fq> acc) {
+// wave reduction: lane 0 ends with the sum of all 64 lanes (order irrelevant: abelian group)
+template <class F>
+ZK_D XYZZu<F> wave_sum(XYZZu<F> acc) {
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
-        XYZZ<Fq> o;
+        XYZZu<F> o;
 #pragma unroll
-        for (int i = 0; i < Fq::N; ++i) {
+        for (int i = 0; i < F::NL; ++i) {
             o.x.v[i] = __shfl_down(acc.x.v[i], d, 64);
             o.y.v[i] = __shfl_down(acc.y.v[i], d, 64);
             o.zz.v[i] = __shfl_down(acc.zz.v[i], d, 64);
             o.zzz.v[i] = __shfl_down(acc.zzz.v[i], d, 64);
         }
-        acc = XYZZ<Fq>::add(acc, o);
+        acc = XYZZu<F>::add(acc, o);
     }
     return acc;
 }
 
 // One lane per bucket: a bucket whose entries span p >= 2 chunks has exactly p partials at slots
-// known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued for the
-// wavefront-per-bucket / workgroup-per-bucket kernels below.
+// known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued.
 // queues: q[0] = medium count, q[1] = large count, q[2 ..] medium ids (grow up), q[.. 2+nb) large ids (grow down)
-template <class Fq>
+template <class F>
 __global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L, void* buckets,
                                                     uint32_t* q) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,13 +248,13 @@ __global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const ui
         q[2 + atomicAdd(&q[0], 1u)] = b;
         return;
     }
-    XYZZ<Fq> acc = ld_xyzz<Fq>(part_pt, partial_slot<Fq>(ta, ta, s, L));
-    for (uint32_t t = ta + 1; t <= tb; ++t) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, 2ull * t));
-    st_xyzz<Fq>(buckets, b, acc);
+    XYZZu<F> acc = ld_xyzz<F>(part_pt, partial_slot(ta, ta, s, L));
+    for (uint32_t t = ta + 1; t <= tb; ++t) acc = XYZZu<F>::add(acc, ld_xyzz<F>(part_pt, 2ull * t));
+    st_xyzz<F>(buckets, b, acc);
 }
 
 // medium buckets: one wavefront per bucket, lanes stride over its partials, shuffle tree
-template <class Fq>
+template <class F>
 __global__ void __launch_bounds__(256) msm_combine_wave(const void* part_pt, const uint32_t* offsets, uint32_t L, void* buckets,
                                                          const uint32_t* q) {
     const uint32_t lane = threadIdx.x & 63;
@@ -259,15 +265,15 @@ __global__ void __launch_bounds__(256) msm_combine_wave(const void* part_pt, con
         const uint32_t b = q[2 + h];
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t ta = s / L, tb = (e - 1) / L;
-        XYZZ<Fq> acc = XYZZ<Fq>::infinity();
-        for (uint32_t t = ta + lane; t <= tb; t += 64) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, partial_slot<Fq>(t, ta, s, L)));
-        acc = wave_sum<Fq>(acc);
-        if (lane == 0) st_xyzz<Fq>(buckets, b, acc);
+        XYZZu<F> acc = XYZZu<F>::infinity();
+        for (uint32_t t = ta + lane; t <= tb; t += 64) acc = XYZZu<F>::add(acc, ld_xyzz<F>(part_pt, partial_slot(t, ta, s, L)));
+        acc = wave_sum<F>(acc);
+        if (lane == 0) st_xyzz<F>(buckets, b, acc);
     }
 }
 
 // large buckets (heavily skewed scalars): one 256-lane workgroup per bucket
-template <class Fq>
+template <class F>
 __global__ void __launch_bounds__(256) msm_combine_block(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L,
                                                           void* buckets, const uint32_t* q) {
     extern __shared__ uint4 sh[];
@@ -277,57 +283,53 @@ __global__ void __launch_bounds__(256) msm_combine_block(const void* part_pt, co
         const uint32_t b = q[2 + nb - 1 - h];
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t ta = s / L, tb = (e - 1) / L;
-        XYZZ<Fq> acc = XYZZ<Fq>::infinity();
-        for (uint32_t t = ta + u; t <= tb; t += 256) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(part_pt, partial_slot<Fq>(t, ta, s, L)));
-        acc = wave_sum<Fq>(acc);
+        XYZZu<F> acc = XYZZu<F>::infinity();
+        for (uint32_t t = ta + u; t <= tb; t += 256) acc = XYZZu<F>::add(acc, ld_xyzz<F>(part_pt, partial_slot(t, ta, s, L)));
+        acc = wave_sum<F>(acc);
         __syncthreads();
-        if ((u & 63) == 0) st_xyzz<Fq>(sh, u >> 6, acc);
+        if ((u & 63) == 0) st_xyzz<F>(sh, u >> 6, acc);
         __syncthreads();
         if (u == 0) {
-            for (uint32_t w = 1; w < 4; ++w) acc = XYZZ<Fq>::add(acc, ld_xyzz<Fq>(sh, w));
-            st_xyzz<Fq>(buckets, b, acc);
+            for (uint32_t w = 1; w < 4; ++w) acc = XYZZu<F>::add(acc, ld_xyzz<F>(sh, w));
+            st_xyzz<F>(buckets, b, acc);
         }
     }
 }
 
 // level 1 of the per-window reduction: segment s of window w covers buckets [s*G, (s+1)*G)
 //   run = sum B_i ; acc = sum (i+1) * B_i   (i local index)
-template <class Fq>
+template <class F>
 __global__ void __launch_bounds__(128) msm_seg_reduce(const void* buckets, const uint32_t* offsets, MsmGeom g, void* seg_run, void* seg_acc) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= g.W * g.ns) return;
     const uint32_t w = id / g.ns, s = id % g.ns;
     const uint32_t G = 1u << g.logG;
-    XYZZ<Fq> run = XYZZ<Fq>::infinity(), acc = XYZZ<Fq>::infinity();
+    XYZZu<F> run = XYZZu<F>::infinity(), acc = XYZZu<F>::infinity();
     for (int i = (int)G - 1; i >= 0; --i) {
         const uint32_t bi = w * g.B + s * G + (uint32_t)i;
-        if (offsets[bi + 1] != offsets[bi]) run = XYZZ<Fq>::add(run, ld_xyzz<Fq>(buckets, bi));
-        acc = XYZZ<Fq>::add(acc, run);
+        if (offsets[bi + 1] != offsets[bi]) run = XYZZu<F>::add(run, ld_xyzz<F>(buckets, bi));
+        acc = XYZZu<F>::add(acc, run);
     }
-    st_xyzz<Fq>(seg_run, id, run);
-    st_xyzz<Fq>(seg_acc, id, acc);
-}
-
-template <class Fq>
-ZK_D XYZZ<Fq> lds_ld(const uint4* sh, uint32_t u) {
-    return ld_xyzz<Fq>(sh, u);
+    st_xyzz<F>(seg_run, id, run);
+    st_xyzz<F>(seg_acc, id, acc);
 }
 
 // level 2: one 256-lane workgroup per window.
 //   S_w = sum_s acc_s + G * sum_s s * run_s
-template <class Fq>
-__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, void* win_out) {
+// The window sum leaves the device in the arkworks layout (XYZZ of 4 x SAT words, canonical).
+template <class F>
+__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, uint32_t* win_out) {
     extern __shared__ uint4 sh[];
     const uint32_t w = blockIdx.x, u = threadIdx.x;
     const uint32_t q = 1u << g.logq;
-    typedef XYZZ<Fq> P;
+    typedef XYZZu<F> P;
     P A = P::infinity(), V = P::infinity(), tsum = P::infinity(), R = P::infinity();
     for (int v = (int)q - 1; v >= 0; --v) {
         const uint32_t s = u * q + (uint32_t)v;
         P x = P::infinity();
         if (s < g.ns) {
-            x = ld_xyzz<Fq>(seg_run, (uint64_t)w * g.ns + s);
-            A = P::add(A, ld_xyzz<Fq>(seg_acc, (uint64_t)w * g.ns + s));
+            x = ld_xyzz<F>(seg_run, (uint64_t)w * g.ns + s);
+            A = P::add(A, ld_xyzz<F>(seg_acc, (uint64_t)w * g.ns + s));
         }
         if (v >= 1) {
             tsum = P::add(tsum, x);
@@ -340,14 +342,14 @@ __global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const
     for (uint32_t k = 0; k < g.logG; ++k) V = P::dbl(V);
     P Y = P::add(A, V);
     // suffix sums Q_u = sum_{u' >= u} R_u'  (Hillis-Steele in LDS)
-    st_xyzz<Fq>(sh, u, R);
+    st_xyzz<F>(sh, u, R);
     for (uint32_t d = 1; d < 256; d <<= 1) {
         __syncthreads();
         P o = P::infinity();
-        if (u + d < 256) o = lds_ld<Fq>(sh, u + d);
+        if (u + d < 256) o = ld_xyzz<F>(sh, u + d);
         __syncthreads();
         R = P::add(R, o);
-        st_xyzz<Fq>(sh, u, R);
+        st_xyzz<F>(sh, u, R);
     }
     // Z = Y + (G*q) * Q_u   (u >= 1)
     P Z = Y;
@@ -357,46 +359,78 @@ __global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const
         Z = P::add(Z, Qm);
     }
     __syncthreads();
-    st_xyzz<Fq>(sh, u, Z);
+    st_xyzz<F>(sh, u, Z);
     for (uint32_t d = 128; d >= 1; d >>= 1) {
         __syncthreads();
         if (u < d) {
-            Z = P::add(Z, lds_ld<Fq>(sh, u + d));
-            st_xyzz<Fq>(sh, u, Z);
+            Z = P::add(Z, ld_xyzz<F>(sh, u + d));
+            st_xyzz<F>(sh, u, Z);
         }
     }
-    if (u == 0) st_xyzz<Fq>(win_out, w, Z);
+    if (u == 0) {
+        uint32_t* o = win_out + (size_t)w * 4 * F::SAT;
+        if (Z.is_inf()) {
+            for (int i = 0; i < 4 * F::SAT; ++i) o[i] = 0;
+        } else {
+            Z.x.to_sat(o);
+            Z.y.to_sat(o + F::SAT);
+            Z.zz.to_sat(o + 2 * F::SAT);
+            Z.zzz.to_sat(o + 3 * F::SAT);
+        }
+    }
 }
 
-// out[i] = scalars[i] * G  (double-and-add from the top bit; per-lane Fermat inversion to affine)
-template <class Cv>
-__global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, uint64_t n, void* out_xy) {
-    typedef typename Cv::Fq Fq;
+// arkworks-layout affine (x||y Montgomery words; x = y = 0 or flagged = infinity) -> internal points
+template <class F>
+__global__ void bases_to_internal(const uint32_t* xy_sat, const uint8_t* inf, uint64_t n, void* out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<Fq> G;
+    const uint32_t* w = xy_sat + i * 2 * F::SAT;
+    uint32_t any = 0;
+    for (int k = 0; k < 2 * F::SAT; ++k) any |= w[k];
+    uint4* q = reinterpret_cast<uint4*>(out) + i * (2 * Store<F>::U4);
+    if (any == 0 || (inf && inf[i])) {
+        st_fu<F>(q, F::zero());
+        st_fu<F>(q + Store<F>::U4, F::zero());
+        return;
+    }
+    st_fu<F>(q, F::canonical_lt2p(F::from_sat(w)));
+    st_fu<F>(q + Store<F>::U4, F::canonical_lt2p(F::from_sat(w + F::SAT)));
+}
+
+// out[i] = scalars[i] * G  (double-and-add from the top bit; per-lane Fermat inversion to affine),
+// written in the arkworks layout; infinity -> x = y = 0 words.
+template <class Cv>
+__global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, uint64_t n, uint32_t* out_xy) {
+    typedef typename Cv::FqU F;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t gw[2 * F::SAT];
 #pragma unroll
-    for (int k = 0; k < Fq::N; ++k) { G.x.v[k] = Cv::FqP::GX(k); G.y.v[k] = Cv::FqP::GY(k); }
+    for (int k = 0; k < F::SAT; ++k) {
+        gw[k] = Cv::FqP::GX(k);
+        gw[F::SAT + k] = Cv::FqP::GY(k);
+    }
+    AffineU<F> G;
+    G.x = F::canonical_lt2p(F::from_sat(gw));
+    G.y = F::canonical_lt2p(F::from_sat(gw + F::SAT));
     const uint32_t* s = scalars + 8 * i;
-    XYZZ<Fq> acc = XYZZ<Fq>::infinity();
+    XYZZu<F> acc = XYZZu<F>::infinity();
     for (int limb = 7; limb >= 0; --limb) {
         const uint32_t word = s[limb];
         for (int b = 31; b >= 0; --b) {
-            acc = XYZZ<Fq>::dbl(acc);
-            if ((word >> b) & 1u) acc = XYZZ<Fq>::madd(acc, G);
+            acc = XYZZu<F>::dbl(acc);
+            if ((word >> b) & 1u) acc = XYZZu<F>::madd(acc, G);
         }
     }
-    Affine<Fq> o;
-    acc.to_affine(o);  // infinity -> (0,0), the device encoding of "no point"
-    st_affine<Fq>(out_xy, i, o);
-}
-
-// zero the coordinates of flagged-infinity bases (device encoding of infinity is x = y = 0)
-__global__ void sanitize_bases(void* xy, const uint8_t* inf, uint64_t n, uint32_t u4_per_point) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !inf[i]) return;
-    uint4* q = reinterpret_cast<uint4*>(xy) + i * u4_per_point;
-    for (uint32_t k = 0; k < u4_per_point; ++k) q[k] = make_uint4(0, 0, 0, 0);
+    AffineU<F> o;
+    uint32_t* dst = out_xy + i * 2 * F::SAT;
+    if (!acc.to_affine(o)) {
+        for (int k = 0; k < 2 * F::SAT; ++k) dst[k] = 0;
+        return;
+    }
+    o.x.to_sat(dst);
+    o.y.to_sat(dst + F::SAT);
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -435,11 +469,17 @@ constexpr uint32_t CHUNK_L = 32;
 
 template <class Cv>
 int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uint64_t* out_xyz) {
-    typedef typename Cv::Fq Fq;
-    typedef XYZZ<Fq> P;
+    typedef typename Cv::Fq Fq;       // host / arkworks-layout arithmetic
+    typedef typename Cv::FqU F;       // device arithmetic
+    typedef XYZZ<Fq> PH;
     constexpr int L64 = Fq::N / 2;
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;   // bytes of one stored XYZZu
     if (n == 0) {
-        memset(out_xyz, 0, sizeof(uint64_t) * 3 * L64);
+        // Jacobian zero as arkworks writes it: (1, 1, 0)
+        Fq one = Fq::one(), zero = Fq::zero();
+        memcpy(out_xyz, one.v, sizeof(uint64_t) * L64);
+        memcpy(out_xyz + L64, one.v, sizeof(uint64_t) * L64);
+        memcpy(out_xyz + 2 * L64, zero.v, sizeof(uint64_t) * L64);
         return ZK_OK;
     }
     if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
@@ -451,17 +491,17 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
     if ((rc = c->msm_counts.ensure((size_t)g.nb * 4))) return rc;
     if ((rc = c->msm_offsets.ensure((size_t)(g.nb + 1) * 4 * 2))) return rc;
     if ((rc = c->msm_entries.ensure((size_t)e_max * 4))) return rc;
-    if ((rc = c->msm_buckets.ensure((size_t)g.nb * sizeof(P)))) return rc;
-    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * sizeof(P)))) return rc;
+    if ((rc = c->msm_buckets.ensure((size_t)g.nb * PT))) return rc;
+    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
     if ((rc = c->msm_part_key.ensure((size_t)(g.nb + 2) * 4))) return rc;   // combine queues: [n_medium, n_large, ids...]
-    if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * sizeof(P)))) return rc;
-    if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(P)))) return rc;
+    if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * PT))) return rc;
+    if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(PH)))) return rc;
     uint32_t* counts = (uint32_t*)c->msm_counts.p;
     uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
     uint32_t* cursor = offsets + (g.nb + 1);
     uint32_t* entries = (uint32_t*)c->msm_entries.p;
     void* seg_run = c->msm_seg.p;
-    void* seg_acc = (char*)c->msm_seg.p + (size_t)g.W * g.ns * sizeof(P);
+    void* seg_acc = (char*)c->msm_seg.p + (size_t)g.W * g.ns * PT;
     hipStream_t st = c->stream;
 
     {
@@ -478,7 +518,7 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         ProfScope ps(c, "msm_accumulate");
         const int T = 128;
         unsigned blocks = (n_lanes + T - 1) / T;
-        hipLaunchKernelGGL(msm_accumulate<Fq>, dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
+        hipLaunchKernelGGL(msm_accumulate<F>, dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
                            c->msm_part_pt.p, CHUNK_L, n_lanes);
         ZK_HIP_TRY(hipGetLastError());
     }
@@ -488,36 +528,33 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         uint32_t* q = (uint32_t*)c->msm_part_key.p;
         ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
         unsigned blocks = (g.nb + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<Fq>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<Fq>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<Fq>, dim3(256), dim3(256), 4 * sizeof(P), st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
+        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(256), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
                            c->msm_buckets.p, q);
         unsigned sblocks = (g.W * g.ns + T - 1) / T;
-        hipLaunchKernelGGL(msm_seg_reduce<Fq>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
-        size_t shmem = 256 * sizeof(P);
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
+        size_t shmem = 256 * PT;
         if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<Fq>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, c->msm_win.p);
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)c->msm_win.p);
         ZK_HIP_TRY(hipGetLastError());
     }
     // window sums -> host, Horner (high window first), Jacobian out
-    std::vector<P> win(g.W);
-    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)g.W * sizeof(P), hipMemcpyDeviceToHost, st));
+    std::vector<PH> win(g.W);
+    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)g.W * sizeof(PH), hipMemcpyDeviceToHost, st));
     ZK_HIP_TRY(hipStreamSynchronize(st));
-    P total = P::infinity();
+    PH total = PH::infinity();
     for (int w = (int)g.W - 1; w >= 0; --w) {
-        for (uint32_t k = 0; k < g.c; ++k) total = P::dbl(total);
-        total = P::add(total, win[w]);
+        for (uint32_t k = 0; k < g.c; ++k) total = PH::dbl(total);
+        total = PH::add(total, win[w]);
     }
     // XYZZ -> Jacobian (X*ZZ, Y*ZZZ, ZZ):  x = X/ZZ = X*ZZ/ZZ^2, y = Y/ZZZ = Y*ZZZ/ZZ^3
-    Fq X = Fq::zero(), Y = Fq::zero(), Z = Fq::zero();
+    Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
     if (!total.is_inf()) {
         X = Fq::mul(total.x, total.zz);
         Y = Fq::mul(total.y, total.zzz);
         Z = total.zz;
-    } else {
-        X = Fq::one();
-        Y = Fq::one();
     }
     memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
     memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
@@ -603,10 +640,23 @@ int ZK_SYM(msm_fixed_base_dev)(zk_ctx* c, const void* d_scalars, size_t n, void*
     if (n == 0) return ZK_OK;
     const int T = 128;
     unsigned blocks = (unsigned)((n + T - 1) / T);
-    hipLaunchKernelGGL(g1_fixed_base<CurveSel>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n, d_out_xy);
+    hipLaunchKernelGGL(g1_fixed_base<CurveSel>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_scalars, (uint64_t)n,
+                       (uint32_t*)d_out_xy);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
+
+int ZK_SYM(msm_convert_bases_dev)(zk_ctx* c, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal) {
+    if (n == 0) return ZK_OK;
+    const int T = 256;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    hipLaunchKernelGGL(bases_to_internal<CurveSel::FqU>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_xy_sat, d_inf, (uint64_t)n,
+                       d_out_internal);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }
 
 int ZK_SYM(g1_jacobian_to_affine_host)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
     return jac_to_affine<CurveSel::Fq>(xyz, out_xy, out_inf);
@@ -615,15 +665,3 @@ int ZK_SYM(g1_jacobian_to_affine_host)(const uint64_t* xyz, uint64_t* out_xy, ui
 int ZK_SYM(g1_sum_partials_host)(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
     return sum_partials<CurveSel::Fq>(partials, count, out_xy, out_inf);
 }
-
-#if ZK_CURVE_SEL == 0
-int msm_sanitize_bases_dev(zk_ctx* c, int curve, void* d_xy, const uint8_t* d_inf, size_t n) {
-    if (n == 0 || !d_inf) return ZK_OK;
-    uint32_t u4 = curve == ZK_CURVE_BLS12_381 ? 6 : 4;
-    const int T = 256;
-    unsigned blocks = (unsigned)((n + T - 1) / T);
-    hipLaunchKernelGGL(sanitize_bases, dim3(blocks), dim3(T), 0, c->stream, d_xy, d_inf, (uint64_t)n, u4);
-    ZK_HIP_TRY(hipGetLastError());
-    return ZK_OK;
-}
-#endif

@@ -5,7 +5,9 @@
     int msm_run_dev##sfx(zk_ctx* c, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);       \
     int msm_fixed_base_dev##sfx(zk_ctx* c, const void* d_scalars, size_t n, void* d_out_xy);                           \
     int g1_jacobian_to_affine_host##sfx(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);                      \
-    int g1_sum_partials_host##sfx(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+    int g1_sum_partials_host##sfx(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);         \
+    int msm_convert_bases_dev##sfx(zk_ctx* c, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out);      \
+    size_t msm_point_bytes##sfx();
 DECLS(_c0)
 DECLS(_c1)
 
@@ -28,4 +30,14 @@ int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint
     if (curve == ZK_CURVE_BLS12_381) return g1_sum_partials_host_c0(partials, count, out_xy, out_inf);
     if (curve == ZK_CURVE_BN254) return g1_sum_partials_host_c1(partials, count, out_xy, out_inf);
     return ZK_ERR_BAD_ARG;
+}
+int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal) {
+    if (curve == ZK_CURVE_BLS12_381) return msm_convert_bases_dev_c0(c, d_xy_sat, d_inf, n, d_out_internal);
+    if (curve == ZK_CURVE_BN254) return msm_convert_bases_dev_c1(c, d_xy_sat, d_inf, n, d_out_internal);
+    return ZK_ERR_BAD_ARG;
+}
+size_t msm_point_bytes(int curve) {
+    if (curve == ZK_CURVE_BLS12_381) return msm_point_bytes_c0();
+    if (curve == ZK_CURVE_BN254) return msm_point_bytes_c1();
+    return 0;
 }

@@ -5,9 +5,10 @@
 // (proof_system/prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,582-591,606,609-618).
 //
 // Pipeline (all on the ctx stream; no host round trip until the W window sums are read back):
-//   1. msm_digits<0>  signed c-bit digits of every scalar -> per-(window,bucket) histogram
-//   2. msm_scan       exclusive scan of the histogram -> bucket offsets (+ scatter cursors)
-//   3. msm_digits<1>  counting-sort the (point, sign) references by (window, bucket)
+//   1. msm_digits     signed c-bit digits of every scalar (window-major int16)
+//   2. msm_hist       per-(window, slab) LDS histograms; msm_scan1/2/3 exclusive scan -> bucket
+//                     offsets and per-slab cursors (no global atomics anywhere in the sort)
+//   3. msm_scatter    counting-sort the (point, sign) references by (window, bucket) via LDS cursors
 //   4. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
 //                     additions (8M+2S, no inversion); runs that cross a chunk edge are emitted
 //                     as partials (load-balanced regardless of the scalar distribution)
@@ -102,9 +103,13 @@ ZK_D uint32_t scalar_bits(const uint32_t* s, uint32_t pos, uint32_t c) {
     return (uint32_t)v & ((1u << c) - 1u);
 }
 
-// Passes over the signed digits of scalar i.  MODE 0: histogram, MODE 1: scatter.
-template <int MODE>
-__global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, uint32_t* counts_or_cursor, uint32_t* entries) {
+// ---- counting sort of the (point, sign) references by (window, bucket), without global atomics ----
+// K0  msm_digits : signed c-bit digits of every scalar, stored window-major as int16 (c <= 16)
+// K1  msm_hist   : one workgroup per (window, slab of scalars): LDS histogram -> hist[w][slab][bucket]
+// K2  msm_scan1/2/3 : exclusive scan in (window, bucket, slab) order -> bucket offsets + per-slab cursors
+// K3  msm_scatter: same grid as K1, LDS cursors, writes the references to their sorted position
+// digit convention: raw = bits + carry; raw >= 2^(c-1) -> digit raw - 2^c (negative), carry 1.
+__global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, int16_t* dig) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* s = scalars + 8 * i;
@@ -112,44 +117,113 @@ __global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, uint3
     const uint32_t half = 1u << (g.c - 1);
     for (uint32_t w = 0; w < g.W; ++w) {
         uint32_t raw = scalar_bits(s, w * g.c, g.c) + carry;
-        uint32_t neg = raw > half ? 1u : 0u;
-        uint32_t mag = neg ? (1u << g.c) - raw : raw;
-        carry = neg;
-        if (mag == 0) continue;
-        uint32_t bucket = w * g.B + (mag - 1);
-        if (MODE == 0) {
-            atomicAdd(&counts_or_cursor[bucket], 1u);
-        } else {
-            uint32_t pos = atomicAdd(&counts_or_cursor[bucket], 1u);
-            entries[pos] = (uint32_t)i | (neg << 31);
-        }
+        carry = raw >= half ? 1u : 0u;
+        int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
+        dig[(uint64_t)w * n + i] = (int16_t)d;
     }
 }
 
-// single-workgroup exclusive scan: offsets[0..n] and cursor[0..n)
-__global__ void msm_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, uint32_t* cursor) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x, T = blockDim.x;
-    const uint32_t chunk = (n + T - 1) / T;
-    const uint32_t b = t * chunk, e = min(n, b + chunk);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += counts[i];
-    part[t] = s;
+ZK_D void slab_range(uint64_t n, uint32_t S, uint32_t slab, uint64_t& lo, uint64_t& hi) {
+    const uint64_t per = (n + S - 1) / S;
+    lo = (uint64_t)slab * per;
+    hi = lo + per < n ? lo + per : n;
+    if (lo > n) lo = n;
+}
+
+__global__ void msm_hist(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t S, uint32_t* hist) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t w = blockIdx.y, slab = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < g.B; j += blockDim.x) lh[j] = 0;
     __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
+    uint64_t lo, hi;
+    slab_range(n, S, slab, lo, hi);
+    const int16_t* dw = dig + (uint64_t)w * n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int32_t d = dw[i];
+        if (d != 0) atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = hist + ((uint64_t)w * S + slab) * g.B;
+    for (uint32_t j = threadIdx.x; j < g.B; j += blockDim.x) out[j] = lh[j];
+}
+
+ZK_D uint32_t bucket_total(const uint32_t* hist, MsmGeom g, uint32_t S, uint32_t k) {
+    const uint32_t w = k / g.B, j = k % g.B;
+    uint32_t t = 0;
+    for (uint32_t s = 0; s < S; ++s) t += hist[((uint64_t)w * S + s) * g.B + j];
+    return t;
+}
+
+// block sums of the per-bucket totals (1024 buckets per block)
+__global__ void msm_scan1(const uint32_t* hist, MsmGeom g, uint32_t S, uint32_t* bsum) {
+    __shared__ uint32_t red[1024];
+    const uint32_t k = blockIdx.x * 1024 + threadIdx.x;
+    red[threadIdx.x] = k < g.nb ? bucket_total(hist, g, S, k) : 0u;
+    __syncthreads();
+    for (uint32_t d = 512; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
         __syncthreads();
     }
-    uint32_t run = part[t] - s;  // exclusive prefix of this chunk
-    for (uint32_t i = b; i < e; ++i) {
-        uint32_t cnt = counts[i];
-        offsets[i] = run;
-        cursor[i] = run;
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+// exclusive scan of the block sums (<= 1024 of them), in place
+__global__ void msm_scan2(uint32_t* bsum, uint32_t nblk) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t v = t < nblk ? bsum[t] : 0u;
+    part[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t o = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    if (t < nblk) bsum[t] = part[t] - v;
+}
+// bucket offsets (offsets[k], offsets[nb] = total) and per-(window, slab, bucket) cursors (in place in hist)
+__global__ void msm_scan3(uint32_t* hist, MsmGeom g, uint32_t S, const uint32_t* bsum, uint32_t* offsets) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t k = blockIdx.x * 1024 + t;
+    const uint32_t tot = k < g.nb ? bucket_total(hist, g, S, k) : 0u;
+    part[t] = tot;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t o = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    if (k >= g.nb) return;
+    uint32_t run = bsum[blockIdx.x] + part[t] - tot;
+    offsets[k] = run;
+    if (k == g.nb - 1) offsets[g.nb] = run + tot;
+    const uint32_t w = k / g.B, j = k % g.B;
+    for (uint32_t s = 0; s < S; ++s) {
+        uint32_t* p = hist + ((uint64_t)w * S + s) * g.B + j;
+        const uint32_t cnt = *p;
+        *p = run;
         run += cnt;
     }
-    if (t == T - 1) offsets[n] = part[T - 1];
+}
+
+__global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t S, const uint32_t* cursors, uint32_t* entries) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t w = blockIdx.y, slab = blockIdx.x;
+    const uint32_t* cur = cursors + ((uint64_t)w * S + slab) * g.B;
+    for (uint32_t j = threadIdx.x; j < g.B; j += blockDim.x) lh[j] = cur[j];
+    __syncthreads();
+    uint64_t lo, hi;
+    slab_range(n, S, slab, lo, hi);
+    const int16_t* dw = dig + (uint64_t)w * n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int32_t d = dw[i];
+        if (d == 0) continue;
+        const uint32_t neg = d < 0 ? 1u : 0u;
+        const uint32_t pos = atomicAdd(&lh[(neg ? -d : d) - 1], 1u);
+        entries[pos] = (uint32_t)i | (neg << 31);
+    }
 }
 
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
@@ -440,7 +514,22 @@ uint32_t ilog2_floor(uint64_t x) {
     return r;
 }
 
-MsmGeom make_geom(uint64_t n, int bits, int c_override) {
+// top_of(shift) must return (r - 1) >> shift (low 32 bits): the largest value the last window can hold
+template <class FrP>
+uint32_t modulus_minus_one_bits(uint32_t shift) {
+    uint32_t w[FrP::N + 1];
+    for (int i = 0; i < FrP::N; ++i) w[i] = FrP::MOD(i);
+    w[FrP::N] = 0;
+    w[0] -= 1;  // r is odd
+    uint32_t limb = shift >> 5, off = shift & 31;
+    if (limb >= (uint32_t)FrP::N) return 0;
+    uint64_t v = ((uint64_t)w[limb + 1] << 32 | w[limb]) >> off;
+    return (uint32_t)v;
+}
+
+template <class FrP>
+MsmGeom make_geom(uint64_t n, int c_override) {
+    const int bits = FrP::BITS;
     MsmGeom g;
     uint32_t c;
     if (c_override > 0) {
@@ -452,9 +541,12 @@ MsmGeom make_geom(uint64_t n, int bits, int c_override) {
         if (c > 16) c = 16;
     }
     if (c < 2) c = 2;
-    if (c > 20) c = 20;
+    if (c > 16) c = 16;   // digits are stored as int16 and a window's histogram lives in LDS
     g.c = c;
     g.W = (uint32_t)bits / c + 1;
+    // the last window must never produce a carry: its largest raw value (top bits of r-1, plus the
+    // incoming carry) has to stay below 2^(c-1); otherwise spend one more window
+    if (modulus_minus_one_bits<FrP>((g.W - 1) * c) + 1 >= (1u << (c - 1))) g.W += 1;
     g.B = 1u << (c - 1);
     g.nb = g.W * g.B;
     g.logG = c - 1 < 4 ? c - 1 : 4;
@@ -483,22 +575,29 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         return ZK_OK;
     }
     if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
-    MsmGeom g = make_geom(n, Cv::FrP::BITS, c->msm_window);
+    MsmGeom g = make_geom<typename Cv::FrP>(n, c->msm_window);
     const uint64_t e_max = (uint64_t)n * g.W;
     if (e_max >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;
     const uint32_t n_lanes = (uint32_t)((e_max + CHUNK_L - 1) / CHUNK_L);
     int rc;
-    if ((rc = c->msm_counts.ensure((size_t)g.nb * 4))) return rc;
-    if ((rc = c->msm_offsets.ensure((size_t)(g.nb + 1) * 4 * 2))) return rc;
+    // slabs of scalars per window: enough workgroups to fill the chip, each with >= ~8K scalars
+    uint32_t S = 1;
+    while (S < 32 && (uint64_t)S * 16384 < n && (uint64_t)(2 * S) * g.W <= 1024) S <<= 1;
+    const unsigned nblk_scan = (g.nb + 1023) / 1024;
+    if (nblk_scan > 1024) return ZK_ERR_UNSUPPORTED;
+    if ((rc = c->msm_counts.ensure((size_t)g.W * S * g.B * 4 + 4096))) return rc;       // hist / cursors + block sums
+    if ((rc = c->msm_offsets.ensure((size_t)(g.nb + 1) * 4))) return rc;
+    if ((rc = c->msm_tmp.ensure((size_t)g.W * n * 2))) return rc;                       // int16 digits, window-major
     if ((rc = c->msm_entries.ensure((size_t)e_max * 4))) return rc;
     if ((rc = c->msm_buckets.ensure((size_t)g.nb * PT))) return rc;
     if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
     if ((rc = c->msm_part_key.ensure((size_t)(g.nb + 2) * 4))) return rc;   // combine queues: [n_medium, n_large, ids...]
     if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * PT))) return rc;
     if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(PH)))) return rc;
-    uint32_t* counts = (uint32_t*)c->msm_counts.p;
+    uint32_t* hist = (uint32_t*)c->msm_counts.p;
+    uint32_t* bsum = hist + (size_t)g.W * S * g.B;
     uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
-    uint32_t* cursor = offsets + (g.nb + 1);
+    int16_t* dig = (int16_t*)c->msm_tmp.p;
     uint32_t* entries = (uint32_t*)c->msm_entries.p;
     void* seg_run = c->msm_seg.p;
     void* seg_acc = (char*)c->msm_seg.p + (size_t)g.W * g.ns * PT;
@@ -506,12 +605,20 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
 
     {
         ProfScope ps(c, "msm_sort");
-        ZK_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)g.nb * 4, st));
         const int T = 256;
         unsigned blocks = (unsigned)((n + T - 1) / T);
-        hipLaunchKernelGGL(msm_digits<0>, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, counts, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, st, counts, g.nb, offsets, cursor);
-        hipLaunchKernelGGL(msm_digits<1>, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, cursor, entries);
+        hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, dig);
+        size_t lds = (size_t)g.B * 4;
+        if (lds > 48 * 1024) {
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL(msm_hist, dim3(S, g.W), dim3(1024), lds, st, dig, (uint64_t)n, g, S, hist);
+        const unsigned nblk = (g.nb + 1023) / 1024;
+        hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, g, S, bsum);
+        hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
+        hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, g, S, bsum, offsets);
+        hipLaunchKernelGGL(msm_scatter, dim3(S, g.W), dim3(1024), lds, st, dig, (uint64_t)n, g, S, hist, entries);
         ZK_HIP_TRY(hipGetLastError());
     }
     {

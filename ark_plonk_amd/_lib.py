@@ -64,6 +64,7 @@ SYMBOLS = {
     "zk_msm_g1": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_srs_register": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "zk_srs_register_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_srs_precompute": (c_int, [c_void_p, c_void_p]),
     "zk_srs_free": (None, [c_void_p]),
     "zk_srs_len": (c_size_t, [c_void_p]),
     "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),

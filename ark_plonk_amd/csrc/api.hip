@@ -346,12 +346,20 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
     return srs_build(c, curve_id, c->io_b.p, d_inf, n, out);
 }
 
+int zk_srs_precompute(zk_ctx* c, zk_srs* s) {
+    if (!c || !s || s->ctx != c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (s->pre_W || s->n == 0) return ZK_OK;
+    return msm_precompute_dev(c, s);
+}
+
 void zk_srs_free(zk_srs* s) {
     if (!s) return;
-    if (s->d_xy) {
+    if (s->d_xy || s->d_pre) {
         Guard g(s->ctx);
         (void)hipStreamSynchronize(s->ctx->stream);
-        (void)hipFree(s->d_xy);
+        if (s->d_xy) (void)hipFree(s->d_xy);
+        if (s->d_pre) (void)hipFree(s->d_pre);
     }
     delete s;
 }
@@ -371,6 +379,7 @@ int zk_msm_g1_srs_partial_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const vo
     int rc = srs_slice(s, base_offset, n, &d_bases);
     if (rc) return rc;
     Guard g(c);
+    if (s->pre_W && n >= ZK_PRE_MIN_N && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
     return msm_run_dev(c, s->curve, d_bases, d_scalars, n, out_xyz);
 }
 

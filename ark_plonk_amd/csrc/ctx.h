@@ -129,6 +129,10 @@ struct zk_srs {
     void* d_xy = nullptr;   // n points in the device-internal form (2 x Fu, 29-bit limbs, padded to 16 B);
                             // "no point" (infinity) is all-zero limbs
     size_t point_bytes = 0;
+    // optional table of window multiples 2^(c*w) * P_i, w = 1 .. pre_W-1, window-major (n points each);
+    // with it all windows of an MSM share ONE bucket set (no per-window reduction, no host doublings)
+    void* d_pre = nullptr;
+    uint32_t pre_c = 0, pre_W = 0;
 };
 
 // profiling helpers (ctx mutex held by caller)
@@ -152,6 +156,10 @@ int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, voi
 // out_xyz: Jacobian (X,Y,Z) 3L u64 limbs on host.
 int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);
 int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy);
+// window-multiples table of an SRS (see zk_srs::d_pre) and the MSM that uses it
+int msm_precompute_dev(zk_ctx* c, zk_srs* s);
+int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
+constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
 int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal);
 size_t msm_point_bytes(int curve);

@@ -208,7 +208,10 @@ __global__ void msm_scan3(uint32_t* hist, MsmGeom g, uint32_t S, const uint32_t*
     }
 }
 
-__global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t S, const uint32_t* cursors, uint32_t* entries) {
+// n_real != 0: dig is the flattened [W][n_real] array sorted as ONE window (shared bucket set); the
+// reference written is sign<<31 | window<<26 | index.
+__global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t S, const uint32_t* cursors, uint32_t* entries,
+                            uint32_t n_real) {
     extern __shared__ uint32_t lh[];
     const uint32_t w = blockIdx.y, slab = blockIdx.x;
     const uint32_t* cur = cursors + ((uint64_t)w * S + slab) * g.B;
@@ -222,14 +225,22 @@ __global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t 
         if (d == 0) continue;
         const uint32_t neg = d < 0 ? 1u : 0u;
         const uint32_t pos = atomicAdd(&lh[(neg ? -d : d) - 1], 1u);
-        entries[pos] = (uint32_t)i | (neg << 31);
+        uint32_t ref = (uint32_t)i;
+        if (n_real) {
+            const uint32_t wq = (uint32_t)i / n_real;
+            ref = (wq << 26) | ((uint32_t)i - wq * n_real);
+        }
+        entries[pos] = ref | (neg << 31);
     }
 }
 
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
-template <class F>
+// PRE: references carry a window number and `bases` is the window-multiples table [W][n_srs]
+// (row w holds 2^(c w) P_i); tab_stride = n_srs, tab_off = base_offset.
+template <class F, bool PRE>
 __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
-                                                       void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes) {
+                                                       void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes, uint64_t tab_stride,
+                                                       uint64_t tab_off) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
     const uint32_t E = offsets[nb];
@@ -259,7 +270,8 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
             } while (bend <= e);
         }
         const uint32_t ref = entries[e];
-        AffineU<F> p = ld_affine<F>(bases, ref & 0x7fffffffu);
+        const uint64_t pidx = PRE ? (uint64_t)((ref >> 26) & 31u) * tab_stride + tab_off + (ref & 0x3ffffffu) : (uint64_t)(ref & 0x7fffffffu);
+        AffineU<F> p = ld_affine<F>(bases, pidx);
         if (p.is_null()) continue;
         if (ref >> 31) p.y = F::neg_canonical(p.y);
         acc = XYZZu<F>::madd(acc, p);
@@ -392,7 +404,10 @@ __global__ void __launch_bounds__(128) msm_seg_reduce(const void* buckets, const
 //   S_w = sum_s acc_s + G * sum_s s * run_s
 // The window sum leaves the device in the arkworks layout (XYZZ of 4 x SAT words, canonical).
 template <class F>
-__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, uint32_t* win_out) {
+// tot_out (optional): sum of all buckets of the window, same layout (used when one real window is
+// reduced as several "virtual" windows to shorten the dependent-addition chain).
+__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, uint32_t* win_out,
+                                                       uint32_t* tot_out) {
     extern __shared__ uint4 sh[];
     const uint32_t w = blockIdx.x, u = threadIdx.x;
     const uint32_t q = 1u << g.logq;
@@ -424,6 +439,17 @@ __global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const
         __syncthreads();
         R = P::add(R, o);
         st_xyzz<F>(sh, u, R);
+    }
+    if (tot_out && u == 0) {
+        uint32_t* o = tot_out + (size_t)w * 4 * F::SAT;
+        if (R.is_inf()) {
+            for (int i = 0; i < 4 * F::SAT; ++i) o[i] = 0;
+        } else {
+            R.x.to_sat(o);
+            R.y.to_sat(o + F::SAT);
+            R.zz.to_sat(o + 2 * F::SAT);
+            R.zzz.to_sat(o + 3 * F::SAT);
+        }
     }
     // Z = Y + (G*q) * Q_u   (u >= 1)
     P Z = Y;
@@ -618,15 +644,15 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, g, S, bsum);
         hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
         hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, g, S, bsum, offsets);
-        hipLaunchKernelGGL(msm_scatter, dim3(S, g.W), dim3(1024), lds, st, dig, (uint64_t)n, g, S, hist, entries);
+        hipLaunchKernelGGL(msm_scatter, dim3(S, g.W), dim3(1024), lds, st, dig, (uint64_t)n, g, S, hist, entries, 0u);
         ZK_HIP_TRY(hipGetLastError());
     }
     {
         ProfScope ps(c, "msm_accumulate");
         const int T = 128;
         unsigned blocks = (n_lanes + T - 1) / T;
-        hipLaunchKernelGGL(msm_accumulate<F>, dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
-                           c->msm_part_pt.p, CHUNK_L, n_lanes);
+        hipLaunchKernelGGL((msm_accumulate<F, false>), dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
+                           c->msm_part_pt.p, CHUNK_L, n_lanes, (uint64_t)0, (uint64_t)0);
         ZK_HIP_TRY(hipGetLastError());
     }
     {
@@ -644,7 +670,8 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         size_t shmem = 256 * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)c->msm_win.p);
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)c->msm_win.p,
+                           (uint32_t*)nullptr);
         ZK_HIP_TRY(hipGetLastError());
     }
     // window sums -> host, Horner (high window first), Jacobian out
@@ -657,6 +684,186 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         total = PH::add(total, win[w]);
     }
     // XYZZ -> Jacobian (X*ZZ, Y*ZZZ, ZZ):  x = X/ZZ = X*ZZ/ZZ^2, y = Y/ZZZ = Y*ZZZ/ZZ^3
+    Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
+    if (!total.is_inf()) {
+        X = Fq::mul(total.x, total.zz);
+        Y = Fq::mul(total.y, total.zzz);
+        Z = total.zz;
+    }
+    memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
+    return ZK_OK;
+}
+
+// table[w][i] = 2^(c w) * P_i for w = 1 .. W-1 (row 0 = the points themselves), affine internal form
+template <class F>
+__global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, uint32_t c, uint32_t W) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AffineU<F> p = ld_affine<F>(table, i);
+    uint4* base = reinterpret_cast<uint4*>(table);
+    if (p.is_null()) {
+        for (uint32_t w = 1; w < W; ++w) {
+            uint4* q = base + ((uint64_t)w * n + i) * (2 * Store<F>::U4);
+            st_fu<F>(q, F::zero());
+            st_fu<F>(q + Store<F>::U4, F::zero());
+        }
+        return;
+    }
+    XYZZu<F> acc = XYZZu<F>::from_affine(p);
+    for (uint32_t w = 1; w < W; ++w) {
+        for (uint32_t k = 0; k < c; ++k) acc = XYZZu<F>::dbl(acc);
+        AffineU<F> a;
+        acc.to_affine(a);   // a point of odd prime order never doubles to infinity
+        a.x = F::canonical_lt2p(a.x);
+        a.y = F::canonical_lt2p(a.y);
+        uint4* q = base + ((uint64_t)w * n + i) * (2 * Store<F>::U4);
+        st_fu<F>(q, a.x);
+        st_fu<F>(q + Store<F>::U4, a.y);
+        acc = XYZZu<F>::from_affine(a);
+    }
+}
+
+constexpr uint32_t PRE_C = 16;        // window of the precomputed table (largest the LDS sort handles)
+constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
+constexpr uint32_t PRE_VW = 32;       // virtual windows for the final bucket reduction
+
+template <class Cv>
+int msm_precompute_run(zk_ctx* c, zk_srs* s) {
+    typedef typename Cv::FqU F;
+    MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)PRE_C);
+    const size_t pb = s->point_bytes;
+    void* tab = nullptr;
+    if (hipMalloc(&tab, (size_t)g.W * s->n * pb) != hipSuccess) return ZK_ERR_OOM;
+    hipError_t e = hipMemcpyAsync(tab, s->d_xy, s->n * pb, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int T = 128;
+        unsigned blocks = (unsigned)((s->n + T - 1) / T);
+        hipLaunchKernelGGL(msm_precompute<F>, dim3(blocks), dim3(T), 0, c->stream, tab, (uint64_t)s->n, g.c, g.W);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        zk_note_hip_error(e, "msm_precompute", __FILE__, __LINE__);
+        return ZK_ERR_HIP;
+    }
+    (void)hipFree(s->d_xy);
+    s->d_xy = tab;      // row 0 of the table is the SRS itself
+    s->pre_c = g.c;
+    s->pre_W = g.W;
+    return ZK_OK;
+}
+
+// MSM over a precomputed SRS: every (scalar, window) digit is a reference to table[w][i] and all
+// windows share one set of 2^(c-1) buckets.
+template <class Cv>
+int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    typedef typename Cv::Fq Fq;
+    typedef typename Cv::FqU F;
+    typedef XYZZ<Fq> PH;
+    constexpr int L64 = Fq::N / 2;
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
+    MsmGeom g = make_geom<typename Cv::FrP>(n, (int)s->pre_c);
+    if (g.W != s->pre_W || g.W > 32) return ZK_ERR_UNSUPPORTED;
+    const uint64_t nf = (uint64_t)n * g.W;              // flattened (window, scalar) digits
+    if (nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+    MsmGeom g1 = g;                                      // the sort sees ONE window of nf digits
+    g1.W = 1;
+    g1.nb = g.B;
+    MsmGeom gv = g;                                      // the reduction sees PRE_VW virtual windows
+    gv.W = PRE_VW;
+    gv.B = g.B / PRE_VW;
+    gv.nb = g.B;
+    gv.logG = 2;
+    gv.ns = gv.B >> gv.logG;
+    gv.logq = 0;
+    while ((256u << gv.logq) < gv.ns) ++gv.logq;
+    // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 waves
+    // of lanes per SIMD on the 256-CU chip (the kernel holds 2 waves/SIMD at its VGPR count)
+    uint32_t chunk_l = PRE_CHUNK_L;
+    while (chunk_l > 16 && nf / chunk_l < 131072) chunk_l >>= 1;
+    const uint32_t n_lanes = (uint32_t)((nf + chunk_l - 1) / chunk_l);
+    uint32_t S = 1;
+    while (S < 128 && (uint64_t)S * 32768 < nf) S <<= 1;
+    int rc;
+    if ((rc = c->msm_counts.ensure((size_t)S * g.B * 4 + 4096))) return rc;
+    if ((rc = c->msm_offsets.ensure((size_t)(g.B + 1) * 4))) return rc;
+    if ((rc = c->msm_tmp.ensure((size_t)nf * 2))) return rc;
+    if ((rc = c->msm_entries.ensure((size_t)nf * 4))) return rc;
+    if ((rc = c->msm_buckets.ensure((size_t)g.B * PT))) return rc;
+    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
+    if ((rc = c->msm_part_key.ensure((size_t)(g.B + 2) * 4))) return rc;
+    if ((rc = c->msm_seg.ensure((size_t)gv.W * gv.ns * 2 * PT))) return rc;
+    if ((rc = c->msm_win.ensure((size_t)2 * gv.W * sizeof(PH)))) return rc;
+    uint32_t* hist = (uint32_t*)c->msm_counts.p;
+    uint32_t* bsum = hist + (size_t)S * g.B;
+    uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
+    int16_t* dig = (int16_t*)c->msm_tmp.p;
+    uint32_t* entries = (uint32_t*)c->msm_entries.p;
+    void* seg_run = c->msm_seg.p;
+    void* seg_acc = (char*)c->msm_seg.p + (size_t)gv.W * gv.ns * PT;
+    uint32_t* win_s = (uint32_t*)c->msm_win.p;
+    uint32_t* win_t = win_s + (size_t)gv.W * 4 * F::SAT;
+    hipStream_t st = c->stream;
+    {
+        ProfScope ps(c, "msm_sort");
+        const int T = 256;
+        unsigned blocks = (unsigned)((n + T - 1) / T);
+        hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, dig);
+        size_t lds = (size_t)g.B * 4;
+        if (lds > 48 * 1024) {
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL(msm_hist, dim3(S, 1), dim3(1024), lds, st, dig, nf, g1, S, hist);
+        const unsigned nblk = (g1.nb + 1023) / 1024;
+        hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, g1, S, bsum);
+        hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
+        hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, g1, S, bsum, offsets);
+        hipLaunchKernelGGL(msm_scatter, dim3(S, 1), dim3(1024), lds, st, dig, nf, g1, S, hist, entries, (uint32_t)n);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "msm_accumulate");
+        const int T = 128;
+        unsigned blocks = (n_lanes + T - 1) / T;
+        hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, entries, offsets, g1.nb, s->d_xy, c->msm_buckets.p,
+                           c->msm_part_pt.p, chunk_l, n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "msm_reduce");
+        const int T = 128;
+        uint32_t* q = (uint32_t*)c->msm_part_key.p;
+        ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
+        unsigned blocks = (g1.nb + T - 1) / T;
+        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, chunk_l, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(256), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l,
+                           c->msm_buckets.p, q);
+        unsigned sblocks = (gv.W * gv.ns + T - 1) / T;
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, gv, seg_run, seg_acc);
+        size_t shmem = 256 * PT;
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(gv.W), dim3(256), shmem, st, seg_run, seg_acc, gv, win_s, win_t);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    std::vector<PH> win(2 * gv.W);
+    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)2 * gv.W * sizeof(PH), hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipStreamSynchronize(st));
+    // S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index)
+    PH total = PH::infinity(), run = PH::infinity(), wsum = PH::infinity();
+    for (int v = (int)gv.W - 1; v >= 1; --v) {
+        run = PH::add(run, win[gv.W + v]);
+        wsum = PH::add(wsum, run);
+    }
+    for (uint32_t k = 0; (1u << k) < gv.B; ++k) wsum = PH::dbl(wsum);
+    for (uint32_t v = 0; v < gv.W; ++v) total = PH::add(total, win[v]);
+    total = PH::add(total, wsum);
     Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
     if (!total.is_inf()) {
         X = Fq::mul(total.x, total.zz);
@@ -761,6 +968,12 @@ int ZK_SYM(msm_convert_bases_dev)(zk_ctx* c, const void* d_xy_sat, const uint8_t
                        d_out_internal);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
+}
+
+int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s) { return msm_precompute_run<CurveSel>(c, s); }
+
+int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

@@ -7,7 +7,9 @@
     int g1_jacobian_to_affine_host##sfx(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);                      \
     int g1_sum_partials_host##sfx(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);         \
     int msm_convert_bases_dev##sfx(zk_ctx* c, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out);      \
-    size_t msm_point_bytes##sfx();
+    size_t msm_point_bytes##sfx();                                                                                     \
+    int msm_precompute_dev##sfx(zk_ctx* c, zk_srs* s);                                                                 \
+    int msm_run_pre_dev##sfx(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 DECLS(_c0)
 DECLS(_c1)
 
@@ -40,4 +42,14 @@ size_t msm_point_bytes(int curve) {
     if (curve == ZK_CURVE_BLS12_381) return msm_point_bytes_c0();
     if (curve == ZK_CURVE_BN254) return msm_point_bytes_c1();
     return 0;
+}
+int msm_precompute_dev(zk_ctx* c, zk_srs* s) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_precompute_dev_c0(c, s);
+    if (s->curve == ZK_CURVE_BN254) return msm_precompute_dev_c1(c, s);
+    return ZK_ERR_BAD_ARG;
+}
+int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_run_pre_dev_c0(c, s, base_offset, d_scalars, n, out_xyz);
+    if (s->curve == ZK_CURVE_BN254) return msm_run_pre_dev_c1(c, s, base_offset, d_scalars, n, out_xyz);
+    return ZK_ERR_BAD_ARG;
 }

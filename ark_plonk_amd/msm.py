@@ -19,6 +19,14 @@ from .context import Context, _is_torch, as_host_u64, check_dev_tensor, default_
 from .curves import get_curve
 
 
+def _has_torch_cuda() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except ImportError:
+        return False
+
+
 class G1Affine:
     """(x, y, infinity) with x, y Montgomery limbs -- the fields of ark's GroupAffine."""
 
@@ -73,6 +81,12 @@ class CommitterKey:
 
     def __len__(self):
         return self.n
+
+    def precompute(self):
+        """Build the window-multiples table (16x the SRS in HBM); later MSMs share one bucket set."""
+        self.ctx.use_torch_stream() if _has_torch_cuda() else None
+        check(lib().zk_srs_precompute(self.ctx.handle, self._h), "zk_srs_precompute")
+        return self
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

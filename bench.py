@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +127,8 @@ def main():
     srs = build_srs(ctx, cv, n, lo, hi, torch)
     ck = zk.CommitterKey(srs, cv, ctx)
     del srs
+    if not args.no_precompute:
+        ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
     sched = ProofSchedule(log_n, ctx, ck, cv, rank=rank, world=world, dist=dist if world > 1 else None)
 
     def barrier():

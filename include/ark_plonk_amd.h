@@ -116,6 +116,10 @@ int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t
 /* Device-resident SRS (CommitterKey::powers_of_g after PC::trim, circuit.rs:236,276). */
 int zk_srs_register(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out);
 int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out);
+/* Optional: build the table of window multiples 2^(16 w) * P_i (w = 1..15) for this SRS, 16x its
+ * size in HBM (2 GiB per 2^20 BLS12-381 points; the card has 288 GB).  MSMs over the SRS then use a
+ * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged. */
+int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 void zk_srs_free(zk_srs* srs);
 size_t zk_srs_len(const zk_srs* srs);
 

@@ -100,7 +100,7 @@ def test_vs_cpu_oracle_medium(cid, log_n, ctx, oracle_cpu):
     assert_point(got, exp_xy, exp_inf, cid)
 
 
-def _kzg_identity(cid, log_n, ctx, skew=False):
+def _kzg_identity(cid, log_n, ctx, skew=False, precompute=False, offset=0):
     """MSM(s, tau^i G) == (sum_i s_i tau^i mod r) G : O(N) big-int work, valid at any size."""
     import torch
     cv = bo.CURVES[cid]
@@ -128,7 +128,18 @@ def _kzg_identity(cid, log_n, ctx, skew=False):
     acc %= cv.r
     exp = bo.ec_mul(cv, acc, (cv.gx, cv.gy))
     ck = zk.CommitterKey(bases, cid, ctx)
-    got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
+    if precompute:
+        ck.precompute()
+    if offset:
+        # MSM over powers[offset:], as kzg10::commit does after stripping leading zero coefficients
+        acc = 0
+        for s, p in zip(s_int[: n - offset], pw[offset:]):
+            acc += s * p
+        acc %= cv.r
+        exp = bo.ec_mul(cv, acc, (cv.gx, cv.gy))
+        got = ck.msm(torch.from_numpy(scal[: n - offset].view(np.int64)).cuda(), base_offset=offset)
+    else:
+        got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
     ck.close()
     assert not got.infinity
     assert zk.curves.fq_from_mont(cid, got.x.reshape(1, -1))[0] == exp[0]
@@ -145,6 +156,46 @@ def test_kzg_identity_2_20(ctx):
 
 def test_kzg_identity_2_20_skewed_scalars(ctx):
     _kzg_identity(0, 20, ctx, skew=True)
+
+
+def test_precomputed_table_2_20(ctx):
+    _kzg_identity(0, 20, ctx, precompute=True)
+
+
+def test_precomputed_table_2_20_skewed(ctx):
+    _kzg_identity(0, 20, ctx, skew=True, precompute=True)
+
+
+def test_precomputed_table_offset_and_bn254(ctx):
+    _kzg_identity(0, 16, ctx, precompute=True, offset=777)
+    _kzg_identity(1, 16, ctx, precompute=True)
+
+
+def test_precomputed_table_matches_plain_path(ctx, oracle_cpu):
+    """Same SRS, same scalars: shared-bucket path == per-window path == CPU oracle (2^14 points)."""
+    import torch
+    cid, n = 0, 1 << 14
+    cv = bo.CURVES[cid]
+    rng = np.random.default_rng(5)
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    ks[:, 0] = rng.integers(1, 1 << 62, size=n, dtype=np.uint64)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_k.data_ptr(), n, bases.data_ptr()))
+    scal = np.stack([np.frombuffer(int(v).to_bytes(32, "little"), dtype="<u8") for v in
+                     bo.seeded_scalars(cv, 4242, n)]).astype(np.uint64)
+    scal[3] = 0
+    scal[4] = zk.curves.ints_to_limbs([cv.r - 1], 4)[0]
+    d_s = torch.from_numpy(scal.view(np.int64)).cuda()
+    ck = zk.CommitterKey(bases, cid, ctx)
+    plain = ck.msm(d_s)
+    ck.precompute()
+    pre = ck.msm(d_s)
+    ck.close()
+    exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases.cpu().numpy().view(np.uint64), scal)
+    assert plain == pre
+    assert_point(pre, exp_xy, exp_inf, cid)
 
 
 @pytest.mark.parametrize("cid", [0, 1])

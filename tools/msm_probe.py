@@ -16,6 +16,8 @@ ks[:, 1:] = 0
 bases = torch.empty((nmax, 12), dtype=torch.int64, device="cuda")
 _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), nmax, bases.data_ptr()))
 ck = zk.CommitterKey(bases, 0, ctx)
+if os.environ.get("PRE"):
+    t0 = time.perf_counter(); ck.precompute(); torch.cuda.synchronize(); print(f"precompute {time.perf_counter()-t0:.3f}s", flush=True)
 scal = torch.randint(0, 1 << 62, (nmax, 4), dtype=torch.int64, device="cuda", generator=g)
 cases = [(nmax, 0), (nmax - 1, 0), (nmax - 1, 16), (nmax, 15), (nmax, 14), (nmax, 13), (nmax // 2, 0), (nmax, 17), (nmax, 18)]
 if len(sys.argv) > 1:

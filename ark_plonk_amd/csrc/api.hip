@@ -458,6 +458,22 @@ int zk_kzg_open_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d
     return zk_msm_g1_srs_dev(c, s, 0, d_w, wlen, out_xy, out_inf);
 }
 
+int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
+                       const uint64_t* challenge_mont, void* d_out, size_t* out_len) {
+    if (!c || !z_mont || !challenge_mont || !out_len || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
+    void* d_w = nullptr;
+    size_t wlen = 0;
+    Guard g(c);
+    int rc = kzg_open_prepare_dev(c, curve_id, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
+    if (rc) return rc;
+    *out_len = wlen;
+    if (wlen) {
+        if (!d_out) return ZK_ERR_BAD_ARG;
+        ZK_HIP_TRY(hipMemcpyAsync(d_out, d_w, wlen * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return ZK_OK;
+}
+
 // ------------------------------------------------------------------------------------- utilities
 int zk_g1_fixed_base_batch_dev(zk_ctx* c, int curve_id, const void* d_scalars, size_t n, void* d_out_xy) {
     if (!c || (n && (!d_scalars || !d_out_xy))) return ZK_ERR_BAD_ARG;

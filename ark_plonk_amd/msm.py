@@ -158,6 +158,29 @@ class CommitterKey:
         return _point(out, inf, self.curve)
 
 
+def kzg_witness(polys, point_mont, challenge_mont, curve="bls12_381", ctx: Context | None = None):
+    """(sum_k chi^k p_k - value) / (X - z) as canonical scalars on the device (the CPU part of PC::open)."""
+    import torch
+    cv = get_curve(curve)
+    ctx = ctx or default_context(polys[0].device.index)
+    k = len(polys)
+    ptrs = (ctypes.c_void_p * k)()
+    lens = (ctypes.c_size_t * k)()
+    m = 0
+    for i, p in enumerate(polys):
+        lens[i] = check_dev_tensor(p, 4, ctx.device)
+        ptrs[i] = p.data_ptr()
+        m = max(m, lens[i])
+    out = torch.empty((max(m, 1), 4), dtype=torch.int64, device=polys[0].device)
+    z = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
+    ch = np.ascontiguousarray(challenge_mont, dtype=np.uint64).reshape(4)
+    n_out = ctypes.c_size_t()
+    ctx.use_torch_stream()
+    check(lib().zk_kzg_witness_dev(ctx.handle, cv.curve_id, k, ptrs, lens, ptr_of(z), ptr_of(ch), ptr_of(out), ctypes.byref(n_out)),
+          "zk_kzg_witness_dev")
+    return out[: n_out.value]
+
+
 class VariableBaseMSM:
     """`ark_ec::msm::VariableBaseMSM`."""
 

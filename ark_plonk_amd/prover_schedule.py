@@ -55,6 +55,9 @@ class ProofSchedule:
         self.lo = rank * n // world
         self.hi = (rank + 1) * n // world
         self.points = []
+        # evaluation point and opening challenge (transcript outputs in the reference): fixed field elements
+        self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
+        self.chi_mont = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
 
     # -- one commitment = into_repr + MSM over this rank's shard (+ all-gather when world > 1)
     def _commit(self, coeffs, length=None):
@@ -71,13 +74,29 @@ class ProofSchedule:
             check(lib().zk_fr_from_mont_dev(self.ctx.handle, self.cv.curve_id, ptr_of(coeffs[lo:hi]), hi - lo, ptr_of(sc)))
             part = self.ck.msm_partial(sc, 0)
         else:
-            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)
-            part[0] = part[self.cv.fq_limbs] = 1
+            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)   # Z = 0: infinity
         mine = torch.from_numpy(part.view(np.int64)).to(coeffs.device)
         gathered = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(gathered, mine)
         allp = torch.stack(gathered).cpu().numpy().view(np.uint64)
         return sum_partials(allp, self.cv.curve_id)
+
+    # -- one opening = RLC + witness (replicated per rank) + MSM of n-1 (sharded like a commit)
+    def _open(self, polys):
+        if self.world == 1:
+            return self.ck.open(polys, self.z_mont, self.chi_mont)
+        from .msm import kzg_witness
+        w = kzg_witness(polys, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+        lo, hi = self.lo, min(self.hi, w.shape[0])
+        if hi > lo:
+            part = self.ck.msm_partial(w[lo:hi], 0)
+        else:
+            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)
+        torch = self.torch
+        mine = torch.from_numpy(part.view(np.int64)).to(w.device)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine)
+        return sum_partials(torch.stack(gathered).cpu().numpy().view(np.uint64), self.cv.curve_id)
 
     def run_once(self):
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
@@ -117,10 +136,12 @@ class ProofSchedule:
         # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618)
         for poly in (c[5], c[6], c[7], c[8], c[9], c[4], c[11]):
             out.append(self._commit(poly))
-        out.append(self._commit(c[12], n - 1))    # witness of the aggregate opening: n-1 coefficients
-        for poly in (c[8], c[0], c[1], c[3], c[6], c[9], c[4]):
+        # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
+        out.append(self._open([c[5], c[6], c[7], c[8], c[9], c[4], c[11], c[0], c[1], c[2], c[3]]))
+        saw = (c[8], c[0], c[1], c[3], c[6], c[9], c[4])
+        for poly in saw:
             out.append(self._commit(poly))
-        out.append(self._commit(c[10], n - 1))
+        out.append(self._open(list(saw)))         # PC::open at z*omega (prover.rs:609-618)
         assert len(out) == 29
         return out
 

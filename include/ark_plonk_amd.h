@@ -147,6 +147,12 @@ int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t 
 int zk_kzg_open_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                     const uint64_t* z_mont, const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf);
 
+/* Only the CPU-side part of PC::open: writes the witness polynomial's max(len)-1 coefficients as
+ * canonical scalars into d_out (device, max(len) x 4 limbs) and their count into *out_len; the caller
+ * runs the opening MSM itself (e.g. sharded over GPUs with zk_msm_g1_srs_partial_dev). */
+int zk_kzg_witness_dev(zk_ctx* ctx, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
+                       const uint64_t* z_mont, const uint64_t* challenge_mont, void* d_out, size_t* out_len);
+
 /* ---- utilities (synthetic SRS for tests/bench; stands in for PC::setup, out of scope) --------- */
 /* out[i] = scalars[i] * G1 generator, affine Montgomery, device buffers. */
 int zk_g1_fixed_base_batch_dev(zk_ctx* ctx, int curve_id, const void* d_scalars, size_t n, void* d_out_xy);

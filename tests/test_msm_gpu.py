@@ -220,3 +220,58 @@ def test_sharded_msm_partials_match_single(golden, ctx):
     got = zk.sum_partials(np.stack(parts), cid)
     assert_point(got, g["msm_srs_1024_out"], 0, cid)
     ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_kzg_open_golden(cid, golden, ctx):
+    """PC::open (prover.rs:582-591): RLC of the polynomials, witness by division by (X - z), commit."""
+    import torch
+    g = golden[cid]
+    ck = zk.CommitterKey(g["srs_1024"], cid, ctx)
+    polys = [torch.from_numpy(g[f"kzg_poly_{k}"].view(np.int64)).cuda() for k in range(4)]
+    got = ck.open(polys, g["kzg_z"], g["kzg_chi"])
+    assert_point(got, g["kzg_open"], g["kzg_open_inf"][0], cid)
+    # a single constant polynomial has an empty witness -> commitment to zero = infinity
+    one = torch.from_numpy(g["kzg_poly_0"][:1].view(np.int64)).cuda()
+    assert ck.open([one], g["kzg_z"], g["kzg_chi"]).infinity
+    ck.close()
+
+
+def test_kzg_open_vs_cpu_oracle_2_16(ctx, oracle_cpu):
+    """11 polynomials of 2^16 coefficients (the aw opening of prover.rs:582-591), ragged lengths."""
+    import torch
+    cid, n = 0, 1 << 16
+    cv = bo.CURVES[cid]
+    rng = np.random.default_rng(16)
+    tau = 0x7A5C0DE
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * tau % cv.r
+    d_tau = torch.from_numpy(zk.curves.ints_to_limbs(pw, 4).view(np.int64)).cuda()
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_tau.data_ptr(), n, bases.data_ptr()))
+    lens = [n, n, n - 1, n, n - 5, n, n, n // 2, n, n, 3]
+    polys = []
+    for ln in lens:
+        a = rng.integers(0, 1 << 62, size=(ln, 4), dtype=np.uint64)
+        polys.append(a)
+    z = oracle_cpu.convert(cid, "fr", True, zk.curves.ints_to_limbs(bo.seeded_scalars(cv, 1, 1), 4))[0]
+    chi = oracle_cpu.convert(cid, "fr", True, zk.curves.ints_to_limbs(bo.seeded_scalars(cv, 2, 1), 4))[0]
+    # oracle: RLC with its Fr ops, witness by synthetic division, commit
+    comb = np.zeros((n, 4), dtype=np.uint64)
+    chi_pow = oracle_cpu.convert(cid, "fr", True, np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    for p in polys:
+        term = oracle_cpu.fr_op(cid, "mul", p, np.repeat(chi_pow, p.shape[0], axis=0))
+        comb[: p.shape[0]] = oracle_cpu.fr_op(cid, "add", comb[: p.shape[0]], term)
+        chi_pow = oracle_cpu.fr_op(cid, "mul", chi_pow, chi.reshape(1, 4))
+    w = oracle_cpu.kzg_witness(cid, comb, z)
+    b_host = bases.cpu().numpy().view(np.uint64)
+    exp_xy, exp_inf = oracle_cpu.kzg_commit(cid, b_host, w)
+    ck = zk.CommitterKey(bases, cid, ctx)
+    got = ck.open([torch.from_numpy(p.view(np.int64)).cuda() for p in polys], z, chi)
+    assert_point(got, exp_xy, exp_inf, cid)
+    ck.precompute()
+    got2 = ck.open([torch.from_numpy(p.view(np.int64)).cuda() for p in polys], z, chi)
+    assert got2 == got
+    ck.close()

@@ -18,8 +18,8 @@ LIB = os.path.join(HERE, "libark_plonk_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
-FIELD_HDRS = ["field.cuh", "curve_params.h", "zk_common.h"]
-HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]
+FIELD_HDRS = ["field.cuh", "fieldu.cuh", "curve_params.h", "zk_common.h"]
+HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ecu.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]
 
 
 def jobs():
@@ -33,7 +33,7 @@ def jobs():
     ]
     for c in (0, 1):
         out.append((f"msm_c{c}.o", "msm.hip", [f"-DZK_CURVE_SEL={c}"], HOST_HDRS))
-        for s in range(3, 11):
+        for s in range(3, 10):
             out.append((f"ntt_pass_c{c}_s{s}.o", "ntt_pass_inst.hip", [f"-DZK_CURVE_SEL={c}", f"-DZK_NTT_S={s}"],
                         FIELD_HDRS + ["ntt_pass.cuh"]))
     return out

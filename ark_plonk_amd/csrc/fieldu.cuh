@@ -76,6 +76,13 @@ struct Fu {
         normalize(t);
         return t;
     }
+    ZK_HD static Fu sub2(const Fu& a, const Fu& b) {   // a - b + 2p, b < 2p (b a product)
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] - b.v[i] + P::Z2(i);
+        normalize(t);
+        return t;
+    }
     ZK_HD static Fu sub8(const Fu& a, const Fu& b) {   // a - b + 8p, b < 8p
         Fu t;
 #pragma unroll

@@ -4,20 +4,38 @@
 // _in_place as called by the reference at plonk-core/src/proof_system/prover.rs:196-203,240-242,
 // 281-283,302-305, quotient_poly.rs:72-120,175-177,205,294,325, permutation/mod.rs:671-674,751,800.
 //
-// Algorithm (not ark's): a multi-pass Cooley-Tukey decomposition N = 2^s1 * 2^s2 (* 2^s3).  Each
-// pass loads a tile of 2^s rows x C columns, runs the 2^s-point DIF transform with 8 elements per
-// lane held in VGPRs (three radix-2 stages per LDS exchange), multiplies by the inter-pass twiddle
-// w_M^(col*k) read from a precomputed table laid out like the data (coalesced), and stores in
-// place.  The last pass gathers R adjacent output digits per workgroup so the natural-order store
-// is R*32 B contiguous (digit reversal costs no extra pass).  Inner twiddles w_L^j are staged in
-// LDS.  Zero-extension (in_len < N), the coset pre-scale g^j, the 1/N scale and the coset
-// post-scale g^-j are fused into the first / last pass.  HBM-side the transform is
-// 2 * N * 32 B algorithmic bytes; the kernel is integer-VALU bound (Montgomery products).
+// Algorithm (not ark's): a multi-pass Cooley-Tukey decomposition N = 2^s1 * 2^s2 (* 2^s3), s <= 9.
+// Each pass gives every wavefront a tile of 2^s rows x 2^(9-s) columns = 512 elements, runs the
+// 2^s-point DIT transform in registers (8 elements per lane, three radix-2 stages per window, a
+// wave-private 2 KiB LDS scratch for the lane<->register transposes between windows -- no workgroup
+// barriers), multiplies by the inter-pass twiddle w_M^(col*k) read from a precomputed table laid out
+// like the data, and stores in place.  The last pass gathers adjacent output digits per wavefront so
+// the natural-order store is contiguous (digit reversal costs no extra pass).  Zero-extension
+// (in_len < N), the coset pre-scale g^j, the 1/N scale and the coset post-scale g^-j are fused into
+// the first / last pass.  Arithmetic: unsaturated 29-bit-limb Montgomery field (fieldu.cuh) with
+// twiddles stored as w * 2^261 mod r so the data never leave the arkworks (R = 2^256) domain.
+// HBM-side the transform is 2 * N * 32 B algorithmic bytes; the kernel is integer-VALU bound.
 #include "ctx.h"
 
 #include "ntt_pass.cuh"
 
 namespace {
+
+template <class Fr>
+ZK_D Fr ld_fr(const void* base, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <class Fr>
+ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
 
 // ------------------------------------------------------------------------------------ table builders
 template <class Fr>
@@ -26,8 +44,10 @@ struct PowBits {
 };
 // mode 0: out[i] = mul * base^i
 // mode 1: out[i] = mul * base^((col * k) mod 2^log_mprev), i = k * M + col, M = 2^log_m
+// Tables are written in the R' = 2^261 Montgomery form the pass kernels multiply with: `to_rp` is the
+// plain integer R' mod r, and Montgomery-multiplying the arkworks-form value by it gives w * R' mod r.
 template <class Fr>
-__global__ void gen_pow_table(void* out, uint64_t n, PowBits<Fr> pb, Fr mul, int mode, uint32_t log_m, uint32_t log_mprev) {
+__global__ void gen_pow_table(void* out, uint64_t n, PowBits<Fr> pb, Fr mul, int mode, uint32_t log_m, uint32_t log_mprev, Fr to_rp) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t e = i;
@@ -40,7 +60,33 @@ __global__ void gen_pow_table(void* out, uint64_t n, PowBits<Fr> pb, Fr mul, int
     for (int b = 0; b < 32; ++b) {
         if ((e >> b) & 1ull) r = Fr::mul(r, pb.p[b]);
     }
-    st_fr<Fr>(out, i, r);
+    st_fr<Fr>(out, i, Fr::mul(r, to_rp));
+}
+
+// tiny transforms (N = 1, 2, 4): one lane, straight from the definition (arkworks-form arithmetic)
+template <class Fr>
+__global__ void ntt_tiny(const void* in, void* out, uint64_t in_len, uint32_t log_n, Fr w /* w_N or its inverse */, Fr pre_g /* g or 1 */,
+                         Fr post_g /* g^-1 or 1 */, Fr scale /* 1/N or 1 */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n = 1u << log_n;
+    Fr x[4], y[4];
+    Fr gp = Fr::one();
+    for (uint32_t i = 0; i < n; ++i) {
+        x[i] = i < in_len ? Fr::mul(ld_fr<Fr>(in, i), gp) : Fr::zero();
+        gp = Fr::mul(gp, pre_g);
+    }
+    Fr wi = Fr::one(), pg = scale;
+    for (uint32_t i = 0; i < n; ++i) {
+        Fr acc = Fr::zero(), wij = Fr::one();
+        for (uint32_t j = 0; j < n; ++j) {
+            acc = Fr::add(acc, Fr::mul(x[j], wij));
+            wij = Fr::mul(wij, wi);
+        }
+        y[i] = Fr::mul(acc, pg);
+        pg = Fr::mul(pg, post_g);
+        wi = Fr::mul(wi, w);
+    }
+    for (uint32_t i = 0; i < n; ++i) st_fr<Fr>(out, i, y[i]);
 }
 
 template <class Fr>
@@ -78,26 +124,37 @@ PowBits<Fr> make_powbits(Fr base) {
     return pb;
 }
 
-template <class Fr>
-int launch_pow_table(zk_ctx* c, void* out, uint64_t n, Fr base, Fr mul, int mode, uint32_t log_m, uint32_t log_mprev) {
+// R' mod r as a plain integer in the saturated type's limbs
+template <class C>
+typename C::Fr rprime_plain() {
+    typename C::Fr r;
+    C::FrU::one().pack_words(r.v);
+    return r;
+}
+
+template <class C>
+int launch_pow_table(zk_ctx* c, void* out, uint64_t n, typename C::Fr base, typename C::Fr mul, int mode, uint32_t log_m,
+                     uint32_t log_mprev) {
+    typedef typename C::Fr Fr;
     if (n == 0) return ZK_OK;
     PowBits<Fr> pb = make_powbits(base);
+    Fr to_rp = rprime_plain<C>();
     const int T = 256;
     uint64_t blocks = (n + T - 1) / T;
-    hipLaunchKernelGGL(gen_pow_table<Fr>, dim3((unsigned)blocks), dim3(T), 0, c->stream, out, n, pb, mul, mode, log_m, log_mprev);
+    hipLaunchKernelGGL(gen_pow_table<Fr>, dim3((unsigned)blocks), dim3(T), 0, c->stream, out, n, pb, mul, mode, log_m, log_mprev, to_rp);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
 
-// pass decomposition: every pass radix in [3, 10] (single pass for log_n <= 10)
+// pass decomposition: every pass radix in [3, 9] (a wavefront holds 2^9 elements)
 void decompose(uint32_t log_n, int& n_pass, int s[4]) {
     s[0] = s[1] = s[2] = s[3] = 0;
-    if (log_n <= 10) {
+    if (log_n <= 9) {
         n_pass = 1;
         s[0] = (int)log_n;
         return;
     }
-    n_pass = (int)((log_n + 9) / 10);
+    n_pass = (int)((log_n + 8) / 9);
     int base = (int)log_n / n_pass, extra = (int)log_n % n_pass;
     for (int i = 0; i < n_pass; ++i) s[i] = base + (i < extra ? 1 : 0);
 }
@@ -116,7 +173,7 @@ int get_inner_tw(zk_ctx* c, int s, bool inverse, void** out) {
     ZK_HIP_TRY(hipMalloc(&p, cnt * sizeof(Fr)));
     Fr w = root_of_unity_host<C>((uint32_t)s);
     if (inverse) w = Fr::inverse(w);
-    int rc = launch_pow_table<Fr>(c, p, cnt, w, Fr::one(), 0, 0, 0);
+    int rc = launch_pow_table<C>(c, p, cnt, w, Fr::one(), 0, 0, 0);
     if (rc) return rc;
     c->inner_tw[key] = p;
     *out = p;
@@ -137,7 +194,6 @@ int get_plan(zk_ctx* c, uint32_t log_n, bool inverse, NttPlan** out) {
     pl->log_n = log_n;
     pl->inverse = inverse;
     decompose(log_n, pl->n_pass, pl->s);
-    Fr n_inv = Fr::inverse(Fr::from_u64(1ull << log_n));
     uint32_t log_mprev = log_n;
     for (int p = 0; p < pl->n_pass; ++p) {
         if (log_n >= 3) {
@@ -151,9 +207,7 @@ int get_plan(zk_ctx* c, uint32_t log_n, bool inverse, NttPlan** out) {
             if (e != hipSuccess) { delete pl; return ZK_ERR_OOM; }
             Fr w = root_of_unity_host<C>(log_mprev);
             if (inverse) w = Fr::inverse(w);
-            // 1/N is folded into the first inter-pass table of an inverse transform
-            Fr mul = (inverse && p == 0) ? n_inv : Fr::one();
-            int rc = launch_pow_table<Fr>(c, pl->tw_pass[p], cnt, w, mul, 1, log_m, log_mprev);
+            int rc = launch_pow_table<C>(c, pl->tw_pass[p], cnt, w, Fr::one(), 1, log_m, log_mprev);
             if (rc) { delete pl; return rc; }
             log_mprev = log_m;
         }
@@ -163,6 +217,7 @@ int get_plan(zk_ctx* c, uint32_t log_n, bool inverse, NttPlan** out) {
     return ZK_OK;
 }
 
+// g^j (forward) or g^-j (inverse) tables, R'-form.
 template <class C>
 int ensure_coset(zk_ctx* c, bool inv, uint64_t len, void** out) {
     typedef typename C::Fr Fr;
@@ -178,7 +233,7 @@ int ensure_coset(zk_ctx* c, bool inv, uint64_t len, void** out) {
         if (rc) return rc;
         Fr g = Fr::from_u32(C::FrP::GENERATOR);
         if (inv) g = Fr::inverse(g);
-        rc = launch_pow_table<Fr>(c, buf.p, want, g, Fr::one(), 0, 0, 0);
+        rc = launch_pow_table<C>(c, buf.p, want, g, Fr::one(), 0, 0, 0);
         if (rc) return rc;
         have = want;
     }
@@ -188,38 +243,44 @@ int ensure_coset(zk_ctx* c, bool inv, uint64_t len, void** out) {
 
 // The pass kernels are compiled per (curve, S) in ntt_pass_inst.hip; ntt_pass_table.hip maps
 // (curve, S) to the launcher of that object.
-typedef int (*NttPassLauncher)(int final_pass, const NttPassArgs* a, uint64_t n_tiles, uint32_t threads, size_t shmem, hipStream_t st);
+typedef int (*NttPassLauncher)(int final_pass, const NttPassArgs* a, hipStream_t st);
 extern "C" NttPassLauncher zk_ntt_pass_launcher(int curve, int s);
 
 template <class C>
-int dispatch_pass(zk_ctx* c, int s, bool final_pass, const NttPassArgs& a, uint64_t n_tiles, uint32_t threads) {
-    if (s < 3 || s > 10) return ZK_ERR_UNSUPPORTED;
+int dispatch_pass(zk_ctx* c, int s, bool final_pass, const NttPassArgs& a) {
+    if (s < 3 || s > 9) return ZK_ERR_UNSUPPORTED;
     NttPassLauncher fn = zk_ntt_pass_launcher(C::ID, s);
     if (!fn) return ZK_ERR_UNSUPPORTED;
-    const uint32_t L = 1u << s;
-    const uint32_t Cc = 1u << a.logc;
-    const uint32_t nslots = (L * Cc + (((L * Cc) >> 4) << 1)) + 2;
-    const size_t shmem = (size_t)(2 * nslots + L) * sizeof(uint4);
     ProfScope ps(c, "ntt_pass");
-    hipError_t e = (hipError_t)fn(final_pass ? 1 : 0, &a, n_tiles, threads, shmem, c->stream);
+    hipError_t e = (hipError_t)fn(final_pass ? 1 : 0, &a, c->stream);
     ZK_HIP_TRY(e);
     return ZK_OK;
 }
-
-// tile elements per workgroup: 2^11 (64 KiB of data + padding -> two workgroups per CU)
-constexpr uint32_t LOG_TILE = 11;
 
 template <class C>
 int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
     typedef typename C::Fr Fr;
     if (log_n > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
-    if (log_n > 30) return ZK_ERR_UNSUPPORTED;
+    if (log_n > 27) return ZK_ERR_UNSUPPORTED;
     const uint64_t N = 1ull << log_n;
     if (in_len > N) return ZK_ERR_BAD_ARG;
     const bool inverse = (kind == ZK_NTT_IFFT || kind == ZK_NTT_COSET_IFFT);
+    int rc;
+    Fr n_inv = Fr::inverse(Fr::from_u64(N));
+    if (log_n < 3) {
+        Fr w = root_of_unity_host<C>(log_n);
+        if (inverse) w = Fr::inverse(w);
+        Fr g = Fr::from_u32(C::FrP::GENERATOR);
+        Fr pre_g = kind == ZK_NTT_COSET_FFT ? g : Fr::one();
+        Fr post_g = kind == ZK_NTT_COSET_IFFT ? Fr::inverse(g) : Fr::one();
+        ProfScope ps(c, "ntt_pass");
+        hipLaunchKernelGGL(ntt_tiny<Fr>, dim3(1), dim3(64), 0, c->stream, d_in, d_out, (uint64_t)in_len, log_n, w, pre_g, post_g,
+                           inverse ? n_inv : Fr::one());
+        ZK_HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
     void* pre = nullptr;
     void* post = nullptr;
-    int rc;
     if (kind == ZK_NTT_COSET_FFT && in_len > 0) {
         rc = ensure_coset<C>(c, false, in_len, &pre);
         if (rc) return rc;
@@ -227,22 +288,6 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
     if (kind == ZK_NTT_COSET_IFFT) {
         rc = ensure_coset<C>(c, true, N, &post);
         if (rc) return rc;
-    }
-    Fr n_inv = Fr::inverse(Fr::from_u64(N));
-
-    NttPassArgs a;
-    memset(&a, 0, sizeof a);
-    a.log_n = log_n;
-    if (log_n < 3) {
-        a.in = d_in; a.out = d_out; a.in_len = in_len; a.pre_mul = pre; a.post_mul = post;
-        a.has_scale = inverse ? 1 : 0;
-        for (int i = 0; i < 8; ++i) a.scale[i] = n_inv.v[i];
-        Fr w = root_of_unity_host<C>(log_n);
-        if (inverse) w = Fr::inverse(w);
-        ProfScope ps(c, "ntt_pass");
-        hipLaunchKernelGGL(ntt_tiny<Fr>, dim3(1), dim3(64), 0, c->stream, a, w);
-        ZK_HIP_TRY(hipGetLastError());
-        return ZK_OK;
     }
     NttPlan* pl = nullptr;
     rc = get_plan<C>(c, log_n, inverse, &pl);
@@ -254,7 +299,11 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
         if (rc) return rc;
         work = c->ntt_work.p;
     }
+    // the last pass multiplies every output by 1/N (inverse) or 1 (forward) -- the product that also
+    // brings the lazily reduced value back under 2r -- and, for coset_ifft, by g^-j from the table
+    const Fr to_rp = rprime_plain<C>();
     uint32_t log_mprev = log_n;
+    NttPassArgs a;
     for (int p = 0; p < pl->n_pass; ++p) {
         const int s = pl->s[p];
         const bool last = (p + 1 == pl->n_pass);
@@ -265,34 +314,27 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
         a.in_len = (p == 0) ? in_len : N;
         a.tw_inner = pl->tw_inner[p];
         a.pre_mul = (p == 0) ? pre : nullptr;
-        uint64_t n_tiles;
-        uint32_t threads;
+        const uint32_t LC = 9u - (uint32_t)s;
         if (!last) {
             uint32_t log_m = log_mprev - (uint32_t)s;
-            uint32_t logc = LOG_TILE > (uint32_t)s ? LOG_TILE - (uint32_t)s : 0;
-            if (logc > log_m) logc = log_m;
+            uint32_t logc = LC < log_m ? LC : log_m;
             a.logc = logc;
             a.log_m = log_m;
             a.log_mprev = log_mprev;
             a.tw_pass = pl->tw_pass[p];
-            n_tiles = N >> ((uint32_t)s + logc);
-            threads = 1u << ((uint32_t)s + logc - 3);
+            a.n_tiles = (uint32_t)(N >> ((uint32_t)s + logc));
             log_mprev = log_m;
         } else {
             uint32_t s1 = (pl->n_pass > 1) ? (uint32_t)pl->s[0] : 0;
-            uint32_t logc = LOG_TILE > (uint32_t)s ? LOG_TILE - (uint32_t)s : 0;
-            if (logc > 3) logc = 3;   // 8 x 32 B = 256 B contiguous store segments are enough
-            if (logc > s1) logc = s1;
+            uint32_t logc = LC < s1 ? LC : s1;
             a.logc = logc;
             a.s1 = s1;
             a.post_mul = post;
-            // the 1/N factor rides on the first inter-pass table when there is one
-            a.has_scale = (inverse && pl->n_pass == 1) ? 1 : 0;
-            for (int i = 0; i < 8; ++i) a.scale[i] = n_inv.v[i];
-            n_tiles = N >> ((uint32_t)s + logc);
-            threads = 1u << ((uint32_t)s + logc - 3);
+            Fr sc = Fr::mul(inverse ? n_inv : Fr::one(), to_rp);   // R'-form of 1/N or 1
+            for (int i = 0; i < 8; ++i) a.scale[i] = sc.v[i];
+            a.n_tiles = (uint32_t)(N >> ((uint32_t)s + logc));
         }
-        rc = dispatch_pass<C>(c, s, last, a, n_tiles, threads);
+        rc = dispatch_pass<C>(c, s, last, a);
         if (rc) return rc;
     }
     return ZK_OK;

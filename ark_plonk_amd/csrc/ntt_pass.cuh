@@ -1,66 +1,40 @@
 // NTT pass kernels (templates).  Instantiated once per (curve, radix exponent S) in
 // ntt_pass_inst.hip so the heavy kernels build in parallel; see ntt.hip for the algorithm notes.
+//
+// One WAVEFRONT owns a tile of 512 elements = 2^S rows x 2^(9-S) columns and runs the 2^S-point
+// decimation-in-time transform of each column entirely in its own registers: 8 elements per lane,
+// three radix-2 stages per window, and between windows a lane<->register transpose through a 2 KiB
+// wave-private LDS scratch (one 29-bit limb plane at a time -- no workgroup barrier, no LDS-resident
+// tile, so occupancy is bounded by VGPRs only).  Arithmetic is the unsaturated 29-bit-limb Montgomery
+// field (fieldu.cuh): data stay in the arkworks Montgomery domain (R = 2^256) because every twiddle
+// table holds w * 2^261 mod r, and DIT butterflies (t = w*b; a + t, a - t + 2r) grow the lazily
+// reduced values only additively (< 20 r after 9 stages), so no reduction is needed inside a pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_params.h"
 #include "field.cuh"
-
-
-// ------------------------------------------------------------------------------------------------
-template <class Fr>
-ZK_D Fr ld_fr(const void* base, uint64_t idx) {
-    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
-    uint4 a = q[0], b = q[1];
-    Fr r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
-}
-template <class Fr>
-ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
-    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
-
-ZK_D uint32_t lds_pad(uint32_t slot) { return slot + ((slot >> 4) << 1); }
-
-template <class Fr>
-ZK_D void lds_put(uint4* lo, uint4* hi, uint32_t slot, const Fr& r) {
-    uint32_t p = lds_pad(slot);
-    lo[p] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    hi[p] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
-template <class Fr>
-ZK_D Fr lds_get(const uint4* lo, const uint4* hi, uint32_t slot) {
-    uint32_t p = lds_pad(slot);
-    uint4 a = lo[p], b = hi[p];
-    Fr r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
-}
+#include "fieldu.cuh"
 
 struct NttPassArgs {
     const void* in;
     void* out;
-    const void* tw_inner;   // L/2 entries w_L^j (or inverse)
-    const void* tw_pass;    // inter-pass table [k][col], nullptr on the last pass
+    const void* tw_inner;   // 2^S / 2 entries w_L^j (R'-form, 32 B packed)
+    const void* tw_pass;    // inter-pass table [k][col] (R'-form), nullptr on the last pass
     const void* pre_mul;    // g^j table (first pass of coset_fft) or nullptr
     const void* post_mul;   // g^-j table (last pass of coset_ifft) or nullptr
-    uint32_t scale[8];      // 1/N (single-pass inverse only)
-    int has_scale;
+    uint32_t scale[8];      // last pass: 1 or 1/N, R'-form packed (applied to every output)
     uint64_t in_len;        // valid elements of `in` (first pass); N otherwise
     uint32_t log_n;
-    uint32_t logc;          // log2 of tile columns (non-final) / gathered blocks (final)
+    uint32_t logc;          // log2 of the columns (non-final) / gathered blocks (final) actually used, <= 9 - S
     uint32_t log_m;         // non-final: log2 of the row stride M
     uint32_t log_mprev;     // non-final: log2 of the block this pass transforms (M * L)
     uint32_t s1;            // final: size (bits) of the most significant digit of the block index
+    uint32_t n_tiles;
 };
 
 __host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __brev(x) >> (32 - bits);
+    return bits ? __brev(x) >> (32 - bits) : 0u;
 #else
     uint32_t r = 0;
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
@@ -68,215 +42,182 @@ __host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
 #endif
 }
 
-// One window of up to three DIF stages on the 8 registers of a lane.
-//   B0   : lowest row bit covered by the window; element e <-> row bits [B0, B0+3)
-//   NST  : number of stages performed (row bits B0+NST-1 .. B0), 1..3
-template <class Fr, int S, int B0, int NST>
-ZK_D void dif_window(Fr (&x)[8], uint32_t v, const uint4* tw_lo, const uint4* tw_hi) {
+// 32-byte packed integer -> limbs (no domain change)
+template <class F>
+ZK_D F ld_u(const void* base, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    uint4 a = q[0], b = q[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return F::split_words(w);
+}
+// value < 2r -> canonical -> 32-byte store
+template <class F>
+ZK_D void st_u(void* base, uint64_t idx, const F& x) {
+    uint32_t w[8];
+    F::canonical_lt2p(x).pack_words(w);
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+template <int B0>
+ZK_D uint32_t window_pos(uint32_t v, uint32_t e) {
+    return ((v >> B0) << (B0 + 3)) | (e << B0) | (v & ((1u << B0) - 1u));
+}
+
+// lane <-> register transpose through the wave's scratch plane, one limb at a time
+template <class F>
+ZK_D void wave_exchange(F (&x)[8], volatile uint32_t* sc, const uint32_t (&widx)[8], const uint32_t (&ridx)[8]) {
+#pragma unroll
+    for (int l = 0; l < F::NL; ++l) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc[widx[e]] = x[e].v[l];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e].v[l] = sc[ridx[e]];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// DIT stages for the position bits B0+LB_LO .. B0+LB_HI-1 on the 8 registers of a lane
+// (register e <-> position bits [B0, B0+3) ; v = the other position bits)
+template <class F, int S, int B0, int LB_LO, int LB_HI>
+ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
     const uint32_t vlow = v & ((1u << B0) - 1u);
 #pragma unroll
-    for (int lb = NST - 1; lb >= 0; --lb) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int beta = B0 + lb;                 // row bit paired by this stage
+    for (int lb = LB_LO; lb < LB_HI; ++lb) {
+        const int t = B0 + lb;   // position bit paired by this stage; twiddle w_{2^(t+1)}^(p mod 2^t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (e & (1 << lb)) continue;
             const int eo = e | (1 << lb);
-            // twiddle exponent: (row mod 2^beta) * 2^(S-1-beta)
-            const uint32_t rowlow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
-            const uint32_t j = rowlow << (S - 1 - beta);
-            Fr a = x[e], b = x[eo];
-            x[e] = Fr::add(a, b);
-            Fr d = Fr::sub(a, b);
-            uint4 wl = tw_lo[j], wh = tw_hi[j];
-            Fr w;
-            w.v[0] = wl.x; w.v[1] = wl.y; w.v[2] = wl.z; w.v[3] = wl.w;
-            w.v[4] = wh.x; w.v[5] = wh.y; w.v[6] = wh.z; w.v[7] = wh.w;
-            x[eo] = Fr::mul(d, w);
+            const uint32_t plow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
+            const uint32_t j = plow << (S - 1 - t);
+            F w = ld_u<F>(tw, j);
+            F m = F::mul(x[eo], w);            // < 2r
+            x[eo] = F::sub2(x[e], m);
+            x[e] = F::add(x[e], m);
         }
     }
 }
 
-template <int B0>
-ZK_D uint32_t window_row(uint32_t v, uint32_t e) {
-    return ((v >> B0) << (B0 + 3)) | (e << B0) | (v & ((1u << B0) - 1u));
-}
-
-// Run all DIF stages of a 2^S-point transform.  On entry x[e] holds row e*(L/8)+v (window
-// B0 = S-3); on exit x[e] holds position row = 8*v+e of the bit-reversed-order result.
-// SLOT(row) maps a row of this lane's column to an LDS slot.
-template <class Fr, int S, int REM, class SlotFn>
-ZK_D void dif_all(Fr (&x)[8], uint32_t v, uint4* d_lo, uint4* d_hi, const uint4* tw_lo, const uint4* tw_hi, SlotFn slot) {
+// all windows of a 2^S-point DIT; on entry x[e] holds position 8v+e (window B0 = 0), on exit the
+// top-window layout: position (e << (S-3)) | v  (S >= 3)
+template <class F, int S, int B0>
+ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw, volatile uint32_t* sc) {
+    constexpr int REM = S - B0;          // position bits not yet processed
     if constexpr (REM >= 3) {
-        constexpr int B0 = REM - 3;
-        dif_window<Fr, S, B0, 3>(x, v, tw_lo, tw_hi);
-        if constexpr (B0 > 0) {
-            constexpr int NB0 = (B0 >= 3) ? B0 - 3 : 0;
-            // exchange: write rows of this window, read rows of the next
+        dit_window<F, S, B0, 0, 3>(x, v, tw);
+        if constexpr (REM > 3) {
+            constexpr int NB0 = (REM - 3 >= 3) ? B0 + 3 : S - 3;
+            uint32_t wi[8], ri[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) lds_put<Fr>(d_lo, d_hi, slot(window_row<B0>(v, e)), x[e]);
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = lds_get<Fr>(d_lo, d_hi, slot(window_row<NB0>(v, e)));
-            dif_all<Fr, S, B0, SlotFn>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
+            for (int e = 0; e < 8; ++e) {
+                wi[e] = (window_pos<B0>(v, e) << LC) | c;
+                ri[e] = (window_pos<NB0>(v, e) << LC) | c;
+            }
+            wave_exchange<F>(x, sc, wi, ri);
+            if constexpr (REM - 3 >= 3) {
+                dit_all<F, S, B0 + 3>(x, v, c, LC, tw, sc);
+            } else {
+                // last, partial window: registers cover position bits [S-3, S); only the top REM-3 are new
+                dit_window<F, S, S - 3, 3 - (REM - 3), 3>(x, v, tw);
+            }
         }
-    } else if constexpr (REM > 0) {
-        dif_window<Fr, S, 0, REM>(x, v, tw_lo, tw_hi);
     }
 }
 
 // ---------------------------------------------------------------------------------- non-final pass
-template <class Fr, int S>
-__global__ void ntt_pass_mid(NttPassArgs a) {
-    constexpr uint32_t L = 1u << S;
-    extern __shared__ uint4 smem[];
-    const uint32_t logc = a.logc;
-    const uint32_t C = 1u << logc;
-    const uint32_t nslots = lds_pad(L * C) + 2;
-    uint4* d_lo = smem;
-    uint4* d_hi = smem + nslots;
-    uint4* tw_lo = smem + 2 * nslots;
-    uint4* tw_hi = tw_lo + L / 2;
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t T = blockDim.x;
-    for (uint32_t j = tid; j < L / 2; j += T) {
-        const uint4* q = reinterpret_cast<const uint4*>(a.tw_inner) + 2 * j;
-        tw_lo[j] = q[0];
-        tw_hi[j] = q[1];
-    }
-    const uint32_t c = tid & (C - 1);
-    const uint32_t v = tid >> logc;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t lcg = a.log_m - logc;                    // log2(column groups per block)
-    const uint64_t blk = tile >> lcg;
-    const uint64_t cg = tile & ((1ull << lcg) - 1);
-    const uint64_t col = (cg << logc) + c;
+template <class F, int S>
+__global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
+    constexpr uint32_t LC = 9 - S;
+    __shared__ uint32_t scratch[4][512];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= a.n_tiles) return;
+    volatile uint32_t* sc = scratch[wv];
+    const uint32_t c = lane & ((1u << LC) - 1u);
+    const uint32_t v = lane >> LC;
+    const bool active = c < (1u << a.logc);
+    const uint32_t lcg = a.log_m - a.logc;                   // log2(column groups per block)
+    const uint64_t blk = (uint64_t)tile >> lcg;
+    const uint64_t cg = (uint64_t)tile & ((1ull << lcg) - 1);
+    const uint64_t col = (cg << a.logc) + c;
     const uint64_t base = (blk << a.log_mprev) + col;
 
-    Fr x[8];
+    F x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const uint64_t row = (uint64_t)e * (L / 8) + v;
+        const uint64_t row = bitrev32((v << 3) | e, S);      // DIT consumes bit-reversed rows
         const uint64_t idx = base + (row << a.log_m);
-        if (idx < a.in_len) {
-            x[e] = ld_fr<Fr>(a.in, idx);
-            if (a.pre_mul) x[e] = Fr::mul(x[e], ld_fr<Fr>(a.pre_mul, idx));
+        if (active && idx < a.in_len) {
+            x[e] = ld_u<F>(a.in, idx);
+            if (a.pre_mul) x[e] = F::mul(x[e], ld_u<F>(a.pre_mul, idx));
         } else {
-            x[e] = Fr::zero();
+            x[e] = F::zero();
         }
     }
-    __syncthreads();  // inner twiddles staged
-    auto slot = [=](uint32_t row) -> uint32_t { return (row << logc) | c; };
-    dif_all<Fr, S, S>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
-
+    dit_all<F, S, 0>(x, v, c, LC, a.tw_inner, sc);
+    if (!active) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const uint32_t row = (v << 3) | e;
-        const uint64_t k = bitrev32(row, S);
-        Fr w = ld_fr<Fr>(a.tw_pass, (k << a.log_m) + col);
-        st_fr<Fr>(a.out, base + (k << a.log_m), Fr::mul(x[e], w));
+        const uint64_t k = S >= 3 ? (((uint64_t)e << (S - 3)) | v) : e;
+        F w = ld_u<F>(a.tw_pass, (k << a.log_m) + col);
+        st_u<F>(a.out, base + (k << a.log_m), F::mul(x[e], w));
     }
 }
 
 // -------------------------------------------------------------------------------------- final pass
-template <class Fr, int S>
-__global__ void ntt_pass_final(NttPassArgs a) {
+template <class F, int S>
+__global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
     constexpr uint32_t L = 1u << S;
-    extern __shared__ uint4 smem[];
-    const uint32_t logc = a.logc;
-    const uint32_t C = 1u << logc;
-    const uint32_t nslots = lds_pad(L * C) + 2;
-    uint4* d_lo = smem;
-    uint4* d_hi = smem + nslots;
-    uint4* tw_lo = smem + 2 * nslots;
-    uint4* tw_hi = tw_lo + L / 2;
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t T = blockDim.x;
-    for (uint32_t j = tid; j < L / 2; j += T) {
-        const uint4* q = reinterpret_cast<const uint4*>(a.tw_inner) + 2 * j;
-        tw_lo[j] = q[0];
-        tw_hi[j] = q[1];
-    }
-    // block index digits: b = k1 * 2^log_rest + rho ; this tile gathers C consecutive k1
+    constexpr uint32_t LC = 9 - S;
+    __shared__ uint32_t scratch[4][512];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= a.n_tiles) return;
+    volatile uint32_t* sc = scratch[wv];
+    // block index digits: b = k1 * 2^log_rest + rho ; this tile gathers 2^logc consecutive k1
     const uint32_t log_nb = a.log_n - S;
     const uint32_t log_rest = log_nb - a.s1;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t lg = a.s1 - logc;
-    const uint64_t rho = tile >> lg;
-    const uint64_t g = tile & ((1ull << lg) - 1);
+    const uint32_t lg = a.s1 - a.logc;
+    const uint64_t rho = (uint64_t)tile >> lg;
+    const uint64_t g = (uint64_t)tile & ((1ull << lg) - 1);
 
-    // load mapping: lanes run along the (contiguous) row axis
-    const uint32_t v = tid & (L / 8 - 1);
-    const uint32_t c = tid >> (S - 3);
-    const uint64_t k1 = (g << logc) + c;
-    const uint64_t b = (k1 << log_rest) | rho;
-    Fr x[8];
+    // coalesced load: element q = e*64 + lane -> (gathered block q >> S, row q & (L-1))
+    F x[8];
+    uint32_t wi[8], ri[8];
+    const uint32_t c = lane & ((1u << LC) - 1u);
+    const uint32_t v = lane >> LC;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const uint64_t row = (uint64_t)e * (L / 8) + v;
+        const uint32_t q = (uint32_t)e * 64u + lane;
+        const uint32_t cb = q >> S, row = q & (L - 1);
+        const uint64_t b = ((((uint64_t)g << a.logc) + cb) << log_rest) | rho;
         const uint64_t idx = (b << S) + row;
-        if (idx < a.in_len) {
-            x[e] = ld_fr<Fr>(a.in, idx);
-            if (a.pre_mul) x[e] = Fr::mul(x[e], ld_fr<Fr>(a.pre_mul, idx));
+        if (cb < (1u << a.logc) && idx < a.in_len) {
+            x[e] = ld_u<F>(a.in, idx);
+            if (a.pre_mul) x[e] = F::mul(x[e], ld_u<F>(a.pre_mul, idx));
         } else {
-            x[e] = Fr::zero();
+            x[e] = F::zero();
         }
+        wi[e] = (bitrev32(row, S) << LC) | cb;               // DIT position of this row
+        ri[e] = (((v << 3) | (uint32_t)e) << LC) | c;        // window-0 layout
     }
-    __syncthreads();
-    auto slot = [=](uint32_t row) -> uint32_t { return (c << S) | row; };
-    dif_all<Fr, S, S>(x, v, d_lo, d_hi, tw_lo, tw_hi, slot);
-
-    // transpose through LDS so that stores run along the gathered-digit axis
+    wave_exchange<F>(x, sc, wi, ri);
+    dit_all<F, S, 0>(x, v, c, LC, a.tw_inner, sc);
+    if (c >= (1u << a.logc)) return;
+    const uint64_t k1o = ((uint64_t)g << a.logc) + c;
+    const uint64_t obase = k1o + (rho << a.s1);              // digit-reversed block index
+    F sc_mul = F::split_words(a.scale);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lds_put<Fr>(d_lo, d_hi, slot((v << 3) | e), x[e]);
-    __syncthreads();
-    const uint32_t c2 = tid & (C - 1);
-    const uint32_t j2 = tid >> logc;
-    const uint64_t k1o = (g << logc) + c2;
-    const uint64_t obase = k1o + (rho << a.s1);   // digit-reversed block index
-    Fr sc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sc.v[i] = a.scale[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t k = j2 + (uint32_t)i * (L / 8);
-        const uint32_t row = bitrev32(k, S);
-        Fr y = lds_get<Fr>(d_lo, d_hi, (c2 << S) | row);
-        const uint64_t oidx = obase + ((uint64_t)k << log_nb);
-        if (a.has_scale) y = Fr::mul(y, sc);
-        if (a.post_mul) y = Fr::mul(y, ld_fr<Fr>(a.post_mul, oidx));
-        st_fr<Fr>(a.out, oidx, y);
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t k = S >= 3 ? (((uint64_t)e << (S - 3)) | v) : e;
+        const uint64_t oidx = obase + (k << log_nb);
+        // every output passes one Montgomery product: it carries 1/N or g^-j/N where needed and
+        // brings the lazily reduced value (< 20 r) back under 2r for the canonical store
+        F y = F::mul(x[e], sc_mul);
+        if (a.post_mul) y = F::mul(y, ld_u<F>(a.post_mul, oidx));
+        st_u<F>(a.out, oidx, y);
     }
 }
-
-// tiny transforms (N = 1, 2, 4): one lane, straight from the definition
-template <class Fr>
-__global__ void ntt_tiny(NttPassArgs a, Fr w /* w_N */) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t n = 1u << a.log_n;
-    Fr x[4], y[4];
-    for (uint32_t i = 0; i < n; ++i) {
-        x[i] = i < a.in_len ? ld_fr<Fr>(a.in, i) : Fr::zero();
-        if (a.pre_mul && i < a.in_len) x[i] = Fr::mul(x[i], ld_fr<Fr>(a.pre_mul, i));
-    }
-    Fr sc;
-    for (int i = 0; i < 8; ++i) sc.v[i] = a.scale[i];
-    Fr wi = Fr::one();  // w^i
-    for (uint32_t i = 0; i < n; ++i) {
-        Fr acc = Fr::zero();
-        Fr wij = Fr::one();
-        for (uint32_t j = 0; j < n; ++j) {
-            acc = Fr::add(acc, Fr::mul(x[j], wij));
-            wij = Fr::mul(wij, wi);
-        }
-        if (a.has_scale) acc = Fr::mul(acc, sc);
-        if (a.post_mul) acc = Fr::mul(acc, ld_fr<Fr>(a.post_mul, i));
-        y[i] = acc;
-        wi = Fr::mul(wi, w);
-    }
-    for (uint32_t i = 0; i < n; ++i) st_fr<Fr>(a.out, i, y[i]);
-}
-

@@ -112,6 +112,7 @@ def unsat_struct(sname, p, nl, sat_words):
         "C_OUT": limbs29(Rs % p, nl),                     # x*R' -> x*R : montmul by R
         # multiples of p added before a subtraction (limbs are signed during carry propagation)
         "ZP": limbs29(p, nl),
+        "Z2": limbs29(2 * p, nl),
         "Z8": limbs29(8 * p, nl),
         "Z16": limbs29(16 * p, nl),
     }

@@ -16,7 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libark_plonk_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# -pragma-unroll-threshold: the NTT passes keep 8 field elements per lane in registers and every loop over
+# them must fully unroll (a rolled loop indexes the array at run time and sends it to scratch memory)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+         "-mllvm", "-pragma-unroll-threshold=1000000", "-Wpass-failed"]
 
 FIELD_HDRS = ["field.cuh", "fieldu.cuh", "curve_params.h", "zk_common.h"]
 HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ecu.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]

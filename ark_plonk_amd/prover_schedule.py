@@ -75,7 +75,14 @@ class ProofSchedule:
             part = self.ck.msm_partial(sc, 0)
         else:
             part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)   # Z = 0: infinity
-        mine = torch.from_numpy(part.view(np.int64)).to(coeffs.device)
+        return self._gather_sum(part, coeffs.device)
+
+    def _gather_sum(self, part, device):
+        """all-gather the 3L-limb Jacobian partials (144 B per rank) and add them up on the host"""
+        torch = self.torch
+        mine = torch.from_numpy(part.view(np.int64))
+        if self.dist.get_backend() == "nccl":
+            mine = mine.to(device)
         gathered = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(gathered, mine)
         allp = torch.stack(gathered).cpu().numpy().view(np.uint64)
@@ -92,11 +99,7 @@ class ProofSchedule:
             part = self.ck.msm_partial(w[lo:hi], 0)
         else:
             part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)
-        torch = self.torch
-        mine = torch.from_numpy(part.view(np.int64)).to(w.device)
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(gathered, mine)
-        return sum_partials(torch.stack(gathered).cpu().numpy().view(np.uint64), self.cv.curve_id)
+        return self._gather_sum(part, w.device)
 
     def run_once(self):
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""

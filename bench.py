@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
+    ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     args = ap.parse_args()
 
     import torch
@@ -105,9 +107,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % n_dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % n_dev))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world:
@@ -137,8 +143,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pts = None
     for _ in range(args.warmup):
-        sched.run_once()
+        pts = sched.run_once()
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
@@ -189,6 +196,12 @@ def main():
         "ntt_GBps": (sched.ntt_bytes() * steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
         "ntt_ms_per_proof": ntt_ms / steps,
     }
+    if args.check:
+        import hashlib
+        if pts is None:
+            pts = sched.run_once()
+        h = hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in pts)).hexdigest()
+        line["commitments_sha256"] = h
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

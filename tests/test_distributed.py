@@ -111,3 +111,25 @@ def test_sharded_msm_two_ranks_one_gpu():
     g = np.load(os.path.join(ROOT, "tests", "golden", "bls12_381.npz"))
     for rank, xy, inf in res:
         assert not inf and np.array_equal(np.array(xy, dtype=np.uint64), g["msm_srs_1024_out"]), f"rank {rank}"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_matches_one_rank():
+    """bench.py's N > 1 path (point-sharded MSMs + all-gather, replicated NTTs) on one card with gloo:
+    the 29 commitments must equal the single-rank run's, bit for bit."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = [os.path.join(ROOT, "bench.py"), "--log-n", "15", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--check"]
+    one = subprocess.run([sys.executable] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    port = _free_port()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port)] + common + ["--gpus", "2", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    assert d1["commitments_sha256"] == d2["commitments_sha256"]

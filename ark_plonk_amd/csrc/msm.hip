@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     }
 }
 
-constexpr uint32_t COMBINE_SMALL = 8;      // buckets spanning <= this many chunks: summed by one lane
+constexpr uint32_t COMBINE_SMALL = 32;     // buckets spanning <= this many chunks: summed by one lane
 constexpr uint32_t COMBINE_MEDIUM = 2048;  // <= this many: one wavefront per bucket; above: one workgroup
 
 ZK_D uint64_t partial_slot(uint32_t t, uint32_t ta, uint32_t s, uint32_t L) {
@@ -662,8 +662,8 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
         unsigned blocks = (g.nb + T - 1) / T;
         hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(256), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
                            c->msm_buckets.p, q);
         unsigned sblocks = (g.W * g.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
@@ -841,8 +841,8 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
         ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
         unsigned blocks = (g1.nb + T - 1) / T;
         hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(1024), dim3(256), 0, st, c->msm_part_pt.p, offsets, chunk_l, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(256), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l,
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, c->msm_part_pt.p, offsets, chunk_l, c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l,
                            c->msm_buckets.p, q);
         unsigned sblocks = (gv.W * gv.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, gv, seg_run, seg_acc);

@@ -13,7 +13,8 @@ void zk_note_hip_error(hipError_t e, const char* what, const char* file, int lin
 }
 
 // ------------------------------------------------------------------------------------- profiling
-ProfScope::ProfScope(zk_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+ProfScope::ProfScope(zk_ctx* ctx, const char* nm) : ProfScope(ctx, nm, ctx->stream) {}
+ProfScope::ProfScope(zk_ctx* ctx, const char* nm, hipStream_t stream) : c(ctx), name(nm), st(stream) {
     if (!c->profiling) return;
     auto take = [&]() -> hipEvent_t {
         if (!c->event_pool.empty()) {
@@ -27,11 +28,11 @@ ProfScope::ProfScope(zk_ctx* ctx, const char* nm) : c(ctx), name(nm) {
     };
     a = take();
     b = take();
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->prof[name].pending.emplace_back(a, b);
 }
 void zk_prof_collect(zk_ctx* c) {
@@ -140,7 +141,12 @@ int zk_ctx_create(int device, zk_ctx** out) {
         return ZK_ERR_HIP;
     }
     c->stream = c->own_stream;
+    for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
     (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        zk_ctx_destroy(c);
+        return ZK_ERR_HIP;
+    }
     *out = c;
     return ZK_OK;
 }
@@ -153,9 +159,11 @@ void zk_ctx_destroy(zk_ctx* c) {
         zk_prof_collect(c);
         for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
         ntt_ctx_free(c);
-        DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_counts, &c->msm_offsets, &c->msm_entries, &c->msm_buckets, &c->msm_part_pt,
-                          &c->msm_part_key, &c->msm_seg, &c->msm_win, &c->msm_scalars, &c->msm_tmp};
+        DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_tmp};
         for (DevBuf* b : bufs) b->release();
+        c->mb[0].release();
+        for (int i = 0; i < 16; ++i)
+            if (c->ev_job[i]) (void)hipEventDestroy(c->ev_job[i]);
         if (c->pinned) (void)hipHostFree(c->pinned);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
@@ -395,11 +403,11 @@ int zk_msm_g1_srs(zk_ctx* c, zk_srs* s, size_t base_offset, const uint64_t* scal
     if (!c || !s || s->ctx != c || !out_xy || (n && !scalars)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     {
-        int rc = c->msm_scalars.ensure((n ? n : 1) * 32);
+        int rc = c->mb[0].scalars.ensure((n ? n : 1) * 32);
         if (rc) return rc;
-        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->msm_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->mb[0].scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     }
-    return zk_msm_g1_srs_dev(c, s, base_offset, c->msm_scalars.p, n, out_xy, out_inf);
+    return zk_msm_g1_srs_dev(c, s, base_offset, c->mb[0].scalars.p, n, out_xy, out_inf);
 }
 
 int zk_msm_g1(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, const uint64_t* scalars, size_t n,
@@ -425,12 +433,40 @@ int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n,
     if (n > s->n) return ZK_ERR_BAD_ARG;
     Guard g(c);
     {
-        int rc = c->msm_scalars.ensure((n ? n : 1) * 32);
+        int rc = c->mb[0].scalars.ensure((n ? n : 1) * 32);
         if (rc) return rc;
-        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont, n, c->msm_scalars.p);
+        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont, n, c->mb[0].scalars.p);
         if (rc) return rc;
     }
-    return zk_msm_g1_srs_dev(c, s, 0, c->msm_scalars.p, n, out_xy, out_inf);
+    return zk_msm_g1_srs_dev(c, s, 0, c->mb[0].scalars.p, n, out_xy, out_inf);
+}
+
+int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
+                            uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
+    if (n_polys > 16) return ZK_ERR_BAD_ARG;
+    const int L = fq_limbs64(s->curve);
+    bool pipelined = s->pre_W != 0 && c->msm_window == 0;
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if (lens[k] > s->n || (lens[k] && !d_coeffs_mont[k])) return ZK_ERR_BAD_ARG;
+        if (lens[k] < ZK_PRE_MIN_N) pipelined = false;
+    }
+    if (!pipelined) {   // no table or tiny polynomials: one at a time
+        for (uint32_t k = 0; k < n_polys; ++k) {
+            int rc = zk_kzg_commit_dev(c, s, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+            if (rc) return rc;
+        }
+        return ZK_OK;
+    }
+    Guard g(c);
+    uint64_t xyz[16 * 18];
+    int rc = msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        rc = finish_point(s->curve, xyz + (size_t)k * 3 * L, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+        if (rc) return rc;
+    }
+    return ZK_OK;
 }
 
 int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {

@@ -74,6 +74,14 @@ struct DevBuf {
     }
 };
 
+struct MsmBufs {
+    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars;
+    void release() {
+        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
 struct ProfEntry {
     double total_ms = 0;
     uint64_t launches = 0;
@@ -115,11 +123,12 @@ struct zk_ctx {
     size_t coset_inv_len[2] = {0, 0};
     DevBuf io_a, io_b;                           // staging for the host-buffer entry points
 
-    // MSM state
-    DevBuf msm_counts, msm_offsets, msm_entries, msm_buckets, msm_part_pt, msm_part_key;
-    DevBuf msm_seg, msm_win, msm_scalars, msm_tmp;
-    void* pinned = nullptr;
+    // MSM state (mb[0] is the working set; a batch queues its jobs back to back on the ctx stream)
+    MsmBufs mb[1];
+    hipEvent_t ev_job[16] = {};
+    void* pinned = nullptr;      // virtual-window sums of up to 16 batched MSMs land here
     size_t pinned_cap = 0;
+    DevBuf msm_tmp;       // infinity flags staging (SRS registration)
 };
 
 struct zk_srs {
@@ -140,7 +149,9 @@ struct ProfScope {
     zk_ctx* c;
     const char* name;
     hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st = nullptr;
     ProfScope(zk_ctx* ctx, const char* nm);
+    ProfScope(zk_ctx* ctx, const char* nm, hipStream_t stream);
     ~ProfScope();
 };
 void zk_prof_collect(zk_ctx* c);
@@ -159,6 +170,9 @@ int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, vo
 // window-multiples table of an SRS (see zk_srs::d_pre) and the MSM that uses it
 int msm_precompute_dev(zk_ctx* c, zk_srs* s);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
+// a batch of commitments over one SRS, queued back to back; the host blocks once per result
+int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz);
+int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
 int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal);

@@ -145,7 +145,7 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     int rc;
     if ((rc = c->io_a.ensure(m * 32))) return rc;                       // comb
     if ((rc = c->io_b.ensure(n_chunks * 32 * 2))) return rc;            // H | A
-    if ((rc = c->msm_scalars.ensure(m * 32))) return rc;                // witness, canonical
+    if ((rc = c->mb[0].scalars.ensure(m * 32))) return rc;                // witness, canonical
     void* comb = c->io_a.p;
     void* H = c->io_b.p;
     void* A = (char*)c->io_b.p + n_chunks * 32;
@@ -158,9 +158,9 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     size_t shmem = (size_t)SCAN_T * 2 * 32;
     ZK_HIP_TRY(hipFuncSetAttribute((const void*)kzg_chunk_scan<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kzg_chunk_scan<Fr>, dim3(1), dim3(SCAN_T), shmem, st, H, n_chunks, zk, A);
-    hipLaunchKernelGGL(kzg_witness<Fr>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, z, A, c->msm_scalars.p, n_chunks);
+    hipLaunchKernelGGL(kzg_witness<Fr>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, z, A, c->mb[0].scalars.p, n_chunks);
     ZK_HIP_TRY(hipGetLastError());
-    *d_w = c->msm_scalars.p;
+    *d_w = c->mb[0].scalars.p;
     return ZK_OK;
 }
 

@@ -606,27 +606,28 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
     if (e_max >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;
     const uint32_t n_lanes = (uint32_t)((e_max + CHUNK_L - 1) / CHUNK_L);
     int rc;
+    MsmBufs& mb = c->mb[0];
     // slabs of scalars per window: enough workgroups to fill the chip, each with >= ~8K scalars
     uint32_t S = 1;
     while (S < 32 && (uint64_t)S * 16384 < n && (uint64_t)(2 * S) * g.W <= 1024) S <<= 1;
     const unsigned nblk_scan = (g.nb + 1023) / 1024;
     if (nblk_scan > 1024) return ZK_ERR_UNSUPPORTED;
-    if ((rc = c->msm_counts.ensure((size_t)g.W * S * g.B * 4 + 4096))) return rc;       // hist / cursors + block sums
-    if ((rc = c->msm_offsets.ensure((size_t)(g.nb + 1) * 4))) return rc;
-    if ((rc = c->msm_tmp.ensure((size_t)g.W * n * 2))) return rc;                       // int16 digits, window-major
-    if ((rc = c->msm_entries.ensure((size_t)e_max * 4))) return rc;
-    if ((rc = c->msm_buckets.ensure((size_t)g.nb * PT))) return rc;
-    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
-    if ((rc = c->msm_part_key.ensure((size_t)(g.nb + 2) * 4))) return rc;   // combine queues: [n_medium, n_large, ids...]
-    if ((rc = c->msm_seg.ensure((size_t)g.W * g.ns * 2 * PT))) return rc;
-    if ((rc = c->msm_win.ensure((size_t)g.W * sizeof(PH)))) return rc;
-    uint32_t* hist = (uint32_t*)c->msm_counts.p;
+    if ((rc = mb.counts.ensure((size_t)g.W * S * g.B * 4 + 4096))) return rc;       // hist / cursors + block sums
+    if ((rc = mb.offsets.ensure((size_t)(g.nb + 1) * 4))) return rc;
+    if ((rc = mb.tmp.ensure((size_t)g.W * n * 2))) return rc;                       // int16 digits, window-major
+    if ((rc = mb.entries.ensure((size_t)e_max * 4))) return rc;
+    if ((rc = mb.buckets.ensure((size_t)g.nb * PT))) return rc;
+    if ((rc = mb.part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
+    if ((rc = mb.part_key.ensure((size_t)(g.nb + 2) * 4))) return rc;   // combine queues: [n_medium, n_large, ids...]
+    if ((rc = mb.seg.ensure((size_t)g.W * g.ns * 2 * PT))) return rc;
+    if ((rc = mb.win.ensure((size_t)g.W * sizeof(PH)))) return rc;
+    uint32_t* hist = (uint32_t*)mb.counts.p;
     uint32_t* bsum = hist + (size_t)g.W * S * g.B;
-    uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
-    int16_t* dig = (int16_t*)c->msm_tmp.p;
-    uint32_t* entries = (uint32_t*)c->msm_entries.p;
-    void* seg_run = c->msm_seg.p;
-    void* seg_acc = (char*)c->msm_seg.p + (size_t)g.W * g.ns * PT;
+    uint32_t* offsets = (uint32_t*)mb.offsets.p;
+    int16_t* dig = (int16_t*)mb.tmp.p;
+    uint32_t* entries = (uint32_t*)mb.entries.p;
+    void* seg_run = mb.seg.p;
+    void* seg_acc = (char*)mb.seg.p + (size_t)g.W * g.ns * PT;
     hipStream_t st = c->stream;
 
     {
@@ -651,32 +652,32 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         ProfScope ps(c, "msm_accumulate");
         const int T = 128;
         unsigned blocks = (n_lanes + T - 1) / T;
-        hipLaunchKernelGGL((msm_accumulate<F, false>), dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, c->msm_buckets.p,
-                           c->msm_part_pt.p, CHUNK_L, n_lanes, (uint64_t)0, (uint64_t)0);
+        hipLaunchKernelGGL((msm_accumulate<F, false>), dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, mb.buckets.p,
+                           mb.part_pt.p, CHUNK_L, n_lanes, (uint64_t)0, (uint64_t)0);
         ZK_HIP_TRY(hipGetLastError());
     }
     {
         ProfScope ps(c, "msm_reduce");
         const int T = 128;
-        uint32_t* q = (uint32_t*)c->msm_part_key.p;
+        uint32_t* q = (uint32_t*)mb.part_key.p;
         ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
         unsigned blocks = (g.nb + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, c->msm_part_pt.p, offsets, CHUNK_L, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g.nb, CHUNK_L,
-                           c->msm_buckets.p, q);
+        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, mb.part_pt.p, offsets, g.nb, CHUNK_L, mb.buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, mb.part_pt.p, offsets, CHUNK_L, mb.buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, mb.part_pt.p, offsets, g.nb, CHUNK_L,
+                           mb.buckets.p, q);
         unsigned sblocks = (g.W * g.ns + T - 1) / T;
-        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, g, seg_run, seg_acc);
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, mb.buckets.p, offsets, g, seg_run, seg_acc);
         size_t shmem = 256 * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)c->msm_win.p,
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)mb.win.p,
                            (uint32_t*)nullptr);
         ZK_HIP_TRY(hipGetLastError());
     }
     // window sums -> host, Horner (high window first), Jacobian out
     std::vector<PH> win(g.W);
-    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)g.W * sizeof(PH), hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipMemcpyAsync(win.data(), mb.win.p, (size_t)g.W * sizeof(PH), hipMemcpyDeviceToHost, st));
     ZK_HIP_TRY(hipStreamSynchronize(st));
     PH total = PH::infinity();
     for (int w = (int)g.W - 1; w >= 0; --w) {
@@ -756,113 +757,143 @@ int msm_precompute_run(zk_ctx* c, zk_srs* s) {
     return ZK_OK;
 }
 
-// MSM over a precomputed SRS: every (scalar, window) digit is a reference to table[w][i] and all
-// windows share one set of 2^(c-1) buckets.
+// ---- MSM over a precomputed SRS -------------------------------------------------------------------
+// Every (scalar, window) digit is a reference to table[w][i]; all windows share one set of 2^(c-1)
+// buckets.  The work of one MSM is queued in two pieces so that a batch can pipeline them:
+//   sort   (digits, LDS counting sort)        -- light kernels, few VGPRs: they co-reside with the
+//                                                 accumulate waves of the PREVIOUS MSM (aux stream)
+//   heavy  (accumulate, combine, reduction, read-back of the virtual-window sums)   (main stream)
+struct PrePlan {
+    MsmGeom g, g1, gv;
+    uint64_t nf;
+    uint32_t chunk_l, n_lanes, S;
+    size_t win_bytes;
+};
+
 template <class Cv>
-int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     typedef typename Cv::Fq Fq;
     typedef typename Cv::FqU F;
     typedef XYZZ<Fq> PH;
-    constexpr int L64 = Fq::N / 2;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
-    MsmGeom g = make_geom<typename Cv::FrP>(n, (int)s->pre_c);
-    if (g.W != s->pre_W || g.W > 32) return ZK_ERR_UNSUPPORTED;
-    const uint64_t nf = (uint64_t)n * g.W;              // flattened (window, scalar) digits
-    if (nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
-    MsmGeom g1 = g;                                      // the sort sees ONE window of nf digits
-    g1.W = 1;
-    g1.nb = g.B;
-    MsmGeom gv = g;                                      // the reduction sees PRE_VW virtual windows
-    gv.W = PRE_VW;
-    gv.B = g.B / PRE_VW;
-    gv.nb = g.B;
-    gv.logG = 2;
-    gv.ns = gv.B >> gv.logG;
-    gv.logq = 0;
-    while ((256u << gv.logq) < gv.ns) ++gv.logq;
+    pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c);
+    if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
+    pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
+    if (pl.nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+    pl.g1 = pl.g;                                       // the sort sees ONE window of nf digits
+    pl.g1.W = 1;
+    pl.g1.nb = pl.g.B;
+    pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows
+    pl.gv.W = PRE_VW;
+    pl.gv.B = pl.g.B / PRE_VW;
+    pl.gv.nb = pl.g.B;
+    pl.gv.logG = 2;
+    pl.gv.ns = pl.gv.B >> pl.gv.logG;
+    pl.gv.logq = 0;
+    while ((256u << pl.gv.logq) < pl.gv.ns) ++pl.gv.logq;
     // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 waves
     // of lanes per SIMD on the 256-CU chip (the kernel holds 2 waves/SIMD at its VGPR count)
-    uint32_t chunk_l = PRE_CHUNK_L;
-    while (chunk_l > 16 && nf / chunk_l < 131072) chunk_l >>= 1;
-    const uint32_t n_lanes = (uint32_t)((nf + chunk_l - 1) / chunk_l);
-    uint32_t S = 1;
-    while (S < 128 && (uint64_t)S * 32768 < nf) S <<= 1;
+    pl.chunk_l = PRE_CHUNK_L;
+    while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 131072) pl.chunk_l >>= 1;
+    pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
+    pl.S = 1;
+    while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;
+    pl.win_bytes = (size_t)2 * pl.gv.W * sizeof(PH);
     int rc;
-    if ((rc = c->msm_counts.ensure((size_t)S * g.B * 4 + 4096))) return rc;
-    if ((rc = c->msm_offsets.ensure((size_t)(g.B + 1) * 4))) return rc;
-    if ((rc = c->msm_tmp.ensure((size_t)nf * 2))) return rc;
-    if ((rc = c->msm_entries.ensure((size_t)nf * 4))) return rc;
-    if ((rc = c->msm_buckets.ensure((size_t)g.B * PT))) return rc;
-    if ((rc = c->msm_part_pt.ensure((size_t)n_lanes * 2 * PT))) return rc;
-    if ((rc = c->msm_part_key.ensure((size_t)(g.B + 2) * 4))) return rc;
-    if ((rc = c->msm_seg.ensure((size_t)gv.W * gv.ns * 2 * PT))) return rc;
-    if ((rc = c->msm_win.ensure((size_t)2 * gv.W * sizeof(PH)))) return rc;
-    uint32_t* hist = (uint32_t*)c->msm_counts.p;
-    uint32_t* bsum = hist + (size_t)S * g.B;
-    uint32_t* offsets = (uint32_t*)c->msm_offsets.p;
-    int16_t* dig = (int16_t*)c->msm_tmp.p;
-    uint32_t* entries = (uint32_t*)c->msm_entries.p;
-    void* seg_run = c->msm_seg.p;
-    void* seg_acc = (char*)c->msm_seg.p + (size_t)gv.W * gv.ns * PT;
-    uint32_t* win_s = (uint32_t*)c->msm_win.p;
-    uint32_t* win_t = win_s + (size_t)gv.W * 4 * F::SAT;
-    hipStream_t st = c->stream;
-    {
-        ProfScope ps(c, "msm_sort");
-        const int T = 256;
-        unsigned blocks = (unsigned)((n + T - 1) / T);
-        hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, g, dig);
-        size_t lds = (size_t)g.B * 4;
-        if (lds > 48 * 1024) {
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        hipLaunchKernelGGL(msm_hist, dim3(S, 1), dim3(1024), lds, st, dig, nf, g1, S, hist);
-        const unsigned nblk = (g1.nb + 1023) / 1024;
-        hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, g1, S, bsum);
-        hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
-        hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, g1, S, bsum, offsets);
-        hipLaunchKernelGGL(msm_scatter, dim3(S, 1), dim3(1024), lds, st, dig, nf, g1, S, hist, entries, (uint32_t)n);
+    if ((rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
+    if ((rc = mb.offsets.ensure((size_t)(pl.g.B + 1) * 4))) return rc;
+    if ((rc = mb.tmp.ensure((size_t)pl.nf * 2))) return rc;
+    if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
+    if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
+    if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
+    if ((rc = mb.part_key.ensure((size_t)(pl.g.B + 2) * 4))) return rc;
+    if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
+    if ((rc = mb.win.ensure(pl.win_bytes))) return rc;
+    return ZK_OK;
+}
+
+template <class Cv>
+int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scalars, size_t n, hipStream_t st) {
+    uint32_t* hist = (uint32_t*)mb.counts.p;
+    uint32_t* bsum = hist + (size_t)pl.S * pl.g.B;
+    uint32_t* offsets = (uint32_t*)mb.offsets.p;
+    int16_t* dig = (int16_t*)mb.tmp.p;
+    uint32_t* entries = (uint32_t*)mb.entries.p;
+    ProfScope ps(c, "msm_sort", st);
+    const int T = 256;
+    unsigned blocks = (unsigned)((n + T - 1) / T);
+    hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+    size_t lds = (size_t)pl.g.B * 4;
+    if (lds > 48 * 1024) {
+        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(msm_hist, dim3(pl.S, 1), dim3(1024), lds, st, dig, pl.nf, pl.g1, pl.S, hist);
+    const unsigned nblk = (pl.g1.nb + 1023) / 1024;
+    hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, pl.g1, pl.S, bsum);
+    hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
+    hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, pl.g1, pl.S, bsum, offsets);
+    hipLaunchKernelGGL(msm_scatter, dim3(pl.S, 1), dim3(1024), lds, st, dig, pl.nf, pl.g1, pl.S, hist, entries, (uint32_t)n);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class Cv>
+int pre_queue_heavy(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, size_t base_offset, void* h_win, hipStream_t st, int part = 3) {
+    typedef typename Cv::FqU F;
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    uint32_t* offsets = (uint32_t*)mb.offsets.p;
+    uint32_t* entries = (uint32_t*)mb.entries.p;
+    void* seg_run = mb.seg.p;
+    void* seg_acc = (char*)mb.seg.p + (size_t)pl.gv.W * pl.gv.ns * PT;
+    uint32_t* win_s = (uint32_t*)mb.win.p;
+    uint32_t* win_t = win_s + (size_t)pl.gv.W * 4 * F::SAT;
+    if (part & 1) {
+        ProfScope ps(c, "msm_accumulate", st);
+        const int T = 128;
+        unsigned blocks = (pl.n_lanes + T - 1) / T;
+        hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, entries, offsets, pl.g1.nb, s->d_xy, mb.buckets.p,
+                           mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
         ZK_HIP_TRY(hipGetLastError());
     }
+    if (!(part & 2)) return ZK_OK;
     {
-        ProfScope ps(c, "msm_accumulate");
+        ProfScope ps(c, "msm_reduce", st);
         const int T = 128;
-        unsigned blocks = (n_lanes + T - 1) / T;
-        hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, entries, offsets, g1.nb, s->d_xy, c->msm_buckets.p,
-                           c->msm_part_pt.p, chunk_l, n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
-        ZK_HIP_TRY(hipGetLastError());
-    }
-    {
-        ProfScope ps(c, "msm_reduce");
-        const int T = 128;
-        uint32_t* q = (uint32_t*)c->msm_part_key.p;
+        uint32_t* q = (uint32_t*)mb.part_key.p;
         ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
-        unsigned blocks = (g1.nb + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, c->msm_part_pt.p, offsets, chunk_l, c->msm_buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, c->msm_part_pt.p, offsets, g1.nb, chunk_l,
-                           c->msm_buckets.p, q);
-        unsigned sblocks = (gv.W * gv.ns + T - 1) / T;
-        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, c->msm_buckets.p, offsets, gv, seg_run, seg_acc);
+        unsigned blocks = (pl.g1.nb + T - 1) / T;
+        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, mb.part_pt.p, offsets, pl.g1.nb, pl.chunk_l, mb.buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, mb.part_pt.p, offsets, pl.chunk_l, mb.buckets.p, q);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, mb.part_pt.p, offsets, pl.g1.nb, pl.chunk_l,
+                           mb.buckets.p, q);
+        unsigned sblocks = (pl.gv.W * pl.gv.ns + T - 1) / T;
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, mb.buckets.p, offsets, pl.gv, seg_run, seg_acc);
         size_t shmem = 256 * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<F>, dim3(gv.W), dim3(256), shmem, st, seg_run, seg_acc, gv, win_s, win_t);
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(pl.gv.W), dim3(256), shmem, st, seg_run, seg_acc, pl.gv, win_s, win_t);
         ZK_HIP_TRY(hipGetLastError());
     }
-    std::vector<PH> win(2 * gv.W);
-    ZK_HIP_TRY(hipMemcpyAsync(win.data(), c->msm_win.p, (size_t)2 * gv.W * sizeof(PH), hipMemcpyDeviceToHost, st));
-    ZK_HIP_TRY(hipStreamSynchronize(st));
-    // S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index)
+    ZK_HIP_TRY(hipMemcpyAsync(h_win, mb.win.p, pl.win_bytes, hipMemcpyDeviceToHost, st));
+    return ZK_OK;
+}
+
+// host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index)
+template <class Cv>
+void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
+    typedef typename Cv::Fq Fq;
+    typedef XYZZ<Fq> PH;
+    constexpr int L64 = Fq::N / 2;
+    const PH* win = (const PH*)h_win;
     PH total = PH::infinity(), run = PH::infinity(), wsum = PH::infinity();
-    for (int v = (int)gv.W - 1; v >= 1; --v) {
-        run = PH::add(run, win[gv.W + v]);
+    for (int v = (int)VW - 1; v >= 1; --v) {
+        run = PH::add(run, win[VW + v]);
         wsum = PH::add(wsum, run);
     }
-    for (uint32_t k = 0; (1u << k) < gv.B; ++k) wsum = PH::dbl(wsum);
-    for (uint32_t v = 0; v < gv.W; ++v) total = PH::add(total, win[v]);
+    for (uint32_t k = 0; (1u << k) < VB; ++k) wsum = PH::dbl(wsum);
+    for (uint32_t v = 0; v < VW; ++v) total = PH::add(total, win[v]);
     total = PH::add(total, wsum);
     Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
     if (!total.is_inf()) {
@@ -873,6 +904,65 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
     memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
     memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
+}
+
+int ensure_pinned(zk_ctx* c, size_t bytes) {
+    if (c->pinned_cap >= bytes) return ZK_OK;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    if (hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault) != hipSuccess) return ZK_ERR_OOM;
+    c->pinned_cap = bytes;
+    return ZK_OK;
+}
+
+// one MSM, everything on the main stream
+template <class Cv>
+int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    MsmBufs& mb = c->mb[0];
+    PrePlan pl;
+    int rc = pre_plan<Cv>(c, s, n, mb, pl);
+    if (rc) return rc;
+    if ((rc = ensure_pinned(c, pl.win_bytes * 16))) return rc;
+    if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_scalars, n, c->stream))) return rc;
+    if ((rc = pre_queue_heavy<Cv>(c, pl, mb, s, base_offset, c->pinned, c->stream))) return rc;
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
+    return ZK_OK;
+}
+
+// A batch of commitments over the same SRS (the polynomials of one prover round): Montgomery
+// coefficients in, Jacobian results out.
+template <class Cv>
+int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */) {
+    typedef typename Cv::Fq Fq;
+    constexpr int L64 = Fq::N / 2;
+    if (n_polys == 0) return ZK_OK;
+    if (n_polys > 16) return ZK_ERR_UNSUPPORTED;
+    int rc;
+    PrePlan pl[16];
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[0], pl[k]))) return rc;
+        if ((rc = c->mb[0].scalars.ensure(lens[k] * 32))) return rc;
+    }
+    const size_t wb = pl[0].win_bytes;
+    if ((rc = ensure_pinned(c, wb * 16))) return rc;
+    hipStream_t st = c->stream;
+    // All jobs are queued back to back on the main stream (one buffer set suffices: stream order) and
+    // the host only blocks to collect each job's virtual-window sums.  Running the sort or the bucket
+    // reduction of a neighbouring job on a second stream was measured (profiles/r01_notes.md) to slow
+    // msm_accumulate by more than it hides, so there is deliberately no cross-stream overlap here.
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        MsmBufs& mb = c->mb[0];
+        if ((rc = fr_convert_stream(c, s->curve, d_coeffs[k], lens[k], mb.scalars.p, st))) return rc;
+        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, mb.scalars.p, lens[k], st))) return rc;
+        if ((rc = pre_queue_heavy<Cv>(c, pl[k], mb, s, 0, (char*)c->pinned + (size_t)k * wb, st, 3))) return rc;
+        ZK_HIP_TRY(hipEventRecord(c->ev_job[k], st));
+    }
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        ZK_HIP_TRY(hipEventSynchronize(c->ev_job[k]));
+        pre_host_combine<Cv>((char*)c->pinned + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, out_xyz + (size_t)k * 3 * L64);
+    }
     return ZK_OK;
 }
 
@@ -974,6 +1064,9 @@ int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s) { return msm_precompute_run
 
 int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
+}
+int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz) {
+    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

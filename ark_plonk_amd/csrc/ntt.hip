@@ -380,18 +380,26 @@ void ntt_ctx_free(zk_ctx* c) {
     }
 }
 
-int fr_convert_dev(zk_ctx* c, int curve, int to_mont, const void* d_in, size_t n, void* d_out) {
+static int fr_convert_on(int curve, int to_mont, const void* d_in, size_t n, void* d_out, hipStream_t st) {
     if (n == 0) return ZK_OK;
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
     if (curve == ZK_CURVE_BLS12_381)
-        hipLaunchKernelGGL(fr_convert_kernel<FrBls>, dim3(blocks), dim3(T), 0, c->stream, d_in, d_out, (uint64_t)n, to_mont);
+        hipLaunchKernelGGL(fr_convert_kernel<FrBls>, dim3(blocks), dim3(T), 0, st, d_in, d_out, (uint64_t)n, to_mont);
     else if (curve == ZK_CURVE_BN254)
-        hipLaunchKernelGGL(fr_convert_kernel<FrBn>, dim3(blocks), dim3(T), 0, c->stream, d_in, d_out, (uint64_t)n, to_mont);
+        hipLaunchKernelGGL(fr_convert_kernel<FrBn>, dim3(blocks), dim3(T), 0, st, d_in, d_out, (uint64_t)n, to_mont);
     else
         return ZK_ERR_BAD_ARG;
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
+}
+int fr_convert_dev(zk_ctx* c, int curve, int to_mont, const void* d_in, size_t n, void* d_out) {
+    return fr_convert_on(curve, to_mont, d_in, n, d_out, c->stream);
+}
+// Montgomery -> canonical (into_repr) on a chosen stream
+int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st) {
+    (void)c;
+    return fr_convert_on(curve, 0, d_in, n, d_out, st);
 }
 
 int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, void* out) {

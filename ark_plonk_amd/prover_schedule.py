@@ -88,6 +88,13 @@ class ProofSchedule:
         allp = torch.stack(gathered).cpu().numpy().view(np.uint64)
         return sum_partials(allp, self.cv.curve_id)
 
+    # -- the commitments of one prover round: submitted back to back, collected together (the
+    #    transcript needs them only at the end of the round)
+    def _commit_round(self, polys):
+        if self.world > 1:
+            return [self._commit(p) for p in polys]
+        return self.ck.commit_batch(list(polys))
+
     # -- one opening = RLC + witness (replicated per rank) + MSM of n-1 (sharded like a commit)
     def _open(self, polys):
         if self.world == 1:
@@ -109,16 +116,14 @@ class ProofSchedule:
         # Round 1: 4 ifft + 4 commits (prover.rs:196-203, 213)
         for i in range(4):
             c[i] = d.ifft(self.evals[i])
-        for i in range(4):
-            out.append(self._commit(c[i]))
+        out += self._commit_round(c[:4])
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         c[4] = d.ifft(self.aux_evals[0])          # table_poly
         c[5] = d.ifft(self.aux_evals[1])          # f_poly
         out.append(self._commit(c[5]))
         c[6] = d.ifft(self.aux_evals[2])          # h1
         c[7] = d.ifft(self.aux_evals[3])          # h2
-        out.append(self._commit(c[6]))
-        out.append(self._commit(c[7]))
+        out += self._commit_round([c[6], c[7]])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         for i in range(4):
             d.fft(self.sigma[i])
@@ -134,16 +139,13 @@ class ProofSchedule:
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
         t = d4.coset_ifft(self.quot)              # quotient polynomial, 4n coefficients
-        for i in range(4):                        # t_1..t_4 (prover.rs:455-469)
-            out.append(self._commit(t[i * n:(i + 1) * n]))
+        out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)])   # t_1..t_4 (prover.rs:455-469)
         # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618)
-        for poly in (c[5], c[6], c[7], c[8], c[9], c[4], c[11]):
-            out.append(self._commit(poly))
+        out += self._commit_round([c[5], c[6], c[7], c[8], c[9], c[4], c[11]])
         # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
         out.append(self._open([c[5], c[6], c[7], c[8], c[9], c[4], c[11], c[0], c[1], c[2], c[3]]))
         saw = (c[8], c[0], c[1], c[3], c[6], c[9], c[4])
-        for poly in saw:
-            out.append(self._commit(poly))
+        out += self._commit_round(list(saw))
         out.append(self._open(list(saw)))         # PC::open at z*omega (prover.rs:609-618)
         assert len(out) == 29
         return out

@@ -141,6 +141,14 @@ int zk_g1_sum_partials(int curve_id, const uint64_t* partials_xyz, size_t count,
 int zk_kzg_commit_dev(zk_ctx* ctx, zk_srs* srs, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
 int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
 
+/* The commitments of one prover round (e.g. the 4 wire commits of prover.rs:213, the 7 + 7 of
+ * prover.rs:569-607): n_polys (<= 16) device-resident coefficient vectors over one precomputed SRS.
+ * Results are identical to n_polys calls of zk_kzg_commit_dev; the batch queues all device work back to
+ * back and the host blocks once per result instead of once per call.
+ * out_xy: n_polys x 2L limbs, out_inf: n_polys flags. */
+int zk_kzg_commit_batch_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
+                            uint64_t* out_xy, uint8_t* out_inf);
+
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).
  * polys: n_polys device pointers to Montgomery coefficient vectors of lens[k] elements. */

@@ -275,3 +275,27 @@ def test_kzg_open_vs_cpu_oracle_2_16(ctx, oracle_cpu):
     got2 = ck.open([torch.from_numpy(p.view(np.int64)).cuda() for p in polys], z, chi)
     assert got2 == got
     ck.close()
+
+
+def test_commit_batch_equals_single_commits(ctx):
+    """zk_kzg_commit_batch_dev (pipelined over two buffer sets / two streams) == one commit at a time."""
+    import torch
+    cid, n = 0, 1 << 14
+    cv = bo.CURVES[cid]
+    g = torch.Generator(device="cuda").manual_seed(99)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, ks.data_ptr(), n, bases.data_ptr()))
+    polys = [torch.randint(0, 1 << 62, (ln, 4), dtype=torch.int64, device="cuda", generator=g)
+             for ln in (n, n, n - 1, n, n - 100, n, n)]
+    ck = zk.CommitterKey(bases, cid, ctx)
+    plain = [ck.commit(p) for p in polys]           # per-window path
+    assert ck.commit_batch(polys) == plain           # batch without table falls back to single commits
+    ck.precompute()
+    single = [ck.commit(p) for p in polys]
+    batch = ck.commit_batch(polys)
+    again = ck.commit_batch(polys[:3])
+    ck.close()
+    assert single == plain and batch == plain and again == plain[:3]

@@ -161,7 +161,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         ntt_ctx_free(c);
         DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_tmp};
         for (DevBuf* b : bufs) b->release();
-        c->mb[0].release();
+        for (int i = 0; i < 16; ++i) c->mb[i].release();
         for (int i = 0; i < 16; ++i)
             if (c->ev_job[i]) (void)hipEventDestroy(c->ev_job[i]);
         if (c->pinned) (void)hipHostFree(c->pinned);

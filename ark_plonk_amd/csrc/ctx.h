@@ -123,8 +123,9 @@ struct zk_ctx {
     size_t coset_inv_len[2] = {0, 0};
     DevBuf io_a, io_b;                           // staging for the host-buffer entry points
 
-    // MSM state (mb[0] is the working set; a batch queues its jobs back to back on the ctx stream)
-    MsmBufs mb[1];
+    // MSM state: mb[0] is the working set of a single MSM; a batch (<= 16 jobs) gives every job its own
+    // set so that the jobs' bucket reductions can run as one fused launch
+    MsmBufs mb[16];
     hipEvent_t ev_job[16] = {};
     void* pinned = nullptr;      // virtual-window sums of up to 16 batched MSMs land here
     size_t pinned_cap = 0;

@@ -288,6 +288,21 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     }
 }
 
+// The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by
+// ONE launch of each kernel, so the latency of the dependent-addition chains is paid once per round.
+constexpr int MAX_JOBS = 16;
+struct RJobs {
+    const void* part_pt[MAX_JOBS];
+    const uint32_t* offsets[MAX_JOBS];
+    void* buckets[MAX_JOBS];
+    uint32_t* q[MAX_JOBS];
+    void* seg_run[MAX_JOBS];
+    void* seg_acc[MAX_JOBS];
+    uint32_t* win_s[MAX_JOBS];
+    uint32_t* win_t[MAX_JOBS];
+    uint32_t L[MAX_JOBS];
+};
+
 constexpr uint32_t COMBINE_SMALL = 32;     // buckets spanning <= this many chunks: summed by one lane
 constexpr uint32_t COMBINE_MEDIUM = 2048;  // <= this many: one wavefront per bucket; above: one workgroup
 
@@ -317,8 +332,12 @@ ZK_D XYZZu<F> wave_sum(XYZZu<F> acc) {
 // known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued.
 // queues: q[0] = medium count, q[1] = large count, q[2 ..] medium ids (grow up), q[.. 2+nb) large ids (grow down)
 template <class F>
-__global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L, void* buckets,
-                                                    uint32_t* q) {
+__global__ void __launch_bounds__(128) msm_combine(RJobs jobs, uint32_t nb) {
+    const void* part_pt = jobs.part_pt[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* buckets = jobs.buckets[blockIdx.y];
+    uint32_t* q = jobs.q[blockIdx.y];
+    const uint32_t L = jobs.L[blockIdx.y];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t s = offsets[b], e = offsets[b + 1];
@@ -341,8 +360,12 @@ __global__ void __launch_bounds__(128) msm_combine(const void* part_pt, const ui
 
 // medium buckets: one wavefront per bucket, lanes stride over its partials, shuffle tree
 template <class F>
-__global__ void __launch_bounds__(256) msm_combine_wave(const void* part_pt, const uint32_t* offsets, uint32_t L, void* buckets,
-                                                         const uint32_t* q) {
+__global__ void __launch_bounds__(256) msm_combine_wave(RJobs jobs) {
+    const void* part_pt = jobs.part_pt[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* buckets = jobs.buckets[blockIdx.y];
+    const uint32_t* q = jobs.q[blockIdx.y];
+    const uint32_t L = jobs.L[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -360,9 +383,13 @@ __global__ void __launch_bounds__(256) msm_combine_wave(const void* part_pt, con
 
 // large buckets (heavily skewed scalars): one 256-lane workgroup per bucket
 template <class F>
-__global__ void __launch_bounds__(256) msm_combine_block(const void* part_pt, const uint32_t* offsets, uint32_t nb, uint32_t L,
-                                                          void* buckets, const uint32_t* q) {
+__global__ void __launch_bounds__(256) msm_combine_block(RJobs jobs, uint32_t nb) {
     extern __shared__ uint4 sh[];
+    const void* part_pt = jobs.part_pt[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* buckets = jobs.buckets[blockIdx.y];
+    const uint32_t* q = jobs.q[blockIdx.y];
+    const uint32_t L = jobs.L[blockIdx.y];
     const uint32_t u = threadIdx.x;
     const uint32_t nl = q[1];
     for (uint32_t h = blockIdx.x; h < nl; h += gridDim.x) {
@@ -385,7 +412,11 @@ __global__ void __launch_bounds__(256) msm_combine_block(const void* part_pt, co
 // level 1 of the per-window reduction: segment s of window w covers buckets [s*G, (s+1)*G)
 //   run = sum B_i ; acc = sum (i+1) * B_i   (i local index)
 template <class F>
-__global__ void __launch_bounds__(128) msm_seg_reduce(const void* buckets, const uint32_t* offsets, MsmGeom g, void* seg_run, void* seg_acc) {
+__global__ void __launch_bounds__(128) msm_seg_reduce(RJobs jobs, MsmGeom g) {
+    const void* buckets = jobs.buckets[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* seg_run = jobs.seg_run[blockIdx.y];
+    void* seg_acc = jobs.seg_acc[blockIdx.y];
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= g.W * g.ns) return;
     const uint32_t w = id / g.ns, s = id % g.ns;
@@ -406,9 +437,12 @@ __global__ void __launch_bounds__(128) msm_seg_reduce(const void* buckets, const
 template <class F>
 // tot_out (optional): sum of all buckets of the window, same layout (used when one real window is
 // reduced as several "virtual" windows to shorten the dependent-addition chain).
-__global__ void __launch_bounds__(256) msm_win_finish(const void* seg_run, const void* seg_acc, MsmGeom g, uint32_t* win_out,
-                                                       uint32_t* tot_out) {
+__global__ void __launch_bounds__(256) msm_win_finish(RJobs jobs, MsmGeom g) {
     extern __shared__ uint4 sh[];
+    const void* seg_run = jobs.seg_run[blockIdx.y];
+    const void* seg_acc = jobs.seg_acc[blockIdx.y];
+    uint32_t* win_out = jobs.win_s[blockIdx.y];
+    uint32_t* tot_out = jobs.win_t[blockIdx.y];
     const uint32_t w = blockIdx.x, u = threadIdx.x;
     const uint32_t q = 1u << g.logq;
     typedef XYZZu<F> P;
@@ -534,6 +568,27 @@ __global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, ui
 }
 
 // ---------------------------------------------------------------------------------------- host side
+// combine + segmented reduction of n_jobs MSMs that share the geometry (nb buckets, reduction geometry gr)
+template <class F>
+int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st) {
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    ProfScope ps(c, "msm_reduce", st);
+    const int T = 128;
+    for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
+    unsigned blocks = (nb + T - 1) / T;
+    hipLaunchKernelGGL(msm_combine<F>, dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+    hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);
+    unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
+    hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
+    size_t shmem = 256 * PT;
+    if (shmem > 48 * 1024)
+        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(msm_win_finish<F>, dim3(gr.W, n_jobs), dim3(256), shmem, st, jobs, gr);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 uint32_t ilog2_floor(uint64_t x) {
     uint32_t r = 0;
     while (x >>= 1) ++r;
@@ -657,23 +712,18 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         ZK_HIP_TRY(hipGetLastError());
     }
     {
-        ProfScope ps(c, "msm_reduce");
-        const int T = 128;
-        uint32_t* q = (uint32_t*)mb.part_key.p;
-        ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
-        unsigned blocks = (g.nb + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, mb.part_pt.p, offsets, g.nb, CHUNK_L, mb.buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, mb.part_pt.p, offsets, CHUNK_L, mb.buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, mb.part_pt.p, offsets, g.nb, CHUNK_L,
-                           mb.buckets.p, q);
-        unsigned sblocks = (g.W * g.ns + T - 1) / T;
-        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, mb.buckets.p, offsets, g, seg_run, seg_acc);
-        size_t shmem = 256 * PT;
-        if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<F>, dim3(g.W), dim3(256), shmem, st, seg_run, seg_acc, g, (uint32_t*)mb.win.p,
-                           (uint32_t*)nullptr);
-        ZK_HIP_TRY(hipGetLastError());
+        RJobs jobs;
+        memset(&jobs, 0, sizeof jobs);
+        jobs.part_pt[0] = mb.part_pt.p;
+        jobs.offsets[0] = offsets;
+        jobs.buckets[0] = mb.buckets.p;
+        jobs.q[0] = (uint32_t*)mb.part_key.p;
+        jobs.seg_run[0] = seg_run;
+        jobs.seg_acc[0] = seg_acc;
+        jobs.win_s[0] = (uint32_t*)mb.win.p;
+        jobs.win_t[0] = nullptr;
+        jobs.L[0] = CHUNK_L;
+        if ((rc = queue_reduce<F>(c, jobs, 1, g.nb, g, st))) return rc;
     }
     // window sums -> host, Horner (high window first), Jacobian out
     std::vector<PH> win(g.W);
@@ -840,43 +890,42 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
 }
 
 template <class Cv>
-int pre_queue_heavy(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, size_t base_offset, void* h_win, hipStream_t st, int part = 3) {
+int pre_queue_accumulate(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, size_t base_offset, hipStream_t st) {
+    typedef typename Cv::FqU F;
+    ProfScope ps(c, "msm_accumulate", st);
+    const int T = 128;
+    unsigned blocks = (pl.n_lanes + T - 1) / T;
+    hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, (const uint32_t*)mb.entries.p, (const uint32_t*)mb.offsets.p,
+                       pl.g1.nb, s->d_xy, mb.buckets.p, mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// fused reduction of the jobs mbs[0..n_jobs) (same geometry) + read-back of their virtual-window sums
+// into h_win (n_jobs x win_bytes)
+template <class Cv>
+int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_jobs, void* h_win, hipStream_t st) {
     typedef typename Cv::FqU F;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
-    uint32_t* offsets = (uint32_t*)mb.offsets.p;
-    uint32_t* entries = (uint32_t*)mb.entries.p;
-    void* seg_run = mb.seg.p;
-    void* seg_acc = (char*)mb.seg.p + (size_t)pl.gv.W * pl.gv.ns * PT;
-    uint32_t* win_s = (uint32_t*)mb.win.p;
-    uint32_t* win_t = win_s + (size_t)pl.gv.W * 4 * F::SAT;
-    if (part & 1) {
-        ProfScope ps(c, "msm_accumulate", st);
-        const int T = 128;
-        unsigned blocks = (pl.n_lanes + T - 1) / T;
-        hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, entries, offsets, pl.g1.nb, s->d_xy, mb.buckets.p,
-                           mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
-        ZK_HIP_TRY(hipGetLastError());
+    RJobs jobs;
+    memset(&jobs, 0, sizeof jobs);
+    const PrePlan& p0 = pls[0];
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        MsmBufs& mb = mbs[k];
+        jobs.part_pt[k] = mb.part_pt.p;
+        jobs.offsets[k] = (const uint32_t*)mb.offsets.p;
+        jobs.buckets[k] = mb.buckets.p;
+        jobs.q[k] = (uint32_t*)mb.part_key.p;
+        jobs.seg_run[k] = mb.seg.p;
+        jobs.seg_acc[k] = (char*)mb.seg.p + (size_t)p0.gv.W * p0.gv.ns * PT;
+        jobs.win_s[k] = (uint32_t*)mb.win.p;
+        jobs.win_t[k] = (uint32_t*)mb.win.p + (size_t)p0.gv.W * 4 * F::SAT;
+        jobs.L[k] = pls[k].chunk_l;
     }
-    if (!(part & 2)) return ZK_OK;
-    {
-        ProfScope ps(c, "msm_reduce", st);
-        const int T = 128;
-        uint32_t* q = (uint32_t*)mb.part_key.p;
-        ZK_HIP_TRY(hipMemsetAsync(q, 0, 8, st));
-        unsigned blocks = (pl.g1.nb + T - 1) / T;
-        hipLaunchKernelGGL(msm_combine<F>, dim3(blocks), dim3(T), 0, st, mb.part_pt.p, offsets, pl.g1.nb, pl.chunk_l, mb.buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256), dim3(256), 0, st, mb.part_pt.p, offsets, pl.chunk_l, mb.buckets.p, q);
-        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64), dim3(256), 4 * PT, st, mb.part_pt.p, offsets, pl.g1.nb, pl.chunk_l,
-                           mb.buckets.p, q);
-        unsigned sblocks = (pl.gv.W * pl.gv.ns + T - 1) / T;
-        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks), dim3(T), 0, st, mb.buckets.p, offsets, pl.gv, seg_run, seg_acc);
-        size_t shmem = 256 * PT;
-        if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish<F>, dim3(pl.gv.W), dim3(256), shmem, st, seg_run, seg_acc, pl.gv, win_s, win_t);
-        ZK_HIP_TRY(hipGetLastError());
-    }
-    ZK_HIP_TRY(hipMemcpyAsync(h_win, mb.win.p, pl.win_bytes, hipMemcpyDeviceToHost, st));
+    int rc = queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        ZK_HIP_TRY(hipMemcpyAsync((char*)h_win + (size_t)k * p0.win_bytes, mbs[k].win.p, p0.win_bytes, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
 
@@ -923,46 +972,47 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     PrePlan pl;
     int rc = pre_plan<Cv>(c, s, n, mb, pl);
     if (rc) return rc;
-    if ((rc = ensure_pinned(c, pl.win_bytes * 16))) return rc;
+    if ((rc = ensure_pinned(c, pl.win_bytes * MAX_JOBS))) return rc;
     if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_scalars, n, c->stream))) return rc;
-    if ((rc = pre_queue_heavy<Cv>(c, pl, mb, s, base_offset, c->pinned, c->stream))) return rc;
+    if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, base_offset, c->stream))) return rc;
+    if ((rc = pre_queue_reduce<Cv>(c, &pl, &mb, 1, c->pinned, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
     return ZK_OK;
 }
 
 // A batch of commitments over the same SRS (the polynomials of one prover round): Montgomery
-// coefficients in, Jacobian results out.
+// coefficients in, Jacobian results out.  Every job has its own buffer set; the jobs' sorts and
+// accumulations are queued back to back and their combine / segmented-reduction steps run as ONE
+// launch per kernel (job = blockIdx.y), so the dependent-addition chains of the reduction are paid
+// once per round instead of once per MSM.  Everything stays on the ctx stream: overlapping
+// neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md).
 template <class Cv>
 int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */) {
     typedef typename Cv::Fq Fq;
     constexpr int L64 = Fq::N / 2;
     if (n_polys == 0) return ZK_OK;
-    if (n_polys > 16) return ZK_ERR_UNSUPPORTED;
+    if (n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
-    PrePlan pl[16];
+    PrePlan pl[MAX_JOBS];
     for (uint32_t k = 0; k < n_polys; ++k) {
-        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[0], pl[k]))) return rc;
-        if ((rc = c->mb[0].scalars.ensure(lens[k] * 32))) return rc;
+        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[k], pl[k]))) return rc;
+        if ((rc = c->mb[k].scalars.ensure(lens[k] * 32))) return rc;
+        if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
     }
     const size_t wb = pl[0].win_bytes;
-    if ((rc = ensure_pinned(c, wb * 16))) return rc;
+    if ((rc = ensure_pinned(c, wb * MAX_JOBS))) return rc;
     hipStream_t st = c->stream;
-    // All jobs are queued back to back on the main stream (one buffer set suffices: stream order) and
-    // the host only blocks to collect each job's virtual-window sums.  Running the sort or the bucket
-    // reduction of a neighbouring job on a second stream was measured (profiles/r01_notes.md) to slow
-    // msm_accumulate by more than it hides, so there is deliberately no cross-stream overlap here.
     for (uint32_t k = 0; k < n_polys; ++k) {
-        MsmBufs& mb = c->mb[0];
+        MsmBufs& mb = c->mb[k];
         if ((rc = fr_convert_stream(c, s->curve, d_coeffs[k], lens[k], mb.scalars.p, st))) return rc;
         if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, mb.scalars.p, lens[k], st))) return rc;
-        if ((rc = pre_queue_heavy<Cv>(c, pl[k], mb, s, 0, (char*)c->pinned + (size_t)k * wb, st, 3))) return rc;
-        ZK_HIP_TRY(hipEventRecord(c->ev_job[k], st));
+        if ((rc = pre_queue_accumulate<Cv>(c, pl[k], mb, s, 0, st))) return rc;
     }
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        ZK_HIP_TRY(hipEventSynchronize(c->ev_job[k]));
+    if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;
+    ZK_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t k = 0; k < n_polys; ++k)
         pre_host_combine<Cv>((char*)c->pinned + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, out_xyz + (size_t)k * 3 * L64);
-    }
     return ZK_OK;
 }
 

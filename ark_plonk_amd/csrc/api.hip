@@ -441,6 +441,29 @@ int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n,
     return zk_msm_g1_srs_dev(c, s, 0, c->mb[0].scalars.p, n, out_xy, out_inf);
 }
 
+int zk_kzg_commit_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
+                                    uint64_t* out_xyz) {
+    if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
+    if (n_polys > 16) return ZK_ERR_BAD_ARG;
+    const int L = fq_limbs64(s->curve);
+    bool fused = s->pre_W != 0 && c->msm_window == 0;
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if (lens[k] > s->n || (lens[k] && !d_coeffs_mont[k])) return ZK_ERR_BAD_ARG;
+        if (lens[k] < ZK_PRE_MIN_N) fused = false;
+    }
+    Guard g(c);
+    if (fused) return msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, out_xyz);
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        int rc = c->mb[0].scalars.ensure((lens[k] ? lens[k] : 1) * 32);
+        if (rc) return rc;
+        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont[k], lens[k], c->mb[0].scalars.p);
+        if (rc) return rc;
+        rc = zk_msm_g1_srs_partial_dev(c, s, 0, c->mb[0].scalars.p, lens[k], out_xyz + (size_t)k * 3 * L);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+
 int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                             uint64_t* out_xy, uint8_t* out_inf) {
     if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;

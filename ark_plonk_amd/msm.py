@@ -154,6 +154,21 @@ class CommitterKey:
         check(lib().zk_kzg_commit_batch_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(out), ptr_of(inf)), "zk_kzg_commit_batch_dev")
         return [_point(out[i], inf[i:i + 1], self.curve) for i in range(k)]
 
+    def commit_batch_partial(self, polys) -> np.ndarray:
+        """Sharded form: Jacobian partials (k, 3L) of the given coefficient slices over this rank's SRS shard."""
+        L = self.curve.fq_limbs
+        k = len(polys)
+        ptrs = (ctypes.c_void_p * k)()
+        lens = (ctypes.c_size_t * k)()
+        for i, p in enumerate(polys):
+            lens[i] = check_dev_tensor(p, 4, self.ctx.device)
+            ptrs[i] = p.data_ptr()
+        out = np.zeros((k, 3 * L), dtype=np.uint64)
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_commit_batch_partial_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(out)),
+              "zk_kzg_commit_batch_partial_dev")
+        return out
+
     # -- PC::open(ck, polys, comms, point, opening_challenge, rands, None)
     def open(self, polys, point_mont, challenge_mont) -> G1Affine:
         L = self.curve.fq_limbs

@@ -91,9 +91,24 @@ class ProofSchedule:
     # -- the commitments of one prover round: submitted back to back, collected together (the
     #    transcript needs them only at the end of the round)
     def _commit_round(self, polys):
-        if self.world > 1:
-            return [self._commit(p) for p in polys]
-        return self.ck.commit_batch(list(polys))
+        polys = list(polys)
+        if self.world == 1:
+            return self.ck.commit_batch(polys)
+        # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the round
+        torch = self.torch
+        L3 = 3 * self.cv.fq_limbs
+        slices = [p[self.lo:min(self.hi, p.shape[0])] for p in polys]
+        if all(sl.shape[0] > 0 for sl in slices):
+            parts = self.ck.commit_batch_partial(slices)
+        else:
+            parts = np.stack([self.ck.commit_batch_partial([sl])[0] if sl.shape[0] else np.zeros(L3, dtype=np.uint64) for sl in slices])
+        mine = torch.from_numpy(parts.view(np.int64).reshape(-1))
+        if self.dist.get_backend() == "nccl":
+            mine = mine.to(polys[0].device)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine)
+        allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, len(polys), L3)
+        return [sum_partials(np.ascontiguousarray(allp[:, k, :]), self.cv.curve_id) for k in range(len(polys))]
 
     # -- one opening = RLC + witness (replicated per rank) + MSM of n-1 (sharded like a commit)
     def _open(self, polys):
@@ -120,7 +135,7 @@ class ProofSchedule:
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         c[4] = d.ifft(self.aux_evals[0])          # table_poly
         c[5] = d.ifft(self.aux_evals[1])          # f_poly
-        out.append(self._commit(c[5]))
+        out += self._commit_round([c[5]])
         c[6] = d.ifft(self.aux_evals[2])          # h1
         c[7] = d.ifft(self.aux_evals[3])          # h2
         out += self._commit_round([c[6], c[7]])
@@ -128,9 +143,9 @@ class ProofSchedule:
         for i in range(4):
             d.fft(self.sigma[i])
         c[8] = d.ifft(self.aux_evals[4])          # z
-        out.append(self._commit(c[8]))
+        out += self._commit_round([c[8]])
         c[9] = d.ifft(self.aux_evals[5])          # z2
-        out.append(self._commit(c[9]))
+        out += self._commit_round([c[9]])
         c[10] = d.ifft(self.aux_evals[6])         # pi
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         c[11] = d.ifft(self.aux_evals[7])         # l1

@@ -149,6 +149,11 @@ int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t 
 int zk_kzg_commit_batch_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                             uint64_t* out_xy, uint8_t* out_inf);
 
+/* Multi-GPU form of the batch: this rank's Jacobian partials (n_polys x 3L limbs) over ITS shard of the
+ * SRS, for coefficient slices that already are the rank's [lo, hi) ranges; one all-gather per round. */
+int zk_kzg_commit_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont,
+                                    const size_t* lens, uint64_t* out_xyz);
+
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).
  * polys: n_polys device pointers to Montgomery coefficient vectors of lens[k] elements. */

@@ -74,6 +74,7 @@ SYMBOLS = {
     "zk_kzg_commit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
     "zk_kzg_open_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
                                 c_void_p, c_void_p]),

@@ -466,6 +466,11 @@ int zk_kzg_commit_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, cons
 
 int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                             uint64_t* out_xy, uint8_t* out_inf) {
+    return zk_kzg_round_batch_dev(c, s, n_polys, d_coeffs_mont, lens, nullptr, out_xy, out_inf);
+}
+
+int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
+                           const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf) {
     if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
     if (n_polys > 16) return ZK_ERR_BAD_ARG;
     const int L = fq_limbs64(s->curve);
@@ -476,14 +481,16 @@ int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* 
     }
     if (!pipelined) {   // no table or tiny polynomials: one at a time
         for (uint32_t k = 0; k < n_polys; ++k) {
-            int rc = zk_kzg_commit_dev(c, s, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+            int rc = (kinds && kinds[k])
+                         ? zk_msm_g1_srs_dev(c, s, 0, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr)
+                         : zk_kzg_commit_dev(c, s, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
             if (rc) return rc;
         }
         return ZK_OK;
     }
     Guard g(c);
     uint64_t xyz[16 * 18];
-    int rc = msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz);
+    int rc = msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz, kinds);
     if (rc) return rc;
     for (uint32_t k = 0; k < n_polys; ++k) {
         rc = finish_point(s->curve, xyz + (size_t)k * 3 * L, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);

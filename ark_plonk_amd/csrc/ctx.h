@@ -172,7 +172,8 @@ int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, vo
 int msm_precompute_dev(zk_ctx* c, zk_srs* s);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 // a batch of commitments over one SRS, queued back to back; the host blocks once per result
-int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz);
+int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
+                      const uint8_t* kinds = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points

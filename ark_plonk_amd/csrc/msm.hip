@@ -988,7 +988,8 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
 // once per round instead of once per MSM.  Everything stays on the ctx stream: overlapping
 // neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md).
 template <class Cv>
-int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */) {
+int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
+                  const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */) {
     typedef typename Cv::Fq Fq;
     constexpr int L64 = Fq::N / 2;
     if (n_polys == 0) return ZK_OK;
@@ -1005,8 +1006,12 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     hipStream_t st = c->stream;
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[k];
-        if ((rc = fr_convert_stream(c, s->curve, d_coeffs[k], lens[k], mb.scalars.p, st))) return rc;
-        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, mb.scalars.p, lens[k], st))) return rc;
+        const void* scal = d_coeffs[k];
+        if (!kinds || kinds[k] == 0) {
+            if ((rc = fr_convert_stream(c, s->curve, d_coeffs[k], lens[k], mb.scalars.p, st))) return rc;
+            scal = mb.scalars.p;
+        }
+        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, scal, lens[k], st))) return rc;
         if ((rc = pre_queue_accumulate<Cv>(c, pl[k], mb, s, 0, st))) return rc;
     }
     if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;
@@ -1115,8 +1120,9 @@ int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s) { return msm_precompute_run
 int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
 }
-int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz) {
-    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz);
+int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
+                              const uint8_t* kinds) {
+    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

@@ -139,10 +139,14 @@ class CommitterKey:
             check(lib().zk_kzg_commit(self.ctx.handle, self._h, ptr_of(a), a.shape[0], ptr_of(out), ptr_of(inf)), "zk_kzg_commit")
         return _point(out, inf, self.curve)
 
-    def commit_batch(self, polys) -> list:
-        """The commitments of one prover round (<= 16 device-resident coefficient vectors), pipelined."""
+    def commit_batch(self, polys, canonical=None) -> list:
+        """The MSMs of one prover round (<= 16 device-resident vectors) as one batch.  canonical[k] marks
+        inputs that already are canonical scalars (opening witnesses) rather than Montgomery coefficients."""
         L = self.curve.fq_limbs
         k = len(polys)
+        kinds = None
+        if canonical is not None:
+            kinds = np.ascontiguousarray([1 if f else 0 for f in canonical], dtype=np.uint8)
         ptrs = (ctypes.c_void_p * k)()
         lens = (ctypes.c_size_t * k)()
         for i, p in enumerate(polys):
@@ -151,7 +155,8 @@ class CommitterKey:
         out = np.zeros((k, 2 * L), dtype=np.uint64)
         inf = np.zeros(k, dtype=np.uint8)
         self.ctx.use_torch_stream()
-        check(lib().zk_kzg_commit_batch_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(out), ptr_of(inf)), "zk_kzg_commit_batch_dev")
+        check(lib().zk_kzg_round_batch_dev(self.ctx.handle, self._h, k, ptrs, lens, None if kinds is None else ptr_of(kinds), ptr_of(out),
+                                           ptr_of(inf)), "zk_kzg_round_batch_dev")
         return [_point(out[i], inf[i:i + 1], self.curve) for i in range(k)]
 
     def commit_batch_partial(self, polys) -> np.ndarray:

@@ -155,13 +155,21 @@ class ProofSchedule:
         d4._run(2, c[12], out=self.ev4n)
         t = d4.coset_ifft(self.quot)              # quotient polynomial, 4n coefficients
         out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)])   # t_1..t_4 (prover.rs:455-469)
-        # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618)
-        out += self._commit_round([c[5], c[6], c[7], c[8], c[9], c[4], c[11]])
-        # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
-        out.append(self._open([c[5], c[6], c[7], c[8], c[9], c[4], c[11], c[0], c[1], c[2], c[3]]))
-        saw = (c[8], c[0], c[1], c[3], c[6], c[9], c[4])
-        out += self._commit_round(list(saw))
-        out.append(self._open(list(saw)))         # PC::open at z*omega (prover.rs:609-618)
+        # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618).
+        # All 16 MSMs depend only on polynomials and challenges known at the start of the round.
+        aw = [c[5], c[6], c[7], c[8], c[9], c[4], c[11]]
+        aw_open = aw + [c[0], c[1], c[2], c[3]]   # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
+        saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]
+        if self.world == 1:
+            from .msm import kzg_witness
+            w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+            w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
+            out += self.ck.commit_batch(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True])
+        else:
+            out += self._commit_round(aw)
+            out.append(self._open(aw_open))
+            out += self._commit_round(saw)
+            out.append(self._open(saw))
         assert len(out) == 29
         return out
 

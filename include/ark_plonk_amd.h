@@ -149,6 +149,12 @@ int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t 
 int zk_kzg_commit_batch_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                             uint64_t* out_xy, uint8_t* out_inf);
 
+/* Same with a per-job input kind: kinds[k] = 0 Montgomery coefficients (a commit), 1 canonical scalars
+ * (e.g. an opening witness from zk_kzg_witness_dev).  kinds == NULL means all 0.  Lets the 16 independent
+ * MSMs of the last prover round (7 commits + opening, 7 commits + opening; prover.rs:569-618) be one batch. */
+int zk_kzg_round_batch_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
+                           const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf);
+
 /* Multi-GPU form of the batch: this rank's Jacobian partials (n_polys x 3L limbs) over ITS shard of the
  * SRS, for coefficient slices that already are the rank's [lo, hi) ranges; one all-gather per round. */
 int zk_kzg_commit_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont,

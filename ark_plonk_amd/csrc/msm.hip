@@ -258,7 +258,20 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     const bool head_partial = offsets[b] < (uint32_t)e0;
     bool first_run = true;
     XYZZu<F> acc = XYZZu<F>::infinity();
+    // software pipeline: the reference and the 128-byte point of iteration e+1 are requested before the
+    // mixed addition of iteration e (two dependent HBM/L2 round trips otherwise sit in front of every add)
+    auto point_index = [&](uint32_t ref) -> uint64_t {
+        return PRE ? (uint64_t)((ref >> 26) & 31u) * tab_stride + tab_off + (ref & 0x3ffffffu) : (uint64_t)(ref & 0x7fffffffu);
+    };
+    uint32_t ref_n = entries[(uint32_t)e0];
+    AffineU<F> p_n = ld_affine<F>(bases, point_index(ref_n));
     for (uint32_t e = (uint32_t)e0; e < e1; ++e) {
+        const uint32_t ref = ref_n;
+        AffineU<F> p = p_n;
+        if (e + 1 < e1) {
+            ref_n = entries[e + 1];
+            p_n = ld_affine<F>(bases, point_index(ref_n));
+        }
         if (e == bend) {
             if (first_run && head_partial) st_xyzz<F>(part_pt, 2ull * t, acc);
             else st_xyzz<F>(buckets, b, acc);
@@ -269,9 +282,6 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
                 bend = offsets[b + 1];
             } while (bend <= e);
         }
-        const uint32_t ref = entries[e];
-        const uint64_t pidx = PRE ? (uint64_t)((ref >> 26) & 31u) * tab_stride + tab_off + (ref & 0x3ffffffu) : (uint64_t)(ref & 0x7fffffffu);
-        AffineU<F> p = ld_affine<F>(bases, pidx);
         if (p.is_null()) continue;
         if (ref >> 31) p.y = F::neg_canonical(p.y);
         acc = XYZZu<F>::madd(acc, p);

@@ -15,6 +15,8 @@
 #include "field.cuh"
 #include "fieldu.cuh"
 
+typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+
 struct NttPassArgs {
     const void* in;
     void* out;
@@ -67,7 +69,7 @@ ZK_D uint32_t window_pos(uint32_t v, uint32_t e) {
 
 // lane <-> register transpose through the wave's scratch plane, one limb at a time
 template <class F>
-ZK_D void wave_exchange(F (&x)[8], volatile uint32_t* sc, const uint32_t (&widx)[8], const uint32_t (&ridx)[8]) {
+ZK_D void wave_exchange(F (&x)[8], lds_u32* sc, const uint32_t (&widx)[8], const uint32_t (&ridx)[8]) {
 #pragma unroll
     for (int l = 0; l < F::NL; ++l) {
 #pragma unroll
@@ -104,7 +106,7 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
 // all windows of a 2^S-point DIT; on entry x[e] holds position 8v+e (window B0 = 0), on exit the
 // top-window layout: position (e << (S-3)) | v  (S >= 3)
 template <class F, int S, int B0>
-ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw, volatile uint32_t* sc) {
+ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw, lds_u32* sc) {
     constexpr int REM = S - B0;          // position bits not yet processed
     if constexpr (REM >= 3) {
         dit_window<F, S, B0, 0, 3>(x, v, tw);
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= a.n_tiles) return;
-    volatile uint32_t* sc = scratch[wv];
+    lds_u32* sc = (lds_u32*)scratch[wv];
     const uint32_t c = lane & ((1u << LC) - 1u);
     const uint32_t v = lane >> LC;
     const bool active = c < (1u << a.logc);
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= a.n_tiles) return;
-    volatile uint32_t* sc = scratch[wv];
+    lds_u32* sc = (lds_u32*)scratch[wv];
     // block index digits: b = k1 * 2^log_rest + rho ; this tile gathers 2^logc consecutive k1
     const uint32_t log_nb = a.log_n - S;
     const uint32_t log_rest = log_nb - a.s1;

@@ -105,3 +105,11 @@ def test_sum_partials_host(cid, golden):
     got3 = zk.sum_partials(arr3, cid)
     exp3 = bo.ec_mul(cv, 6, G)
     assert zk.curves.fq_from_mont(cid, got3.x.reshape(1, L))[0] == exp3[0]
+
+
+def test_cpp_host_header_compiles():
+    """host/ark_plonk_amd.hpp (the C++ mirror of EvaluationDomain / VariableBaseMSM / KZG commit) is valid C++17."""
+    import subprocess
+    src = '#include "host/ark_plonk_amd.hpp"\nint main() { return sizeof(zk::G1Affine) > 0 ? 0 : 1; }\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr

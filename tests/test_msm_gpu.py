@@ -166,6 +166,32 @@ def test_precomputed_table_2_20_skewed(ctx):
     _kzg_identity(0, 20, ctx, skew=True, precompute=True)
 
 
+def test_precomputed_table_threshold_sizes(ctx):
+    # smallest sizes that take the shared-bucket path (ZK_PRE_MIN_N = 2^13) and one just above
+    _kzg_identity(0, 13, ctx, precompute=True)
+    _kzg_identity(0, 14, ctx, precompute=True, offset=8191)   # n - offset = 8193 scalars
+
+
+def test_round_batch_with_canonical_jobs(ctx, oracle_cpu):
+    """zk_kzg_round_batch_dev: Montgomery-coefficient jobs and canonical-scalar jobs in one batch."""
+    import torch
+    cid, n = 0, 1 << 13
+    cv = bo.CURVES[cid]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, ks.data_ptr(), n, bases.data_ptr()))
+    coeffs = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    canon = torch.from_numpy(oracle_cpu.convert(cid, "fr", False, coeffs.cpu().numpy().view(np.uint64)).view(np.int64)).cuda()
+    ck = zk.CommitterKey(bases, cid, ctx).precompute()
+    a, b, c = ck.commit_batch([coeffs, canon, coeffs], canonical=[False, True, False])
+    single = ck.commit(coeffs)
+    ck.close()
+    assert a == single and b == single and c == single
+
+
 def test_precomputed_table_offset_and_bn254(ctx):
     _kzg_identity(0, 16, ctx, precompute=True, offset=777)
     _kzg_identity(1, 16, ctx, precompute=True)

@@ -71,11 +71,13 @@ SYMBOLS = {
     "zk_msm_g1_srs_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_msm_g1_srs_partial_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "zk_g1_sum_partials": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "zk_g1_sum_partials_batch": (c_int, [c_int, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_kzg_commit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
     "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
+    "zk_kzg_round_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
     "zk_kzg_open_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "zk_kzg_witness_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,

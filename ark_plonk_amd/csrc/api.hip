@@ -427,6 +427,26 @@ int zk_g1_sum_partials(int curve_id, const uint64_t* partials_xyz, size_t count,
     return g1_sum_partials_host(curve_id, partials_xyz, count, out_xy, out_inf);
 }
 
+int zk_g1_sum_partials_batch(int curve_id, const uint64_t* partials_xyz, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    if (n_jobs == 0) return ZK_OK;
+    if (!out_xy || !partials_xyz || ranks == 0) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    const size_t L = (size_t)fq_limbs64(curve_id);
+    std::vector<int> rcs(n_jobs, 0);
+    auto one = [&](uint32_t k) {
+        std::vector<uint64_t> mine(ranks * 3 * L);
+        for (size_t r = 0; r < ranks; ++r) memcpy(&mine[r * 3 * L], partials_xyz + (r * n_jobs + k) * 3 * L, 3 * L * sizeof(uint64_t));
+        rcs[k] = g1_sum_partials_host(curve_id, mine.data(), ranks, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+    };
+    for (uint32_t base = 0; base < n_jobs; base += 16) {   // bounded thread count
+        const uint32_t cnt = n_jobs - base < 16 ? n_jobs - base : 16;
+        host_parallel_for(cnt, [&](uint32_t k) { one(base + k); });
+    }
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        if (rcs[k]) return rcs[k];
+    return ZK_OK;
+}
+
 // ------------------------------------------------------------------------------------ KZG commit
 int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!c || !s || s->ctx != c || !out_xy || (n && !d_coeffs_mont)) return ZK_ERR_BAD_ARG;
@@ -443,23 +463,30 @@ int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n,
 
 int zk_kzg_commit_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                                     uint64_t* out_xyz) {
-    if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
-    if (n_polys > 16) return ZK_ERR_BAD_ARG;
+    return zk_kzg_round_batch_partial_dev(c, s, n_polys, d_coeffs_mont, lens, nullptr, out_xyz);
+}
+
+int zk_kzg_round_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
+                                   const uint8_t* kinds, uint64_t* out_xyz) {
+    if (!c || !s || s->ctx != c || (n_jobs && (!d_inputs || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
+    if (n_jobs > 16) return ZK_ERR_BAD_ARG;
     const int L = fq_limbs64(s->curve);
     bool fused = s->pre_W != 0 && c->msm_window == 0;
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        if (lens[k] > s->n || (lens[k] && !d_coeffs_mont[k])) return ZK_ERR_BAD_ARG;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
         if (lens[k] < ZK_PRE_MIN_N) fused = false;
     }
     Guard g(c);
-    if (fused) return msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, out_xyz);
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        int rc = c->mb[0].scalars.ensure((lens[k] ? lens[k] : 1) * 32);
-        if (rc) return rc;
-        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont[k], lens[k], c->mb[0].scalars.p);
-        if (rc) return rc;
-        rc = zk_msm_g1_srs_partial_dev(c, s, 0, c->mb[0].scalars.p, lens[k], out_xyz + (size_t)k * 3 * L);
-        if (rc) return rc;
+    if (fused) return msm_batch_pre_dev(c, s, n_jobs, d_inputs, lens, out_xyz, kinds);
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        const void* sc = d_inputs[k];
+        int rc;
+        if (!(kinds && kinds[k])) {
+            if ((rc = c->mb[0].scalars.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
+            if ((rc = fr_convert_dev(c, s->curve, 0, d_inputs[k], lens[k], c->mb[0].scalars.p))) return rc;
+            sc = c->mb[0].scalars.p;
+        }
+        if ((rc = zk_msm_g1_srs_partial_dev(c, s, 0, sc, lens[k], out_xyz + (size_t)k * 3 * L))) return rc;
     }
     return ZK_OK;
 }
@@ -492,10 +519,12 @@ int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* c
     uint64_t xyz[16 * 18];
     int rc = msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz, kinds);
     if (rc) return rc;
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        rc = finish_point(s->curve, xyz + (size_t)k * 3 * L, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
-        if (rc) return rc;
-    }
+    int rcs[16] = {0};
+    host_parallel_for(n_polys, [&](uint32_t k) {
+        rcs[k] = finish_point(s->curve, xyz + (size_t)k * 3 * L, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+    });
+    for (uint32_t k = 0; k < n_polys; ++k)
+        if (rcs[k]) return rcs[k];
     return ZK_OK;
 }
 

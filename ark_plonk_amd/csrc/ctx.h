@@ -6,6 +6,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <utility>
 
@@ -50,6 +51,18 @@ struct CurveBn {
 void zk_note_hip_error(hipError_t e, const char* what, const char* file, int line);
 
 // device buffer that grows on demand and is reused across calls (no hipMalloc in steady state)
+// fn(k) for k in [0, n): helper threads + the caller.  For the host-side tails of a batch (window
+// combine, affine normalisation: ~0.1 ms of serial field arithmetic per job while the GPU waits).
+template <class Fn>
+inline void host_parallel_for(uint32_t n, Fn fn) {
+    if (n == 0) return;
+    std::vector<std::thread> th;
+    th.reserve(n - 1);
+    for (uint32_t k = 1; k < n; ++k) th.emplace_back([&fn, k] { fn(k); });
+    fn(0);
+    for (auto& t : th) t.join();
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;

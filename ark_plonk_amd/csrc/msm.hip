@@ -1026,8 +1026,10 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     }
     if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(st));
-    for (uint32_t k = 0; k < n_polys; ++k)
-        pre_host_combine<Cv>((char*)c->pinned + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, out_xyz + (size_t)k * 3 * L64);
+    const char* h_win = (const char*)c->pinned;
+    host_parallel_for(n_polys, [&](uint32_t k) {
+        pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, out_xyz + (size_t)k * 3 * L64);
+    });
     return ZK_OK;
 }
 

@@ -159,10 +159,13 @@ class CommitterKey:
                                            ptr_of(inf)), "zk_kzg_round_batch_dev")
         return [_point(out[i], inf[i:i + 1], self.curve) for i in range(k)]
 
-    def commit_batch_partial(self, polys) -> np.ndarray:
+    def commit_batch_partial(self, polys, canonical=None) -> np.ndarray:
         """Sharded form: Jacobian partials (k, 3L) of the given coefficient slices over this rank's SRS shard."""
         L = self.curve.fq_limbs
         k = len(polys)
+        kinds = None
+        if canonical is not None:
+            kinds = np.ascontiguousarray([1 if f else 0 for f in canonical], dtype=np.uint8)
         ptrs = (ctypes.c_void_p * k)()
         lens = (ctypes.c_size_t * k)()
         for i, p in enumerate(polys):
@@ -170,8 +173,8 @@ class CommitterKey:
             ptrs[i] = p.data_ptr()
         out = np.zeros((k, 3 * L), dtype=np.uint64)
         self.ctx.use_torch_stream()
-        check(lib().zk_kzg_commit_batch_partial_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(out)),
-              "zk_kzg_commit_batch_partial_dev")
+        check(lib().zk_kzg_round_batch_partial_dev(self.ctx.handle, self._h, k, ptrs, lens, None if kinds is None else ptr_of(kinds),
+                                                   ptr_of(out)), "zk_kzg_round_batch_partial_dev")
         return out
 
     # -- PC::open(ck, polys, comms, point, opening_challenge, rands, None)
@@ -259,3 +262,17 @@ def sum_partials(partials, curve="bls12_381") -> G1Affine:
     inf = np.zeros(1, dtype=np.uint8)
     check(lib().zk_g1_sum_partials(cv.curve_id, ptr_of(p), p.shape[0], ptr_of(out), ptr_of(inf)), "zk_g1_sum_partials")
     return _point(out, inf, cv)
+
+
+def sum_partials_batch(partials, curve="bls12_381") -> list:
+    """All-gathered partials of one prover round, shape (ranks, jobs, 3L) -> one G1Affine per job."""
+    cv = get_curve(curve)
+    L = cv.fq_limbs
+    p = np.ascontiguousarray(partials, dtype=np.uint64)
+    if p.ndim != 3 or p.shape[2] != 3 * L:
+        raise ValueError(f"expected (ranks, jobs, {3 * L}) limbs, got {p.shape}")
+    ranks, jobs = p.shape[0], p.shape[1]
+    out = np.zeros((jobs, 2 * L), dtype=np.uint64)
+    inf = np.zeros(max(jobs, 1), dtype=np.uint8)
+    check(lib().zk_g1_sum_partials_batch(cv.curve_id, ptr_of(p), ranks, jobs, ptr_of(out), ptr_of(inf)), "zk_g1_sum_partials_batch")
+    return [_point(out[k], inf[k:k + 1], cv) for k in range(jobs)]

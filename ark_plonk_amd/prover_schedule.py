@@ -18,7 +18,7 @@ import numpy as np
 
 from .curves import get_curve
 from .domain import Radix2EvaluationDomain
-from .msm import CommitterKey, sum_partials
+from .msm import CommitterKey, sum_partials_batch
 
 
 class ProofSchedule:
@@ -59,69 +59,29 @@ class ProofSchedule:
         self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
         self.chi_mont = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
 
-    # -- one commitment = into_repr + MSM over this rank's shard (+ all-gather when world > 1)
-    def _commit(self, coeffs, length=None):
-        length = self.n if length is None else length
-        lo, hi = self.lo, min(self.hi, length)
-        if self.world == 1:
-            return self.ck.commit(coeffs[:length])
-        torch = self.torch
-        from ._lib import check, lib
-        from .context import ptr_of
-        sc = self.scratch_n[: max(hi - lo, 0)]
-        if hi > lo:
-            self.ctx.use_torch_stream()
-            check(lib().zk_fr_from_mont_dev(self.ctx.handle, self.cv.curve_id, ptr_of(coeffs[lo:hi]), hi - lo, ptr_of(sc)))
-            part = self.ck.msm_partial(sc, 0)
-        else:
-            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)   # Z = 0: infinity
-        return self._gather_sum(part, coeffs.device)
-
-    def _gather_sum(self, part, device):
-        """all-gather the 3L-limb Jacobian partials (144 B per rank) and add them up on the host"""
-        torch = self.torch
-        mine = torch.from_numpy(part.view(np.int64))
-        if self.dist.get_backend() == "nccl":
-            mine = mine.to(device)
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(gathered, mine)
-        allp = torch.stack(gathered).cpu().numpy().view(np.uint64)
-        return sum_partials(allp, self.cv.curve_id)
-
     # -- the commitments of one prover round: submitted back to back, collected together (the
     #    transcript needs them only at the end of the round)
-    def _commit_round(self, polys):
+    def _commit_round(self, polys, canonical=None):
         polys = list(polys)
         if self.world == 1:
-            return self.ck.commit_batch(polys)
+            return self.ck.commit_batch(polys, canonical=canonical)
         # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the round
         torch = self.torch
         L3 = 3 * self.cv.fq_limbs
-        slices = [p[self.lo:min(self.hi, p.shape[0])] for p in polys]
+        slices = [p[self.lo:max(self.lo, min(self.hi, p.shape[0]))] for p in polys]
         if all(sl.shape[0] > 0 for sl in slices):
-            parts = self.ck.commit_batch_partial(slices)
+            parts = self.ck.commit_batch_partial(slices, canonical=canonical)
         else:
-            parts = np.stack([self.ck.commit_batch_partial([sl])[0] if sl.shape[0] else np.zeros(L3, dtype=np.uint64) for sl in slices])
+            kinds = canonical or [False] * len(polys)
+            parts = np.stack([self.ck.commit_batch_partial([sl], canonical=[kd])[0] if sl.shape[0] else np.zeros(L3, dtype=np.uint64)
+                              for sl, kd in zip(slices, kinds)])
         mine = torch.from_numpy(parts.view(np.int64).reshape(-1))
         if self.dist.get_backend() == "nccl":
             mine = mine.to(polys[0].device)
         gathered = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(gathered, mine)
         allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, len(polys), L3)
-        return [sum_partials(np.ascontiguousarray(allp[:, k, :]), self.cv.curve_id) for k in range(len(polys))]
-
-    # -- one opening = RLC + witness (replicated per rank) + MSM of n-1 (sharded like a commit)
-    def _open(self, polys):
-        if self.world == 1:
-            return self.ck.open(polys, self.z_mont, self.chi_mont)
-        from .msm import kzg_witness
-        w = kzg_witness(polys, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
-        lo, hi = self.lo, min(self.hi, w.shape[0])
-        if hi > lo:
-            part = self.ck.msm_partial(w[lo:hi], 0)
-        else:
-            part = np.zeros(3 * self.cv.fq_limbs, dtype=np.uint64)
-        return self._gather_sum(part, w.device)
+        return sum_partials_batch(allp, self.cv.curve_id)
 
     def run_once(self):
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
@@ -160,16 +120,11 @@ class ProofSchedule:
         aw = [c[5], c[6], c[7], c[8], c[9], c[4], c[11]]
         aw_open = aw + [c[0], c[1], c[2], c[3]]   # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
         saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]
-        if self.world == 1:
-            from .msm import kzg_witness
-            w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
-            w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
-            out += self.ck.commit_batch(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True])
-        else:
-            out += self._commit_round(aw)
-            out.append(self._open(aw_open))
-            out += self._commit_round(saw)
-            out.append(self._open(saw))
+        from .msm import kzg_witness
+        # the witness polynomials are computed by every rank (replicated, like the NTTs); their MSMs shard
+        w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+        w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
+        out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True])
         assert len(out) == 29
         return out
 

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     args = ap.parse_args()
 
@@ -147,7 +148,7 @@ def main():
     for _ in range(args.warmup):
         pts = sched.run_once()
     barrier()
-    ctx.profile(True)
+    ctx.profile(not args.no_profile)
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

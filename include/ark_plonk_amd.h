@@ -134,6 +134,9 @@ int zk_msm_g1_srs_partial_dev(zk_ctx* ctx, zk_srs* srs, size_t base_offset, cons
                               uint64_t* out_xyz);
 /* Host: sum `count` Jacobian partials (count x 3L limbs) and normalise to affine. */
 int zk_g1_sum_partials(int curve_id, const uint64_t* partials_xyz, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+/* Host: the all-gathered partials of one prover round, laid out [rank][job][3L]; job k's sum -> out_xy[k], out_inf[k]. */
+int zk_g1_sum_partials_batch(int curve_id, const uint64_t* partials_xyz, size_t ranks, uint32_t n_jobs, uint64_t* out_xy,
+                             uint8_t* out_inf);
 
 /* ---- a6: KZG10 commit (PC::commit, prover.rs:213,289-291,312-317,361-363,387-389,459-469) ----- */
 /* d_coeffs_mont: n Montgomery Fr coefficients on device.  into_repr + MSM over
@@ -159,6 +162,11 @@ int zk_kzg_round_batch_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void
  * SRS, for coefficient slices that already are the rank's [lo, hi) ranges; one all-gather per round. */
 int zk_kzg_commit_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_coeffs_mont,
                                     const size_t* lens, uint64_t* out_xyz);
+
+/* zk_kzg_round_batch_dev for a sharded SRS: per-job input kinds as above, Jacobian partials out
+ * (n_jobs x 3L limbs); the opening witnesses of prover.rs:582-618 are passed as this rank's slice. */
+int zk_kzg_round_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
+                                   const uint8_t* kinds, uint64_t* out_xyz);
 
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).

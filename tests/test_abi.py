@@ -107,6 +107,35 @@ def test_sum_partials_host(cid, golden):
     assert zk.curves.fq_from_mont(cid, got3.x.reshape(1, L))[0] == exp3[0]
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_sum_partials_batch_host(cid):
+    """zk_g1_sum_partials_batch: [rank][job][3L] partials of one prover round -> one point per job (threaded host tail)."""
+    cv = bo.CURVES[cid]
+    L = cv.fq_limbs
+    G = (cv.gx, cv.gy)
+    ranks, jobs = 3, 20           # > 16 jobs: exercises the bounded thread groups
+    flat, exp = [], []
+    ks = [[1 + 5 * r + 17 * j for j in range(jobs)] for r in range(ranks)]
+    ks[1][4] = 0                  # an infinity partial
+    for r in range(ranks):
+        for j in range(jobs):
+            if ks[r][j] == 0:
+                flat += [1, 1, 0]
+                continue
+            p = bo.ec_mul(cv, ks[r][j], G)
+            z = 2 + r + j
+            flat += [p[0] * z * z % cv.q, p[1] * z * z * z % cv.q, z]
+    arr = zk.curves.fq_to_mont(cid, flat).reshape(ranks, jobs, 3 * L)
+    got = zk.sum_partials_batch(arr, cid)
+    assert len(got) == jobs
+    for j in range(jobs):
+        e = bo.ec_mul(cv, sum(ks[r][j] for r in range(ranks)), G)
+        assert not got[j].infinity
+        assert zk.curves.fq_from_mont(cid, got[j].x.reshape(1, L))[0] == e[0]
+        assert zk.curves.fq_from_mont(cid, got[j].y.reshape(1, L))[0] == e[1]
+        assert got[j] == zk.sum_partials(arr[:, j, :], cid)
+
+
 def test_cpp_host_header_compiles():
     """host/ark_plonk_amd.hpp (the C++ mirror of EvaluationDomain / VariableBaseMSM / KZG commit) is valid C++17."""
     import subprocess

@@ -4,8 +4,16 @@
 A "step" = one proof's hot path: the reference's exact per-proof schedule of 31 transforms and 29
 KZG commitments (ark_plonk_amd/prover_schedule.py <- prover.rs:163-638) at n = 2^20 constraints,
 BLS12-381 + KZG10, on synthetic polynomials with every input (SRS, evaluation vectors) already
-resident in HBM.  N > 1: one process per GPU (torchrun); each MSM is sharded by points over the
-ranks and combined by an RCCL all-gather of Jacobian partials; NTTs are replicated per rank.
+resident in HBM.  N > 1: one process per GPU (torchrun).  `value` is the throughput of N replicas --
+whole proofs are independent, so every rank runs the schedule K times with no data-path collective
+(SURVEY.md 8e "whole proofs: replicas only", scaling "weak").  The same run then times a second leg,
+reported under `msm_sharded` and never part of `value`: one proof stream with every MSM sharded by
+points over the ranks and combined by an RCCL all-gather of Jacobian partials per prover round (NTTs
+replicated) -- the single-proof latency mode.  `--mode shard` makes that leg the headline instead
+(scaling "strong").
+
+N = 1 adds a `concurrent_streams` leg (also never part of `value`): the same GPU with 4 proofs in flight
+(one thread + zk_ctx + HIP stream each), i.e. the throughput a proving service would see.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate) with the
 algorithmic bytes of SURVEY.md 8d (128 B per point) over its HIP-event-timed launches;
@@ -98,6 +106,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
+                    help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by an "
+                         "untimed-for-value sharded leg; 'shard' = every MSM point-sharded over the ranks (strong scaling)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent proof streams per GPU (threads with their own zk_ctx + HIP stream); the K steps are shared out")
+    ap.add_argument("--streams-leg", type=int, default=4,
+                    help="N = 1: after the timed region, also report the throughput with this many concurrent proof streams (0/1 = skip)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="replica mode: skip the extra sharded-MSM leg")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     args = ap.parse_args()
@@ -130,13 +146,12 @@ def main():
     cv = zk.get_curve("bls12_381")
     log_n = args.log_n
     n = 1 << log_n
-    lo, hi = rank * n // world, (rank + 1) * n // world
-    srs = build_srs(ctx, cv, n, lo, hi, torch)
-    ck = zk.CommitterKey(srs, cv, ctx)
-    del srs
-    if not args.no_precompute:
-        ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
-    sched = ProofSchedule(log_n, ctx, ck, cv, rank=rank, world=world, dist=dist if world > 1 else None)
+    steps = args.steps
+    mode = args.mode
+    if mode == "auto":
+        mode = "replica" if world > 1 else "single"
+    if world == 1:
+        mode = "single"
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,65 +159,166 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pts = None
-    for _ in range(args.warmup):
-        pts = sched.run_once()
-    barrier()
-    ctx.profile(not args.no_profile)
-    ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sched.run_once()
-    barrier()
-    dt = time.perf_counter() - t0
-    ctx.profile(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def digest(points):
+        import hashlib
+        return hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in points)).hexdigest()
 
-    acc_ms, acc_n = ctx.profile_get("msm_accumulate")
-    ntt_ms, ntt_n = ctx.profile_get("ntt_pass")
-    sort_ms, _ = ctx.profile_get("msm_sort")
-    red_ms, _ = ctx.profile_get("msm_reduce")
-    steps = args.steps
-    value = steps / dt
-    pts_per_launch = (hi - lo)
-    alg_bytes = 128.0 * pts_per_launch                      # 32 B scalar + 96 B affine base, once
+    def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
+        --streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
+        streams (one thread + zk_ctx + HIP stream each) on this rank's GPU."""
+        import threading
+        lo, hi = (rank * n // world, (rank + 1) * n // world) if sharded else (0, n)
+        S = 1 if sharded else max(1, min(n_streams, steps))
+        lanes = []
+        for i in range(S):
+            cx = ctx if i == 0 else zk.Context(dev)
+            st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                srs = build_srs(cx, cv, n, lo, hi, torch)
+                ck = zk.CommitterKey(srs, cv, cx)
+                del srs
+                if not args.no_precompute:
+                    ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
+                if sharded:
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist)
+                else:
+                    sched = ProofSchedule(log_n, cx, ck, cv)
+                pts = None
+                for _ in range(args.warmup):
+                    pts = sched.run_once()
+            lanes.append({"ctx": cx, "stream": st, "ck": ck, "sched": sched, "pts": pts, "k": steps // S + (1 if i < steps % S else 0)})
+        barrier()
+        ctx.profile(not args.no_profile)
+        ctx.profile_reset()
+        if S == 1:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                lanes[0]["sched"].run_once()
+            barrier()
+            dt = time.perf_counter() - t0
+        else:
+            gate = threading.Barrier(S + 1)
+            errs = []
+
+            def worker(ln):
+                try:
+                    with torch.cuda.stream(ln["stream"]):
+                        gate.wait()
+                        for _ in range(ln["k"]):
+                            ln["sched"].run_once()
+                except Exception as e:  # surfaced below: a failed lane must fail the run
+                    errs.append(e)
+                    gate.abort()
+
+            th = [threading.Thread(target=worker, args=(ln,)) for ln in lanes]
+            for t in th:
+                t.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for t in th:
+                t.join()
+            barrier()
+            dt = time.perf_counter() - t0
+            if errs:
+                raise errs[0]
+        ctx.profile(False)
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce")}
+        digs = []
+        if args.check:
+            for ln in lanes:
+                with torch.cuda.stream(ln["stream"]):
+                    digs.append(digest(ln["pts"] if ln["pts"] is not None else ln["sched"].run_once()))
+            if len(set(digs)) != 1:
+                raise RuntimeError(f"proof streams disagree: {digs}")
+        res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
+               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"]}
+        for ln in lanes:
+            ln["ck"].close()
+        lanes.clear()
+        return res
+
+    main_sharded = mode == "shard"
+    r = timed_region(main_sharded, args.streams)
+    dt = r["dt"]
+    proofs = steps * (1 if (main_sharded or world == 1) else world)   # replicas: every rank proves K times
+    value = proofs / dt
+    acc_ms, acc_n = r["prof"]["msm_accumulate"]
+    ntt_ms, ntt_n = r["prof"]["ntt_pass"]
+    sort_ms, _ = r["prof"]["msm_sort"]
+    red_ms, _ = r["prof"]["msm_reduce"]
+    alg_bytes = 128.0 * r["points_per_launch"]               # 32 B scalar + 96 B affine base, once
     avg_s = (acc_ms / max(acc_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if acc_n else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
-    if os.path.exists(pmc_path) and world == 1 and log_n == 20:
+    if os.path.exists(pmc_path) and not main_sharded and log_n == 20:
         try:
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     msm_total_s = (acc_ms + sort_ms + red_ms) * 1e-3
+    kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
+    S = r["streams"]
+    if world == 1:
+        par = "1 GPU"
+    elif main_sharded:
+        par = f"MSM point-sharded over {world} GPUs + RCCL all-gather of partials; NTT replicated"
+    else:
+        par = f"{world} replicas (one whole proof stream per GPU, no data-path collective)"
     line = {
         "metric": "proofs/sec at 2^20 constraints (BLS12-381, KZG10); MSM G1-adds/s",
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if main_sharded else "weak",
         "vs_baseline": None, "dtype": "u32 limbs (256/384-bit Montgomery integers)", "data": "synthetic",
         "config": {"workload": f"per-proof hot path of Prover::prove at n=2^{log_n}: 13 ifft(n)+4 fft(n)+13 coset_fft(4n)+"
                                f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), BLS12-381, SRS+inputs HBM-resident",
-                   "log_n": log_n, "curve": "bls12_381",
-                   "parallelism": "1 GPU" if world == 1 else f"MSM point-sharded over {world} GPUs + RCCL all-gather of partials; NTT replicated"},
+                   "log_n": log_n, "curve": "bls12_381", "parallelism": par},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes},
-        "msm_g1_adds_per_s": (29 * steps * ark_adds(n)) / msm_total_s if (world == 1 and msm_total_s) else None,
-        "msm_ms_per_proof": msm_total_s / steps * 1e3,
-        "ntt_GBps": (sched.ntt_bytes() * steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
-        "ntt_ms_per_proof": ntt_ms / steps,
+        # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
+        "msm_g1_adds_per_s": ((29 * kp * ark_adds(n)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
+                              if (msm_total_s and S == 1) else None),
+        "msm_ms_per_proof": msm_total_s / kp * 1e3,
+        "ntt_GBps": (r["ntt_bytes"] * kp) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
+        "ntt_ms_per_proof": ntt_ms / kp,
     }
+    if S > 1:
+        line["config"]["parallelism"] += f", {S} concurrent proof streams per GPU (kernel times below overlap other streams' work)"
     if args.check:
-        import hashlib
-        if pts is None:
-            pts = sched.run_once()
-        h = hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in pts)).hexdigest()
-        line["commitments_sha256"] = h
+        line["commitments_sha256"] = r["digest"]
+    if world == 1 and S == 1 and args.streams_leg > 1:
+        # second leg, not part of `value`: the GPU's throughput with several proofs in flight (a proving service):
+        # small kernels of one proof fill the registers/issue slots the 2-waves/SIMD accumulate of another leaves idle
+        try:
+            k2 = max(steps, 2 * args.streams_leg)
+            r2 = timed_region(False, args.streams_leg, k2)
+            line["concurrent_streams"] = {"streams": r2["streams"], "steps": k2, "proofs_per_s": k2 / r2["dt"],
+                                          "ms_per_proof_aggregate": r2["dt"] / k2 * 1e3,
+                                          "commitments_match": (r2["digest"] == r["digest"]) if args.check else None}
+        except Exception as e:
+            line["concurrent_streams"] = {"error": repr(e)}
+    if world > 1 and mode == "replica" and not args.no_sharded_leg:
+        # second leg, not part of `value`: the same proofs with every MSM point-sharded over the ranks
+        # (one RCCL all-gather of Jacobian partials per prover round) -- single-proof latency
+        try:
+            rs = timed_region(True)
+            sa_ms, sa_n = rs["prof"]["msm_accumulate"]
+            line["msm_sharded"] = {
+                "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
+                "speedup_vs_one_gpu_replica": (dt / steps) / (rs["dt"] / steps),
+                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per prover round (7 per proof)",
+                "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
+                "commitments_match_replicas": (rs["digest"] == r["digest"]) if args.check else None,
+            }
+        except Exception as e:  # the headline above stands on its own
+            line["msm_sharded"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -115,8 +115,8 @@ def test_sharded_msm_two_ranks_one_gpu():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_matches_one_rank():
-    """bench.py's N > 1 path (point-sharded MSMs + all-gather, replicated NTTs) on one card with gloo:
-    the 29 commitments must equal the single-rank run's, bit for bit."""
+    """bench.py's N > 1 paths on one card with gloo -- replicas, and point-sharded MSMs + all-gather with
+    replicated NTTs: the 29 commitments must equal the single-rank run's, bit for bit."""
     import json
     import subprocess
     import sys
@@ -125,11 +125,20 @@ def test_bench_two_ranks_matches_one_rank():
     one = subprocess.run([sys.executable] + common, capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
-    port = _free_port()
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port)] + common + ["--gpus", "2", "--backend", "gloo"],
-                         capture_output=True, text=True, env=env, timeout=900)
-    assert two.returncode == 0, two.stderr[-3000:]
-    d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    def two_ranks(extra):
+        port = _free_port()
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port)] + common + ["--gpus", "2", "--backend", "gloo"] + extra,
+                             capture_output=True, text=True, env=env, timeout=900)
+        assert two.returncode == 0, two.stderr[-3000:]
+        return json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+    # default: replicas are the headline (weak scaling), the sharded-MSM leg rides along and must agree
+    d2 = two_ranks([])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak"
     assert d1["commitments_sha256"] == d2["commitments_sha256"]
+    assert d2["msm_sharded"].get("commitments_match_replicas") is True, d2["msm_sharded"]
+    # --mode shard: the sharded path as the headline (strong scaling)
+    d3 = two_ranks(["--mode", "shard"])
+    assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"
+    assert d1["commitments_sha256"] == d3["commitments_sha256"]

@@ -852,10 +852,12 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     pl.gv.ns = pl.gv.B >> pl.gv.logG;
     pl.gv.logq = 0;
     while ((256u << pl.gv.logq) < pl.gv.ns) ++pl.gv.logq;
-    // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 waves
-    // of lanes per SIMD on the 256-CU chip (the kernel holds 2 waves/SIMD at its VGPR count)
+    // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 rounds of
+    // resident lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131072 at the kernel's VGPR count), so that
+    // lanes finishing early are replaced instead of idling through the tail (measured at 2^20:
+    // L = 128 / 64 / 32 / 16 -> 111.8 / 110.3 / 110.8 / 162 ms per proof; 16 overloads the combine)
     pl.chunk_l = PRE_CHUNK_L;
-    while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 131072) pl.chunk_l >>= 1;
+    while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 262144) pl.chunk_l >>= 1;
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
     pl.S = 1;
     while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;

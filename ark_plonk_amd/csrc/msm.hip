@@ -341,6 +341,7 @@ ZK_D XYZZu<F> wave_sum(XYZZu<F> acc) {
 // One lane per bucket: a bucket whose entries span p >= 2 chunks has exactly p partials at slots
 // known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued.
 // queues: q[0] = medium count, q[1] = large count, q[2 ..] medium ids (grow up), q[.. 2+nb) large ids (grow down)
+constexpr uint32_t COMBINE_SG = 4;         // lanes cooperating on one small bucket
 template <class F>
 __global__ void __launch_bounds__(128) msm_combine(RJobs jobs, uint32_t nb) {
     const void* part_pt = jobs.part_pt[blockIdx.y];
@@ -348,24 +349,41 @@ __global__ void __launch_bounds__(128) msm_combine(RJobs jobs, uint32_t nb) {
     void* buckets = jobs.buckets[blockIdx.y];
     uint32_t* q = jobs.q[blockIdx.y];
     const uint32_t L = jobs.L[blockIdx.y];
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const uint32_t s = offsets[b], e = offsets[b + 1];
-    if (e == s) return;
-    const uint32_t ta = s / L, tb = (e - 1) / L;
-    if (ta == tb) return;  // whole bucket inside one chunk: already complete
-    const uint32_t p = tb - ta + 1;
-    if (p > COMBINE_MEDIUM) {
-        q[2 + nb - 1 - atomicAdd(&q[1], 1u)] = b;
-        return;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = id / COMBINE_SG, sub = id % COMBINE_SG;
+    // every lane stays to the end: the sub-group sums below are wave shuffles
+    XYZZu<F> acc = XYZZu<F>::infinity();
+    bool mine = false;
+    if (b < nb) {
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        if (e != s) {
+            const uint32_t ta = s / L, tb = (e - 1) / L;
+            const uint32_t p = tb - ta + 1;   // p == 1: whole bucket inside one chunk, already complete
+            if (p > COMBINE_MEDIUM) {
+                if (sub == 0) q[2 + nb - 1 - atomicAdd(&q[1], 1u)] = b;
+            } else if (p > COMBINE_SMALL) {
+                if (sub == 0) q[2 + atomicAdd(&q[0], 1u)] = b;
+            } else if (p > 1) {
+                mine = true;
+#pragma unroll 1
+                for (uint32_t t = ta + sub; t <= tb; t += COMBINE_SG)
+                    acc = XYZZu<F>::add(acc, ld_xyzz<F>(part_pt, partial_slot(t, ta, s, L)));
+            }
+        }
     }
-    if (p > COMBINE_SMALL) {
-        q[2 + atomicAdd(&q[0], 1u)] = b;
-        return;
+#pragma unroll 1
+    for (int d = COMBINE_SG / 2; d >= 1; d >>= 1) {
+        XYZZu<F> o;
+#pragma unroll
+        for (int i = 0; i < F::NL; ++i) {
+            o.x.v[i] = __shfl_down(acc.x.v[i], d, 64);
+            o.y.v[i] = __shfl_down(acc.y.v[i], d, 64);
+            o.zz.v[i] = __shfl_down(acc.zz.v[i], d, 64);
+            o.zzz.v[i] = __shfl_down(acc.zzz.v[i], d, 64);
+        }
+        acc = XYZZu<F>::add(acc, o);
     }
-    XYZZu<F> acc = ld_xyzz<F>(part_pt, partial_slot(ta, ta, s, L));
-    for (uint32_t t = ta + 1; t <= tb; ++t) acc = XYZZu<F>::add(acc, ld_xyzz<F>(part_pt, 2ull * t));
-    st_xyzz<F>(buckets, b, acc);
+    if (mine && sub == 0) st_xyzz<F>(buckets, b, acc);
 }
 
 // medium buckets: one wavefront per bucket, lanes stride over its partials, shuffle tree
@@ -585,7 +603,7 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
     for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
-    unsigned blocks = (nb + T - 1) / T;
+    unsigned blocks = (unsigned)(((uint64_t)nb * COMBINE_SG + T - 1) / T);
     hipLaunchKernelGGL(msm_combine<F>, dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
     hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
     hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);

@@ -33,6 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# The kernel is integer-VALU bound (SURVEY.md 8d asks for the u32-MAC rate next to the HBM fraction).
+# Instruction counts of the mixed-addition path of msm_accumulate (gfx950 ISA of this build, BLS12-381:
+# 8 products + 2 squares of 14 x 29-bit limbs) and the measured issue costs of profiles/r01_ubench_valu.txt.
+MADD_MADS = 3738            # v_mad_u64_u32 per mixed addition
+MADD_OTHER_VALU = 1316      # and/shift/add/mul_lo around them
+CLOCK_HZ = 2.4e9            # MI355X max engine clock (MI355X_MICROARCH.md chip table)
+LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
+MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
+# issue cycles of one mixed addition at the kernel's 2 waves/SIMD (220 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
+MADD_CYCLES_2WAVES = 3738 * 4.77 + 140 * 4.70 + 520 * 4.45 + 656 * 2.64
 
 
 def ark_adds(n: int, bits: int = 255) -> int:
@@ -262,6 +272,14 @@ def main():
         except Exception:
             traffic = None
     msm_total_s = (acc_ms + sort_ms + red_ms) * 1e-3
+    valu = None
+    if acc_n and not args.no_precompute:
+        madds = 16.0 * r["points_per_launch"]               # one mixed addition per (16-bit window, point)
+        mac_s = madds * MADD_MADS / avg_s
+        peak_mac_s = LANES * CLOCK_HZ / MAD_CYCLES_FULL
+        bound2 = LANES * CLOCK_HZ / MADD_CYCLES_2WAVES
+        valu = {"mixed_adds_per_s": madds / avg_s, "u32_mac_per_s": mac_s, "peak_u32_mac_per_s": peak_mac_s, "frac_of_mad_peak": mac_s / peak_mac_s,
+                "issue_bound_mixed_adds_per_s_at_2_waves_per_simd": bound2, "frac_of_issue_bound": madds / avg_s / bound2}
     kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
     S = r["streams"]
     if world == 1:
@@ -281,7 +299,8 @@ def main():
                    "log_n": log_n, "curve": "bls12_381", "parallelism": par},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes},
+                     "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes,
+                     "valu": valu},
         # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
         "msm_g1_adds_per_s": ((29 * kp * ark_adds(n)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
                               if (msm_total_s and S == 1) else None),

@@ -23,7 +23,7 @@ from .msm import CommitterKey, sum_partials_batch
 
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
-                 dist=None, seed: int = 0x5EED0000):
+                 dist=None, seed: int = 0x5EED0000, dedup: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -32,6 +32,11 @@ class ProofSchedule:
         self.ctx = ctx
         self.ck = ck
         self.rank, self.world, self.dist = rank, world, dist
+        # commitments cached by polynomial label, so the 12 polynomials the reference
+        # commits a second time in round 5 (prover.rs:569-607) cost no MSM: 29 -> 17 per proof, same outputs
+        self.dedup = dedup
+        self._cache = {}
+        self.msms_run = 0
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
         self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
         dev = torch.device("cuda", ctx.device)
@@ -61,8 +66,16 @@ class ProofSchedule:
 
     # -- the commitments of one prover round: submitted back to back, collected together (the
     #    transcript needs them only at the end of the round)
-    def _commit_round(self, polys, canonical=None):
+    def _commit_round(self, polys, canonical=None, labels=None):
         polys = list(polys)
+        if self.dedup and labels is not None:
+            todo = [k for k, lb in enumerate(labels) if lb not in self._cache and lb not in labels[:k]]
+            if todo:
+                got = self._commit_round([polys[k] for k in todo], None if canonical is None else [canonical[k] for k in todo])
+                for k, pt in zip(todo, got):
+                    self._cache[labels[k]] = pt
+            return [self._cache[lb] for lb in labels]
+        self.msms_run += len(polys)
         if self.world == 1:
             return self.ck.commit_batch(polys, canonical=canonical)
         # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the round
@@ -87,25 +100,27 @@ class ProofSchedule:
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
         d, d4, n = self.dom_n, self.dom_4n, self.n
         out = []
+        self._cache = {}
+        self.msms_run = 0
         c = self.coef
         # Round 1: 4 ifft + 4 commits (prover.rs:196-203, 213)
         for i in range(4):
             c[i] = d.ifft(self.evals[i])
-        out += self._commit_round(c[:4])
+        out += self._commit_round(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         c[4] = d.ifft(self.aux_evals[0])          # table_poly
         c[5] = d.ifft(self.aux_evals[1])          # f_poly
-        out += self._commit_round([c[5]])
+        out += self._commit_round([c[5]], labels=["f"])
         c[6] = d.ifft(self.aux_evals[2])          # h1
         c[7] = d.ifft(self.aux_evals[3])          # h2
-        out += self._commit_round([c[6], c[7]])
+        out += self._commit_round([c[6], c[7]], labels=["h1", "h2"])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         for i in range(4):
             d.fft(self.sigma[i])
         c[8] = d.ifft(self.aux_evals[4])          # z
-        out += self._commit_round([c[8]])
+        out += self._commit_round([c[8]], labels=["z"])
         c[9] = d.ifft(self.aux_evals[5])          # z2
-        out += self._commit_round([c[9]])
+        out += self._commit_round([c[9]], labels=["z2"])
         c[10] = d.ifft(self.aux_evals[6])         # pi
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         c[11] = d.ifft(self.aux_evals[7])         # l1
@@ -114,7 +129,7 @@ class ProofSchedule:
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
         t = d4.coset_ifft(self.quot)              # quotient polynomial, 4n coefficients
-        out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)])   # t_1..t_4 (prover.rs:455-469)
+        out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)], labels=["t1", "t2", "t3", "t4"])   # t_1..t_4 (prover.rs:455-469)
         # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618).
         # All 16 MSMs depend only on polynomials and challenges known at the start of the round.
         aw = [c[5], c[6], c[7], c[8], c[9], c[4], c[11]]
@@ -124,7 +139,8 @@ class ProofSchedule:
         # the witness polynomials are computed by every rank (replicated, like the NTTs); their MSMs shard
         w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
         w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
-        out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True])
+        out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True],
+                                  labels=["f", "h1", "h2", "z", "z2", "table", "l1", "W_z", "z", "w_l", "w_r", "w_4", "h1", "z2", "table", "W_zw"])
         assert len(out) == 29
         return out
 

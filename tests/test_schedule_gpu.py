@@ -1,0 +1,43 @@
+"""The per-proof call schedule (ark_plonk_amd/prover_schedule.py <- prover.rs:163-638) on a small domain."""
+import numpy as np
+import pytest
+
+import ark_plonk_amd as zk
+from ark_plonk_amd import _lib
+from ark_plonk_amd.prover_schedule import ProofSchedule
+
+pytestmark = pytest.mark.gpu
+
+
+def _ck(ctx, cv, n):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cv.curve_id, ks.data_ptr(), n, bases.data_ptr()))
+    return zk.CommitterKey(bases, cv, ctx)
+
+
+@pytest.mark.parametrize("log_n", [10, 13])
+def test_schedule_table_path_matches_plain_path_and_dedup(ctx, log_n):
+    """29 outputs per proof; the window-table path, the per-window path and the de-duplicated schedule
+    (17 MSMs) must agree point for point."""
+    cv = zk.get_curve("bls12_381")
+    n = 1 << log_n
+    ck = _ck(ctx, cv, n)
+    plain = ProofSchedule(log_n, ctx, ck, cv).run_once()
+    assert len(plain) == 29
+    ck.precompute()
+    s_tab = ProofSchedule(log_n, ctx, ck, cv)
+    tab = s_tab.run_once()
+    assert s_tab.msms_run == 29
+    s_dd = ProofSchedule(log_n, ctx, ck, cv, dedup=True)
+    dd = s_dd.run_once()
+    assert s_dd.msms_run == 17
+    for a, b, c in zip(plain, tab, dd):
+        assert a == b and a == c
+    # round 5 re-commits polynomials of rounds 1-3 (prover.rs:569-607): outputs 13..19 and 21..27 repeat earlier ones
+    assert tab[13] == tab[4] and tab[16] == tab[7] and tab[21] == tab[7] and tab[22] == tab[0]
+    ck.close()

@@ -56,6 +56,8 @@ SYMBOLS = {
     "zk_domain_new": (c_int, [c_int, c_u64, ctypes.POINTER(DomainInfo)]),
     "zk_ntt": (c_int, [c_void_p, c_int, c_int, c_u32, c_void_p, c_size_t, c_void_p]),
     "zk_ntt_dev": (c_int, [c_void_p, c_int, c_int, c_u32, c_void_p, c_size_t, c_void_p]),
+    "zk_ntt_batch": (c_int, [c_void_p, c_int, c_int, c_u32, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t),
+                             ctypes.POINTER(c_void_p)]),
     "zk_ntt_batch_dev": (c_int, [c_void_p, c_int, c_int, c_u32, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t),
                                  ctypes.POINTER(c_void_p)]),
     "zk_ntt_prepare": (c_int, [c_void_p, c_int, c_u32]),

@@ -285,6 +285,17 @@ int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in
     return ZK_OK;
 }
 
+int zk_ntt_batch(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const uint64_t* const* ins, const size_t* in_lens,
+                 uint64_t* const* outs) {
+    if (!c || (n_polys && (!ins || !in_lens || !outs))) return ZK_ERR_BAD_ARG;
+    Guard g(c);   // one lock for the whole batch; the transforms share the plan
+    for (uint32_t i = 0; i < n_polys; ++i) {
+        int rc = zk_ntt(c, curve_id, kind, log_n, ins[i], in_lens[i], outs[i]);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+
 int zk_fr_from_mont_dev(zk_ctx* c, int curve_id, const void* d_in, size_t n, void* d_out) {
     if (!c || (n && (!d_in || !d_out))) return ZK_ERR_BAD_ARG;
     Guard g(c);

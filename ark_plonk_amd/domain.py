@@ -114,6 +114,41 @@ class Radix2EvaluationDomain:
     def coset_ifft(self, evals):
         return self._run(KIND_COSET_IFFT, evals)
 
+    def batch(self, kind: int, polys):
+        """n_polys transforms of one kind sharing the plan (the 13 coset_fft of quotient_poly.rs:72-120):
+        host arrays -> zk_ntt_batch, device tensors -> zk_ntt_batch_dev.  Returns the list of outputs."""
+        import ctypes
+        polys = list(polys)
+        k = len(polys)
+        if k == 0:
+            return []
+        cid, n = self.curve.curve_id, self._size
+        ctx = self._ctx_for(polys[0])
+        ins = (ctypes.c_void_p * k)()
+        outs = (ctypes.c_void_p * k)()
+        lens = (ctypes.c_size_t * k)()
+        if _is_torch(polys[0]):
+            import torch
+            res = []
+            for i, x in enumerate(polys):
+                lens[i] = check_dev_tensor(x, 4, ctx.device)
+                if lens[i] > n:
+                    raise ValueError("input longer than the domain")
+                res.append(torch.empty((n, 4), dtype=x.dtype, device=x.device))
+                ins[i], outs[i] = x.data_ptr(), res[i].data_ptr()
+            ctx.use_torch_stream()
+            check(lib().zk_ntt_batch_dev(ctx.handle, cid, kind, self._log, k, ins, lens, outs), "zk_ntt_batch_dev")
+            return res
+        arrs = [as_host_u64(x, 4) for x in polys]
+        res = [np.empty((n, 4), dtype=np.uint64) for _ in arrs]
+        for i, a in enumerate(arrs):
+            if a.shape[0] > n:
+                raise ValueError("input longer than the domain")
+            lens[i] = a.shape[0]
+            ins[i], outs[i] = a.ctypes.data, res[i].ctypes.data
+        check(lib().zk_ntt_batch(ctx.handle, cid, kind, self._log, k, ins, lens, outs), "zk_ntt_batch")
+        return res
+
     def _in_place(self, kind, buf):
         if _is_torch(buf):
             if buf.numel() != 4 * self._size:

@@ -72,7 +72,7 @@ def build_srs(ctx, cv, n, lo, hi, torch):
     return out
 
 
-def cpu_baseline(log_n: int):
+def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255):
     """Bounded sample of the same workload on the host cores with the oracle's CPU restatement."""
     from oracle import cpu
     cpu.build()
@@ -81,29 +81,29 @@ def cpu_baseline(log_n: int):
     s_ntt = min(log_n, 18)
     s_msm = min(log_n, 16)
     x = rng.integers(0, 1 << 62, size=(1 << s_ntt, 4), dtype=np.uint64)
-    cpu.ntt(0, 1, 10, x[:1024])  # warm OpenMP
+    cpu.ntt(cid, 1, 10, x[:1024])  # warm OpenMP
     t0 = time.perf_counter()
-    cpu.ntt(0, 1, s_ntt, x)
+    cpu.ntt(cid, 1, s_ntt, x)
     t_ntt_n = time.perf_counter() - t0
     t0 = time.perf_counter()
-    cpu.ntt(0, 2, s_ntt + 2, x)
+    cpu.ntt(cid, 2, s_ntt + 2, x)
     t_ntt_4n = time.perf_counter() - t0
-    srs = cpu.srs_powers(0, 0x7A5C0DE, 1 << 10)
+    srs = cpu.srs_powers(cid, 0x7A5C0DE, 1 << 10)
     bases = np.tile(srs, ((1 << s_msm) >> 10, 1))
     sc = rng.integers(0, 1 << 62, size=(1 << s_msm, 4), dtype=np.uint64)
     t0 = time.perf_counter()
-    cpu.msm_g1(0, bases, sc, threads=cores)
+    cpu.msm_g1(cid, bases, sc, threads=cores)
     t_msm = time.perf_counter() - t0
     # scale to the benchmark size by the reference-equivalent operation counts
     bf = lambda k: (1 << k) // 2 * k  # noqa: E731
     t_proof = (17 * t_ntt_n * bf(log_n) / bf(s_ntt) + 14 * t_ntt_4n * bf(log_n + 2) / bf(s_ntt + 2)
-               + 29 * t_msm * ark_adds(1 << log_n) / ark_adds(1 << s_msm))
+               + 29 * t_msm * ark_adds(1 << log_n, bits) / ark_adds(1 << s_msm, bits))
     return {
         "value": 1.0 / t_proof, "unit": "proofs/s", "cores": cores, "kind": "port",
         "sample": f"oracle/ark_cpu.cpp (OpenMP): ifft 2^{s_ntt} {t_ntt_n:.3f}s, coset_fft 2^{s_ntt + 2} {t_ntt_4n:.3f}s, "
                   f"MSM 2^{s_msm} {t_msm:.3f}s (threads over windows as ark/rayon); scaled to n=2^{log_n} by butterfly / "
                   f"G1-add counts x the 17+14 NTT, 29 MSM per-proof schedule",
-        "msm_adds_per_s": ark_adds(1 << s_msm) / t_msm,
+        "msm_adds_per_s": ark_adds(1 << s_msm, bits) / t_msm,
     }
 
 
@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"],
+                    help="bn254 = BASELINE.json's second-curve config (same kernels, 4-limb base field); the headline is bls12_381")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
@@ -155,7 +157,8 @@ def main():
     dev = torch.cuda.current_device()
     ctx = zk.Context(dev)
     ctx.use_torch_stream()
-    cv = zk.get_curve("bls12_381")
+    cv = zk.get_curve(args.curve)
+    sbits = cv.r.bit_length()
     log_n = args.log_n
     n = 1 << log_n
     steps = args.steps
@@ -263,19 +266,19 @@ def main():
     ntt_ms, ntt_n = r["prof"]["ntt_pass"]
     sort_ms, _ = r["prof"]["msm_sort"]
     red_ms, _ = r["prof"]["msm_reduce"]
-    alg_bytes = 128.0 * r["points_per_launch"]               # 32 B scalar + 96 B affine base, once
+    alg_bytes = (32.0 + 16.0 * cv.fq_limbs) * r["points_per_launch"]   # 32 B scalar + packed affine base (96 B BLS12-381), once
     avg_s = (acc_ms / max(acc_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if acc_n else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
-    if os.path.exists(pmc_path) and not main_sharded and log_n == 20:
+    if os.path.exists(pmc_path) and not main_sharded and log_n == 20 and cv.curve_id == 0:
         try:
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     msm_total_s = (acc_ms + sort_ms + red_ms) * 1e-3
     valu = None
-    if acc_n and not args.no_precompute:
+    if acc_n and not args.no_precompute and cv.curve_id == 0:
         madds = 16.0 * r["points_per_launch"]               # one mixed addition per (16-bit window, point)
         mac_s = madds * MADD_MADS / avg_s
         peak_mac_s = LANES * CLOCK_HZ / MAD_CYCLES_FULL
@@ -297,14 +300,14 @@ def main():
         "scaling": "strong" if main_sharded else "weak",
         "vs_baseline": None, "dtype": "u32 limbs (256/384-bit Montgomery integers)", "data": "synthetic",
         "config": {"workload": f"per-proof hot path of Prover::prove at n=2^{log_n}: 13 ifft(n)+4 fft(n)+13 coset_fft(4n)+"
-                               f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), BLS12-381, SRS+inputs HBM-resident",
-                   "log_n": log_n, "curve": "bls12_381", "parallelism": par},
+                               f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident",
+                   "log_n": log_n, "curve": cv.name, "parallelism": par},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes,
                      "valu": valu},
         # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
-        "msm_g1_adds_per_s": ((29 * kp * ark_adds(n)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
+        "msm_g1_adds_per_s": ((29 * kp * ark_adds(n, sbits)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
                               if (msm_total_s and S == 1) else None),
         "msm_ms_per_proof": msm_total_s / kp * 1e3,
         "ntt_GBps": (r["ntt_bytes"] * kp) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
@@ -346,7 +349,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(log_n)
+                line["cpu_baseline"] = cpu_baseline(log_n, cv.curve_id, sbits)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)

@@ -95,6 +95,9 @@ int zk_domain_new(int curve_id, uint64_t num_coeffs, zk_domain_info* out);
  * out: 2^log_n elements, natural order.  in == out allowed.
  * Replaces ark_poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place. */
 int zk_ntt(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, const uint64_t* in, size_t in_len, uint64_t* out);
+/* n_polys host-buffer transforms of one kind and size; ins[i] == outs[i] allowed. */
+int zk_ntt_batch(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const uint64_t* const* ins,
+                 const size_t* in_lens, uint64_t* const* outs);
 /* Same with device-resident buffers (async on the ctx stream).  d_in == d_out allowed. */
 int zk_ntt_dev(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out);
 /* n_polys transforms of one kind/size sharing a plan (the 13 coset_fft of quotient_poly.rs:72-120). */

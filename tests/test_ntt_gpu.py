@@ -69,6 +69,23 @@ def test_edge_cases(cid, ctx, oracle_cpu):
     assert zk.Radix2EvaluationDomain.new((1 << bo.CURVES[cid].two_adicity) + 1, cid, ctx) is None
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_batch_entry_points(cid, ctx, oracle_cpu):
+    """zk_ntt_batch (host) and zk_ntt_batch_dev: ragged inputs, one plan; each output equals the single call."""
+    import torch
+    cv = bo.CURVES[cid]
+    dom = zk.Radix2EvaluationDomain.new(1 << 11, cid, ctx)
+    polys = [oracle_cpu.convert(cid, "fr", True, oracle_cpu.ints_to_limbs(bo.seeded_scalars(cv, 40 + k, ln), 4))
+             for k, ln in enumerate((2048, 512, 1, 0, 2047))]
+    for kind in (0, 1, 2, 3):
+        exp = [oracle_cpu.ntt(cid, kind, 11, p) for p in polys]
+        got = dom.batch(kind, polys)
+        dev = dom.batch(kind, [torch.from_numpy(p.view(np.int64)).cuda() for p in polys])
+        for e, g, d in zip(exp, got, dev):
+            assert np.array_equal(g, e)
+            assert np.array_equal(d.cpu().numpy().view(np.uint64), e)
+
+
 @pytest.mark.parametrize("log_n", [20, 22])
 def test_large_device_properties(log_n, ctx, oracle_cpu):
     """BASELINE sizes, device-resident: parity with the CPU oracle at 2^20, and size-independent

@@ -17,6 +17,7 @@ ZK_ERR_HIP = -3
 ZK_ERR_OOM = -4
 ZK_ERR_NO_DEVICE = -5
 ZK_ERR_UNSUPPORTED = -6
+ZK_ERR_NOT_INVERTIBLE = -7
 
 c_void_p = ctypes.c_void_p
 c_size_t = ctypes.c_size_t
@@ -72,6 +73,10 @@ SYMBOLS = {
     "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_msm_g1_srs_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_msm_g1_srs_partial_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "zk_perm_product_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "zk_lookup_product_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "zk_g1_sum_partials": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_g1_sum_partials_batch": (c_int, [c_int, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_kzg_commit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

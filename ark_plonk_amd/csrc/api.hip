@@ -117,6 +117,7 @@ const char* zk_strerror(int code) {
     case ZK_ERR_OOM: return "out of device memory";
     case ZK_ERR_NO_DEVICE: return "no usable HIP device";
     case ZK_ERR_UNSUPPORTED: return "size not supported";
+    case ZK_ERR_NOT_INVERTIBLE: return "zero denominator in a grand product";
     default: return "unknown error";
     }
 }
@@ -614,6 +615,26 @@ int zk_dev_download(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     if (bytes) ZK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------ N2: grand products
+int zk_perm_product_dev(zk_ctx* c, int curve_id, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas,
+                        const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont) {
+    if (!c || !d_wires || !d_sigmas || !beta_mont || !gamma_mont || !d_out) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    if (log_n > 32) return ZK_ERR_DOMAIN_TOO_LARGE;
+    for (int k = 0; k < 4; ++k)
+        if (!d_wires[k] || !d_sigmas[k]) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return perm_product_dev(c, curve_id, log_n, d_wires, d_sigmas, beta_mont, gamma_mont, d_out, last_mont);
+}
+
+int zk_lookup_product_dev(zk_ctx* c, int curve_id, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2,
+                          const uint64_t* delta_mont, const uint64_t* epsilon_mont, void* d_out, uint64_t* last_mont) {
+    if (!c || !n || !d_f || !d_t || !d_h1 || !d_h2 || !delta_mont || !epsilon_mont || !d_out) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return lookup_product_dev(c, curve_id, n, d_f, d_t, d_h1, d_h2, delta_mont, epsilon_mont, d_out, last_mont);
 }
 
 }  // extern "C"

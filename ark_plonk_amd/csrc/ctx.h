@@ -194,5 +194,9 @@ int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint
 size_t msm_point_bytes(int curve);
 int g1_jacobian_to_affine_host(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 int g1_sum_partials_host(int curve, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+int perm_product_dev(zk_ctx* c, int curve, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas,
+                     const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont);
+int lookup_product_dev(zk_ctx* c, int curve, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2,
+                       const uint64_t* delta_mont, const uint64_t* eps_mont, void* d_out, uint64_t* last_mont);
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                          const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);

@@ -1,0 +1,280 @@
+// Grand-product builders: the evaluation vectors of the permutation polynomial
+// z(X) and the lookup polynomial z2(X), on the device, feeding the iNTT directly.
+//
+// Reference: plonk-core/src/permutation/mod.rs:652-752 (`compute_permutation_poly`) and :754-822
+// (`compute_lookup_permutation_poly` / `lookup_ratio`), both up to -- not including -- their final
+// `domain.ifft`.  The reference walks the rows serially, inverting one denominator per row:
+//     z[0] = 1,   z[i+1] = z[i] * num_i / den_i,   the (n+1)-th value dropped.
+// Here, with PN_i = prod_{j<i} num_j, SD_i = prod_{j>=i} den_j and T = prod_j den_j:
+//     z[i] = PN_i / prod_{j<i} den_j = PN_i * SD_i * T^-1
+// i.e. two product scans (prefix of num, suffix of den: chunk products -> one-workgroup scan of the
+// chunk products -> per-chunk replay), ONE field inversion on the host, one elementwise product.
+// Field elements are canonical Montgomery residues, so the result is bit-identical with the serial loop.
+// A zero denominator makes the reference panic (`inverse().unwrap()`); here it is ZK_ERR_NOT_INVERTIBLE.
+#include "ctx.h"
+
+namespace {
+
+template <class Fr>
+ZK_D Fr ld_fr(const void* base, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <class Fr>
+ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+constexpr uint32_t TERM_T = 256;     // lanes per workgroup of the term kernels
+constexpr uint32_t TERM_ROWS = 8;    // rows per lane (row = blk*T*ROWS + j*T + lane: coalesced)
+constexpr uint32_t CHUNK = 64;       // rows per lane in the scan phases
+constexpr uint32_t SCAN_T = 1024;    // lanes of the single scan workgroup
+
+template <class Fr>
+struct PermArgs {
+    const void* w[4];
+    const void* s[4];
+    Fr beta, gamma;
+    Fr bk[4];        // beta * K_k, K = (1, 7, 13, 17)  (permutation/constants.rs:12-22)
+    Fr omega;        // group generator of the size-n domain
+    Fr omega_t;      // omega^TERM_T
+};
+
+// num_i = prod_k (w_k[i] + beta*K_k*omega^i + gamma),  den_i = prod_k (w_k[i] + beta*sigma_k[i] + gamma)
+// (numerator_irreducible / denominator_irreducible, permutation/mod.rs:626-647)
+template <class Fr>
+__global__ void __launch_bounds__(TERM_T) gp_perm_terms(PermArgs<Fr> a, uint64_t n, void* N, void* D) {
+    const uint64_t base = (uint64_t)blockIdx.x * TERM_T * TERM_ROWS + threadIdx.x;
+    if (base >= n) return;
+    Fr root = Fr::pow_u64(a.omega, base);
+    for (uint32_t j = 0; j < TERM_ROWS; ++j) {
+        const uint64_t i = base + (uint64_t)j * TERM_T;
+        if (i >= n) break;
+        Fr num, den;
+        for (int k = 0; k < 4; ++k) {
+            Fr wg = Fr::add(ld_fr<Fr>(a.w[k], i), a.gamma);
+            Fr nk = Fr::add(wg, Fr::mul(a.bk[k], root));
+            Fr dk = Fr::add(wg, Fr::mul(a.beta, ld_fr<Fr>(a.s[k], i)));
+            num = k == 0 ? nk : Fr::mul(num, nk);
+            den = k == 0 ? dk : Fr::mul(den, dk);
+        }
+        st_fr<Fr>(N, i, num);
+        st_fr<Fr>(D, i, den);
+        root = Fr::mul(root, a.omega_t);
+    }
+}
+
+template <class Fr>
+struct LookupArgs {
+    const void *f, *t, *h1, *h2;
+    Fr delta, one_plus_delta, eps, eps_opd;   // eps_opd = epsilon * (1 + delta)
+};
+
+// lookup_ratio (permutation/mod.rs:802-822), numerator and denominator kept apart:
+//   num_i = (1+d)(e + f_i)(e(1+d) + t_i + d t_{i+1}),  den_i = (e(1+d) + h1_i + d h2_i)(e(1+d) + h2_i + d h1_{i+1})
+// with the cyclic "next" of mod.rs:771-772.
+template <class Fr>
+__global__ void __launch_bounds__(TERM_T) gp_lookup_terms(LookupArgs<Fr> a, uint64_t n, void* N, void* D) {
+    const uint64_t i = (uint64_t)blockIdx.x * TERM_T + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t nx = i + 1 == n ? 0 : i + 1;
+    Fr f = ld_fr<Fr>(a.f, i), t = ld_fr<Fr>(a.t, i), tn = ld_fr<Fr>(a.t, nx);
+    Fr h1 = ld_fr<Fr>(a.h1, i), h1n = ld_fr<Fr>(a.h1, nx), h2 = ld_fr<Fr>(a.h2, i);
+    Fr num = Fr::mul(Fr::mul(a.one_plus_delta, Fr::add(a.eps, f)), Fr::add(Fr::add(a.eps_opd, t), Fr::mul(a.delta, tn)));
+    Fr den = Fr::mul(Fr::add(Fr::add(a.eps_opd, h1), Fr::mul(h2, a.delta)), Fr::add(Fr::add(a.eps_opd, h2), Fr::mul(h1n, a.delta)));
+    st_fr<Fr>(N, i, num);
+    st_fr<Fr>(D, i, den);
+}
+
+// phase 1: P[c] = prod of chunk c
+template <class Fr>
+__global__ void gp_chunk_prod(const void* X, uint64_t n, void* P, uint64_t n_chunks) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
+    Fr acc = ld_fr<Fr>(X, lo);
+    for (uint64_t i = lo + 1; i < hi; ++i) acc = Fr::mul(acc, ld_fr<Fr>(X, i));
+    st_fr<Fr>(P, c, acc);
+}
+
+// phase 2 (one workgroup): A[c] = product of the chunk products before c (suffix == 0) or after c
+// (suffix == 1) -- the value entering chunk c; A[n_chunks] = product of everything.
+template <class Fr>
+__global__ void __launch_bounds__(SCAN_T) gp_scan_chunks(const void* P, uint64_t n_chunks, int suffix, void* A) {
+    extern __shared__ uint4 sh[];
+    const uint32_t u = threadIdx.x;
+    const uint64_t per = (n_chunks + SCAN_T - 1) / SCAN_T;
+    const uint64_t lo = (uint64_t)u * per < n_chunks ? (uint64_t)u * per : n_chunks;
+    const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
+    Fr loc = Fr::one();
+    for (uint64_t c = lo; c < hi; ++c) loc = Fr::mul(loc, ld_fr<Fr>(P, c));
+    // inclusive Hillis-Steele scan of the lane products (towards lane 0 for suffix, towards the last lane else)
+    Fr inc = loc;
+    for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
+        st_fr<Fr>(sh, u, inc);
+        __syncthreads();
+        const bool has = suffix ? (u + d < SCAN_T) : (u >= d);
+        if (has) inc = Fr::mul(inc, ld_fr<Fr>(sh, suffix ? u + d : u - d));
+        __syncthreads();
+    }
+    st_fr<Fr>(sh, u, inc);
+    __syncthreads();
+    Fr carry = Fr::one();
+    if (suffix) {
+        if (u + 1 < SCAN_T) carry = ld_fr<Fr>(sh, u + 1);
+        for (uint64_t c = hi; c-- > lo;) {
+            st_fr<Fr>(A, c, carry);
+            carry = Fr::mul(carry, ld_fr<Fr>(P, c));
+        }
+        if (u == 0) st_fr<Fr>(A, n_chunks, inc);
+    } else {
+        if (u >= 1) carry = ld_fr<Fr>(sh, u - 1);
+        for (uint64_t c = lo; c < hi; ++c) {
+            st_fr<Fr>(A, c, carry);
+            carry = Fr::mul(carry, ld_fr<Fr>(P, c));
+        }
+        if (u == SCAN_T - 1) st_fr<Fr>(A, n_chunks, inc);
+    }
+}
+
+// phase 3, in place: exclusive prefix products (suffix == 0: X[i] <- prod_{j<i}) or inclusive suffix
+// products (suffix == 1: X[i] <- prod_{j>=i})
+template <class Fr>
+__global__ void gp_apply(void* X, uint64_t n, const void* A, int suffix, uint64_t n_chunks) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
+    Fr carry = ld_fr<Fr>(A, c);
+    if (suffix) {
+        for (uint64_t i = hi; i-- > lo;) {
+            carry = Fr::mul(carry, ld_fr<Fr>(X, i));
+            st_fr<Fr>(X, i, carry);
+        }
+    } else {
+        for (uint64_t i = lo; i < hi; ++i) {
+            Fr x = ld_fr<Fr>(X, i);
+            st_fr<Fr>(X, i, carry);
+            carry = Fr::mul(carry, x);
+        }
+    }
+}
+
+// z[i] = PN_i * SD_i * T^-1
+template <class Fr>
+__global__ void gp_combine(const void* PN, const void* SD, Fr inv_t, uint64_t n, void* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_fr<Fr>(out, i, Fr::mul(Fr::mul(ld_fr<Fr>(PN, i), ld_fr<Fr>(SD, i)), inv_t));
+}
+
+// N (numerators) and D (denominators) are in c->io_a / c->io_b; finishes the product into d_out
+template <class Fr>
+int finish_product(zk_ctx* c, uint64_t n, void* d_out, uint64_t* last_mont) {
+    void* N = c->io_a.p;
+    void* D = c->io_b.p;
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    int rc;
+    // chunk products | chunk carries (+ total), for N then D
+    if ((rc = c->msm_tmp.ensure(4 * (n_chunks + 1) * 32))) return rc;
+    char* t = (char*)c->msm_tmp.p;
+    void *PNc = t, *ANc = t + (n_chunks + 1) * 32, *PDc = t + 2 * (n_chunks + 1) * 32, *ADc = t + 3 * (n_chunks + 1) * 32;
+    hipStream_t st = c->stream;
+    const int T = 256;
+    const unsigned cb = (unsigned)((n_chunks + T - 1) / T);
+    const size_t shmem = (size_t)SCAN_T * 32;
+    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb), dim3(T), 0, st, N, n, PNc, n_chunks);
+    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb), dim3(T), 0, st, D, n, PDc, n_chunks);
+    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(1), dim3(SCAN_T), shmem, st, PNc, n_chunks, 0, ANc);
+    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(1), dim3(SCAN_T), shmem, st, PDc, n_chunks, 1, ADc);
+    ZK_HIP_TRY(hipGetLastError());
+    Fr tot[2];   // total numerator product, total denominator product
+    ZK_HIP_TRY(hipMemcpyAsync(&tot[0], (char*)ANc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipMemcpyAsync(&tot[1], (char*)ADc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb), dim3(T), 0, st, N, n, ANc, 0, n_chunks);
+    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb), dim3(T), 0, st, D, n, ADc, 1, n_chunks);
+    ZK_HIP_TRY(hipStreamSynchronize(st));
+    if (tot[1].is_zero()) return ZK_ERR_NOT_INVERTIBLE;
+    Fr inv_t = Fr::inverse(tot[1]);
+    hipLaunchKernelGGL(gp_combine<Fr>, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, N, D, inv_t, n, d_out);
+    ZK_HIP_TRY(hipGetLastError());
+    if (last_mont) {
+        Fr last = Fr::mul(tot[0], inv_t);
+        memcpy(last_mont, last.v, 32);
+    }
+    return ZK_OK;
+}
+
+template <class C>
+int perm_product(zk_ctx* c, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas, const uint64_t* beta_mont,
+                 const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont) {
+    typedef typename C::Fr Fr;
+    if (log_n > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+    const uint64_t n = 1ull << log_n;
+    int rc;
+    if ((rc = c->io_a.ensure(n * 32))) return rc;
+    if ((rc = c->io_b.ensure(n * 32))) return rc;
+    PermArgs<Fr> a;
+    memcpy(a.beta.v, beta_mont, 32);
+    memcpy(a.gamma.v, gamma_mont, 32);
+    const uint32_t K[4] = {1, 7, 13, 17};
+    for (int k = 0; k < 4; ++k) {
+        a.w[k] = d_wires[k];
+        a.s[k] = d_sigmas[k];
+        a.bk[k] = Fr::mul(a.beta, Fr::from_u32(K[k]));
+    }
+    Fr root;
+    for (int i = 0; i < Fr::N; ++i) root.v[i] = C::FrP::ROOT(i);
+    for (uint32_t k = log_n; k < (uint32_t)C::FrP::TWO_ADICITY; ++k) root = Fr::sqr(root);
+    a.omega = root;
+    a.omega_t = Fr::pow_u64(root, TERM_T);
+    ProfScope ps(c, "grand_product");
+    const unsigned blocks = (unsigned)((n + (uint64_t)TERM_T * TERM_ROWS - 1) / ((uint64_t)TERM_T * TERM_ROWS));
+    hipLaunchKernelGGL(gp_perm_terms<Fr>, dim3(blocks), dim3(TERM_T), 0, c->stream, a, n, c->io_a.p, c->io_b.p);
+    ZK_HIP_TRY(hipGetLastError());
+    return finish_product<Fr>(c, n, d_out, last_mont);
+}
+
+template <class C>
+int lookup_product(zk_ctx* c, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2, const uint64_t* delta_mont,
+                   const uint64_t* eps_mont, void* d_out, uint64_t* last_mont) {
+    typedef typename C::Fr Fr;
+    int rc;
+    if ((rc = c->io_a.ensure(n * 32))) return rc;
+    if ((rc = c->io_b.ensure(n * 32))) return rc;
+    LookupArgs<Fr> a;
+    a.f = d_f;
+    a.t = d_t;
+    a.h1 = d_h1;
+    a.h2 = d_h2;
+    memcpy(a.delta.v, delta_mont, 32);
+    memcpy(a.eps.v, eps_mont, 32);
+    a.one_plus_delta = Fr::add(Fr::one(), a.delta);
+    a.eps_opd = Fr::mul(a.eps, a.one_plus_delta);
+    ProfScope ps(c, "grand_product");
+    hipLaunchKernelGGL(gp_lookup_terms<Fr>, dim3((unsigned)((n + TERM_T - 1) / TERM_T)), dim3(TERM_T), 0, c->stream, a, (uint64_t)n, c->io_a.p,
+                       c->io_b.p);
+    ZK_HIP_TRY(hipGetLastError());
+    return finish_product<Fr>(c, n, d_out, last_mont);
+}
+
+}  // namespace
+
+int perm_product_dev(zk_ctx* c, int curve, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas,
+                     const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont) {
+    if (curve == ZK_CURVE_BLS12_381) return perm_product<CurveBls>(c, log_n, d_wires, d_sigmas, beta_mont, gamma_mont, d_out, last_mont);
+    if (curve == ZK_CURVE_BN254) return perm_product<CurveBn>(c, log_n, d_wires, d_sigmas, beta_mont, gamma_mont, d_out, last_mont);
+    return ZK_ERR_BAD_ARG;
+}
+
+int lookup_product_dev(zk_ctx* c, int curve, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2,
+                       const uint64_t* delta_mont, const uint64_t* eps_mont, void* d_out, uint64_t* last_mont) {
+    if (curve == ZK_CURVE_BLS12_381) return lookup_product<CurveBls>(c, n, d_f, d_t, d_h1, d_h2, delta_mont, eps_mont, d_out, last_mont);
+    if (curve == ZK_CURVE_BN254) return lookup_product<CurveBn>(c, n, d_f, d_t, d_h1, d_h2, delta_mont, eps_mont, d_out, last_mont);
+    return ZK_ERR_BAD_ARG;
+}

@@ -23,7 +23,8 @@ from .msm import CommitterKey, sum_partials_batch
 
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
-                 dist=None, seed: int = 0x5EED0000, dedup: bool = False):
+                 dist=None, seed: int = 0x5EED0000, dedup: bool = False,
+                 grand_products: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -35,6 +36,9 @@ class ProofSchedule:
         # commitments cached by polynomial label, so the 12 polynomials the reference
         # commits a second time in round 5 (prover.rs:569-607) cost no MSM: 29 -> 17 per proof, same outputs
         self.dedup = dedup
+        # z and z2 evaluation vectors built on the device from the wire / sigma /
+        # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
+        self.grand_products = grand_products
         self._cache = {}
         self.msms_run = 0
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
@@ -115,11 +119,17 @@ class ProofSchedule:
         c[7] = d.ifft(self.aux_evals[3])          # h2
         out += self._commit_round([c[6], c[7]], labels=["h1", "h2"])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
-        for i in range(4):
-            d.fft(self.sigma[i])
-        c[8] = d.ifft(self.aux_evals[4])          # z
+        sig = [d.fft(self.sigma[i]) for i in range(4)]
+        z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
+        if self.grand_products:
+            from . import permutation
+            z_evals = permutation.permutation_evals(d, self.evals, sig, self.chi_mont, self.z_mont)       # beta, gamma
+        c[8] = d.ifft(z_evals)                    # z
         out += self._commit_round([c[8]], labels=["z"])
-        c[9] = d.ifft(self.aux_evals[5])          # z2
+        if self.grand_products:
+            z2_evals = permutation.lookup_permutation_evals(self.ctx, self.cv, self.aux_evals[1], self.aux_evals[0], self.aux_evals[2],
+                                                            self.aux_evals[3], self.chi_mont, self.z_mont)  # f, t, h1, h2; delta, epsilon
+        c[9] = d.ifft(z2_evals)                   # z2
         out += self._commit_round([c[9]], labels=["z2"])
         c[10] = d.ifft(self.aux_evals[6])         # pi
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)

@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="replica mode: skip the extra sharded-MSM leg")
     ap.add_argument("--dedup", action="store_true",
                     help="NOT the headline workload: commitments cached by polynomial label (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
+    ap.add_argument("--grand-products", action="store_true",
+                    help="also build the z / z2 evaluation vectors on the device (SURVEY.md 8f N2) inside each step")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     args = ap.parse_args()
@@ -196,9 +198,9 @@ def main():
                 if not args.no_precompute:
                     ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
                 if sharded:
-                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup)
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products)
                 else:
-                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup)
+                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products)
                 pts = None
                 for _ in range(args.warmup):
                     pts = sched.run_once()
@@ -242,7 +244,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce")}
+        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product")}
         digs = []
         if args.check:
             for ln in lanes:
@@ -313,6 +315,10 @@ def main():
         "ntt_GBps": (r["ntt_bytes"] * kp) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
         "ntt_ms_per_proof": ntt_ms / kp,
     }
+    if args.grand_products:
+        gp_ms, gp_n = r["prof"]["grand_product"]
+        line["config"]["workload"] += " + z and z2 grand products on device"
+        line["grand_product_ms_per_proof"] = gp_ms / kp
     if args.dedup:
         line["config"]["workload"] += " -- WITH commitment de-duplication: 17 MSMs computed, 12 served from the per-proof cache"
         line["msm_g1_adds_per_s"] = None

@@ -51,6 +51,7 @@ typedef struct zk_srs zk_srs;
 #define ZK_ERR_OOM (-4)
 #define ZK_ERR_NO_DEVICE (-5)
 #define ZK_ERR_UNSUPPORTED (-6)
+#define ZK_ERR_NOT_INVERTIBLE (-7) /* a grand-product denominator is zero (the reference panics: `inverse().unwrap()`) */
 
 const char* zk_strerror(int code);
 
@@ -182,6 +183,23 @@ int zk_kzg_open_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* cons
  * runs the opening MSM itself (e.g. sharded over GPUs with zk_msm_g1_srs_partial_dev). */
 int zk_kzg_witness_dev(zk_ctx* ctx, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                        const uint64_t* z_mont, const uint64_t* challenge_mont, void* d_out, size_t* out_len);
+
+/* ---- N2: grand-product builders, feeding the iNTT on device ------------------------ */
+/* Evaluations of the permutation polynomial z over the size-2^log_n domain, i.e. everything
+ * `Permutation::compute_permutation_poly` (permutation/mod.rs:652-752) does before its `domain.ifft`:
+ *   out[0] = 1,  out[i+1] = out[i] * prod_k (w_k[i] + beta*K_k*omega^i + gamma) / prod_k (w_k[i] + beta*sigma_k[i] + gamma),
+ * K = (1, 7, 13, 17) (permutation/constants.rs:12-22), the (n+1)-th value dropped as the reference does.
+ * d_wires[k], d_sigmas[k] (k = 0..3): n Montgomery Fr evaluations each (sigma_k = domain.fft(sigma poly k),
+ * mod.rs:671-676); beta, gamma: Montgomery Fr, 4 limbs, host.  d_out: n elements, may alias an input.
+ * last_mont (optional, host, 4 limbs): the dropped value -- 1 for a satisfied permutation.
+ * ZK_ERR_NOT_INVERTIBLE if a denominator is zero (the reference panics there). */
+int zk_perm_product_dev(zk_ctx* ctx, int curve_id, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas,
+                        const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont);
+/* Same for the lookup product z2 (`compute_lookup_permutation_poly` + `lookup_ratio`, mod.rs:754-822):
+ *   ratio_i = (1+d)(e + f_i)(e(1+d) + t_i + d t_{i+1}) / ((e(1+d) + h1_i + d h2_i)(e(1+d) + h2_i + d h1_{i+1})),
+ * indices cyclic; d = delta, e = epsilon.  n need not be a power of two. */
+int zk_lookup_product_dev(zk_ctx* ctx, int curve_id, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2,
+                          const uint64_t* delta_mont, const uint64_t* epsilon_mont, void* d_out, uint64_t* last_mont);
 
 /* ---- utilities (synthetic SRS for tests/bench; stands in for PC::setup, out of scope) --------- */
 /* out[i] = scalars[i] * G1 generator, affine Montgomery, device buffers. */

@@ -22,6 +22,11 @@ What is restated, and the reference call site each function stands behind:
   * kzg_commit/open   -- ark_poly_commit::kzg10::KZG10::{commit,open} semantics
                          (leading-zero stripping, into_repr, witness polynomial division),
                          called from prover.rs:213 and prover.rs:582-591.
+  * perm_product / lookup_product -- the serial loops of Permutation::compute_permutation_poly and
+                         ::compute_lookup_permutation_poly (plonk-core/src/permutation/mod.rs:652-752,
+                         754-822) up to their final domain.ifft; this code IS in
+                         the reference, and is restated line by line (row ratio, running product,
+                         (n+1)-th value dropped).
 External anchors used to pin constants (tests/test_oracle.py):
   * TWO_ADIC_ROOT_OF_UNITY of ark-bls12-381 Fr (decimal constant quoted in SURVEY.md 8a).
   * [2]G1 x-coordinate of BLS12-381 (the published compressed encoding a572cbea...f0f4e).
@@ -281,6 +286,47 @@ def kzg_open(curve: Curve, powers: list, polys: list, z: int, challenge: int):
 
 
 # ----------------------------------------------------------------------------- window rule (for add counting)
+# ----------------------------------------------------------------------------- grand products (N2)
+PERM_K = (1, 7, 13, 17)   # plonk-core/src/permutation/constants.rs:12-22 (K1, K2, K3; the first coset is H itself)
+
+
+def perm_product(curve: Curve, log_n: int, wires, sigmas, beta: int, gamma: int):
+    """Evaluations of z over the domain, permutation/mod.rs:652-752 before the ifft.
+    wires, sigmas: 4 lists of n canonical integers (sigmas = domain.fft of the sigma polynomials, mod.rs:671-676).
+    Returns (z[0..n), dropped (n+1)-th value)."""
+    p, n = curve.r, 1 << log_n
+    w = curve.root_of_unity(log_n)
+    state, root, z = 1, 1, []
+    for i in range(n):
+        z.append(state)
+        num = den = 1
+        for k in range(4):
+            num = num * ((wires[k][i] + beta * PERM_K[k] * root + gamma) % p) % p      # numerator_irreducible, mod.rs:626-636
+            den = den * ((wires[k][i] + beta * sigmas[k][i] + gamma) % p) % p          # denominator_irreducible, mod.rs:638-647
+        if den == 0:
+            raise ZeroDivisionError("zero denominator (the reference panics: inverse().unwrap(), mod.rs:727)")
+        state = state * num % p * pow(den, -1, p) % p
+        root = root * w % p
+    return z, state
+
+
+def lookup_product(curve: Curve, f, t, h1, h2, delta: int, epsilon: int):
+    """Evaluations of z2, permutation/mod.rs:754-822 before the ifft.  Returns (p[0..n), dropped value)."""
+    p, n = curve.r, len(f)
+    opd = (1 + delta) % p
+    e1d = epsilon * opd % p
+    state, out = 1, []
+    for i in range(n):
+        out.append(state)
+        nx = (i + 1) % n                                                                # t_next / h_1_next, mod.rs:771-772
+        num = opd * ((epsilon + f[i]) % p) % p * ((e1d + t[i] + delta * t[nx]) % p) % p
+        den = ((e1d + h1[i] + h2[i] * delta) % p) * ((e1d + h2[i] + h1[nx] * delta) % p) % p
+        if den == 0:
+            raise ZeroDivisionError("zero denominator (lookup_ratio: inverse().unwrap(), mod.rs:820)")
+        state = state * num % p * pow(den, -1, p) % p
+    return out, state
+
+
 def ark_window_size(n: int) -> int:
     """ark-ec 0.3 variable_base.rs: c = 3 if n < 32 else ln_without_floats(n) + 2,
     ln_without_floats(a) = log2(a) * 69 / 100 with log2 = ceil(log2)."""

@@ -1,9 +1,13 @@
 """CPU suite: pins the oracle (C++ restatement of the ark 0.3 algorithms) against the definitional
 big-int oracle, the committed golden vectors and the external constants."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import bigint_oracle as bo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_external_constants():
@@ -111,3 +115,26 @@ def test_cpu_oracle_medium_properties(cid, oracle_cpu):
         assert evi[i] == bo.horner(vals, cv.fr_generator * pow(w, i, cv.r) % cv.r, cv.r)
     ev2 = oracle_cpu.ntt(cid, bo.KIND_FFT, log_n, vm)
     assert np.array_equal(oracle_cpu.ntt(cid, bo.KIND_IFFT, log_n, ev2)[: n // 4], vm)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_grand_product_oracle_matches_fixtures(cid):
+    """oracle/bigint_oracle.py perm_product / lookup_product (permutation/mod.rs:652-822) vs tests/golden/grand_product.npz,
+    and the closing property of a real wire permutation (the reference's own check, mod.rs:1243-1380)."""
+    import ark_plonk_amd.curves as cvs
+    gp = np.load(os.path.join(ROOT, "tests", "golden", "grand_product.npz"))
+    cv = bo.CURVES[cid]
+    ints = lambda a: cvs.fr_from_mont(cid, a)  # noqa: E731
+    for log_n in (3, 6):
+        pre = f"{cv.name}_perm{log_n}"
+        beta, gamma = ints(gp[f"{pre}_beta_gamma"])
+        z, last = bo.perm_product(cv, log_n, [ints(gp[f"{pre}_w{k}"]) for k in range(4)], [ints(gp[f"{pre}_s{k}"]) for k in range(4)], beta, gamma)
+        assert z == ints(gp[f"{pre}_z"]) and [last] == ints(gp[f"{pre}_last"])
+        pre = f"{cv.name}_look{log_n}"
+        delta, eps = ints(gp[f"{pre}_delta_eps"])
+        p, lastp = bo.lookup_product(cv, *[ints(gp[f"{pre}_{nm}"]) for nm in ("f", "t", "h1", "h2")], delta, eps)
+        assert p == ints(gp[f"{pre}_p"]) and [lastp] == ints(gp[f"{pre}_last"])
+    pre = f"{cv.name}_permv"
+    beta, gamma = ints(gp[f"{pre}_beta_gamma"])
+    z, last = bo.perm_product(cv, 4, [ints(gp[f"{pre}_w{k}"]) for k in range(4)], [ints(gp[f"{pre}_s{k}"]) for k in range(4)], beta, gamma)
+    assert z[0] == 1 and last == 1 and z == ints(gp[f"{pre}_z"]) and len(set(z)) > 8

@@ -41,3 +41,18 @@ def test_schedule_table_path_matches_plain_path_and_dedup(ctx, log_n):
     # round 5 re-commits polynomials of rounds 1-3 (prover.rs:569-607): outputs 13..19 and 21..27 repeat earlier ones
     assert tab[13] == tab[4] and tab[16] == tab[7] and tab[21] == tab[7] and tab[22] == tab[0]
     ck.close()
+
+
+def test_schedule_with_device_grand_products(ctx):
+    """N2 inside the schedule: z / z2 built on the device change exactly the outputs that depend on them."""
+    cv = zk.get_curve("bls12_381")
+    log_n = 11
+    ck = _ck(ctx, cv, 1 << log_n).precompute()
+    base = ProofSchedule(log_n, ctx, ck, cv).run_once()
+    gp = ProofSchedule(log_n, ctx, ck, cv, grand_products=True).run_once()
+    again = ProofSchedule(log_n, ctx, ck, cv, grand_products=True).run_once()
+    assert all(a == b for a, b in zip(gp, again))
+    same = [a == b for a, b in zip(base, gp)]
+    # rounds 1-2 (outputs 0..6) and the quotient commitments (9..12) do not involve z / z2 here
+    assert all(same[:7]) and all(same[9:13]) and not same[7] and not same[8]
+    ck.close()

@@ -5,6 +5,8 @@
 //   * products and squares are < 2p; stored coordinates are X, Y < 10p and ZZ, ZZZ < 2p;
 //   * a difference whose subtrahend is a product (or a sum of <= 3 products) uses sub8,
 //     a difference whose subtrahend is a stored coordinate uses sub16;
+//   * Y3 = R*(Q - X3) - Y1*PPP is ONE double product with one Montgomery reduction (Fu::dot2 against
+//     16p - Y1), so Y3 < 2p;
 //   * P == +-Q is detected on the *result*: ZZ3 = ZZ1*PP is a product (< 2p), so ZZ3 == 0 mod p
 //     iff it equals 0 or p -- two compares on one limb in the common path.
 // Infinity is ZZ = 0 with all limbs zero (only ever created explicitly).
@@ -50,7 +52,7 @@ struct XYZZu {
         F m = F::add3(xx, xx, xx);
         XYZZu r;
         r.x = F::sub8(F::sqr(m), F::dbl(s));
-        r.y = F::sub8(F::mul(m, F::sub16(s, r.x)), F::mul(w, p.y));
+        r.y = F::dot2(m, F::sub16(s, r.x), w, F::neg16(p.y));   // m*(s - x3) - w*y, one reduction
         r.zz = v;
         r.zzz = w;
         return r;
@@ -66,7 +68,7 @@ struct XYZZu {
         F m = F::add3(xx, xx, xx);
         XYZZu r;
         r.x = F::sub8(F::sqr(m), F::dbl(s));
-        r.y = F::sub8(F::mul(m, F::sub16(s, r.x)), F::mul(w, p.y));
+        r.y = F::dot2(m, F::sub16(s, r.x), w, F::neg16(p.y));
         r.zz = F::mul(v, p.zz);
         r.zzz = F::mul(w, p.zzz);
         return r;
@@ -90,7 +92,7 @@ struct XYZZu {
         F ppp = F::mul(pp_, pp);
         F qq = F::mul(p.x, pp);
         o.x = F::sub8(rr, F::add3(ppp, qq, qq));
-        o.y = F::sub8(F::mul(r_, F::sub16(qq, o.x)), F::mul(p.y, ppp));
+        o.y = F::dot2(r_, F::sub16(qq, o.x), F::neg16(p.y), ppp);   // r*(qq - x3) - y1*ppp, one reduction
         o.zzz = F::mul(p.zzz, ppp);
         return o;
     }
@@ -116,7 +118,7 @@ struct XYZZu {
         F ppp = F::mul(pp_, pp);
         F qq = F::mul(u1, pp);
         o.x = F::sub8(rr, F::add3(ppp, qq, qq));
-        o.y = F::sub8(F::mul(r_, F::sub16(qq, o.x)), F::mul(s1, ppp));
+        o.y = F::dot2(r_, F::sub16(qq, o.x), F::neg16(s1), ppp);
         o.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
         return o;
     }

@@ -97,6 +97,13 @@ struct Fu {
         normalize(t);
         return t;
     }
+    ZK_HD static Fu neg16(const Fu& a) {                 // 16p - a, a < 16p
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = P::Z16(i) - a.v[i];
+        normalize(t);
+        return t;
+    }
     ZK_HD static Fu neg_canonical(const Fu& a) {        // p - a for a <= p (affine input coordinates)
         Fu t;
 #pragma unroll
@@ -135,6 +142,45 @@ struct Fu {
             for (int i = k - NL + 1; i < NL; ++i) {
                 if (i & 1) a1 += (uint64_t)a.v[i] * b.v[k - i];
                 else a0 += (uint64_t)a.v[i] * b.v[k - i];
+                am += (uint64_t)m[i] * P::MOD(k - i);
+            }
+            uint64_t t = a0 + a1 + am + carry;
+            r.v[k - NL] = (uint32_t)t & M;
+            carry = t >> 29;
+        }
+        r.v[NL - 1] = (uint32_t)carry;
+        return r;
+    }
+    // (a*b + c*d)/R' with ONE Montgomery reduction (saves the NL^2 m*p products of a second one).
+    // Three independent accumulator chains per column; column total < 3*NL*2^58 + carry < 2^64 (NL <= 16).
+    // Output < (a*b + c*d)/R' + p: below 2p whenever a*b + c*d < R'*p -- use only on fields with
+    // SLACK_BITS >= 12 (the base fields), where that allows e.g. 1000p * 1000p.
+    ZK_HD static Fu dot2(const Fu& a, const Fu& b, const Fu& c, const Fu& d) {
+        uint32_t m[NL];
+        Fu r;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            uint64_t a0 = 0, a1 = 0, am = 0;
+#pragma unroll
+            for (int i = 0; i <= k; ++i) {
+                a0 += (uint64_t)a.v[i] * b.v[k - i];
+                a1 += (uint64_t)c.v[i] * d.v[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; ++i) am += (uint64_t)m[i] * P::MOD(k - i);
+            uint64_t t = a0 + a1 + am + carry;
+            m[k] = ((uint32_t)t * P::PINV) & M;
+            t += (uint64_t)m[k] * P::MOD(0);
+            carry = t >> 29;
+        }
+#pragma unroll
+        for (int k = NL; k < 2 * NL - 1; ++k) {
+            uint64_t a0 = 0, a1 = 0, am = 0;
+#pragma unroll
+            for (int i = k - NL + 1; i < NL; ++i) {
+                a0 += (uint64_t)a.v[i] * b.v[k - i];
+                a1 += (uint64_t)c.v[i] * d.v[k - i];
                 am += (uint64_t)m[i] * P::MOD(k - i);
             }
             uint64_t t = a0 + a1 + am + carry;

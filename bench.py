@@ -35,14 +35,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # The kernel is integer-VALU bound (SURVEY.md 8d asks for the u32-MAC rate next to the HBM fraction).
 # Instruction counts of the mixed-addition path of msm_accumulate (gfx950 ISA of this build, BLS12-381:
-# 8 products + 2 squares of 14 x 29-bit limbs) and the measured issue costs of profiles/r01_ubench_valu.txt.
-MADD_MADS = 3738            # v_mad_u64_u32 per mixed addition
-MADD_OTHER_VALU = 1316      # and/shift/add/mul_lo around them
+# 6 products + 2 squares + 1 double product of 14 x 29-bit limbs) and the measured issue costs of
+# profiles/r01_ubench_valu.txt.
+MADD_MADS = 3542            # v_mad_u64_u32 per mixed addition
+MADD_OTHER_VALU = 1221      # and/shift/add/mul_lo around them
 CLOCK_HZ = 2.4e9            # MI355X max engine clock (MI355X_MICROARCH.md chip table)
 LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
 MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
 # issue cycles of one mixed addition at the kernel's 2 waves/SIMD (220 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
-MADD_CYCLES_2WAVES = 3738 * 4.77 + 140 * 4.70 + 520 * 4.45 + 656 * 2.64
+MADD_CYCLES_2WAVES = 3542 * 4.77 + 126 * 4.70 + 468 * 4.45 + 627 * 2.64
 
 
 def ark_adds(n: int, bits: int = 255) -> int:

@@ -23,6 +23,12 @@ static void fu_binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out
         r = F::sqr(F::sub8(t, F::mul(x, y)));
         break;
     }
+    case 9:  // x*y + (x - y)(2x + y) with one reduction
+        r = F::dot2(x, y, F::sub16(x, y), F::add3(x, x, y));
+        break;
+    case 10:  // x*y - y*y through the negated operand
+        r = F::dot2(x, y, F::neg16(y), y);
+        break;
     default: r = F::zero();
     }
     r.to_sat(out);

@@ -123,6 +123,37 @@ __global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, int16
     }
 }
 
+// Two scalars per lane (n even; c = 16, W = 16): 32-byte vector loads, one 4-byte store per window instead of two 2-byte
+// ones.  MONT: the input is a Montgomery coefficient (a commit): into_repr is fused here instead of a
+// separate conversion pass over the vector.
+template <class Fr, bool MONT>
+__global__ void msm_digits2(const uint32_t* scalars, uint64_t n, MsmGeom g, int16_t* dig) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * t >= n) return;
+    uint32_t s[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (2 * t + h);
+        uint4 a = q[0], b = q[1];
+        Fr x;
+        x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+        x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+        if (MONT) x = Fr::from_mont(x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[h][i] = x.v[i];
+    }
+    // 16-bit windows, 16 of them (the window-table geometry): digit w is half-word w of the scalar
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        uint32_t r0 = ((s[0][w >> 1] >> (16 * (w & 1))) & 0xffffu) + c0;
+        uint32_t r1 = ((s[1][w >> 1] >> (16 * (w & 1))) & 0xffffu) + c1;
+        c0 = r0 >= 0x8000u ? 1u : 0u;     // raw >= 2^15 -> digit raw - 2^16 (its low 16 bits are unchanged), carry 1
+        c1 = r1 >= 0x8000u ? 1u : 0u;
+        *reinterpret_cast<uint32_t*>(dig + (uint64_t)w * n + 2 * t) = (r0 & 0xffffu) | (r1 << 16);
+    }
+}
+
 ZK_D void slab_range(uint64_t n, uint32_t S, uint32_t slab, uint64_t& lo, uint64_t& hi) {
     const uint64_t per = (n + S - 1) / S;
     lo = (uint64_t)slab * per;
@@ -878,7 +909,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 262144) pl.chunk_l >>= 1;
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
     pl.S = 1;
-    while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;
+    while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;   // 256 / 512 slabs measured slower (scans grow)
     pl.win_bytes = (size_t)2 * pl.gv.W * sizeof(PH);
     int rc;
     if ((rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
@@ -894,7 +925,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
 }
 
 template <class Cv>
-int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scalars, size_t n, hipStream_t st) {
+int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scalars, size_t n, hipStream_t st, bool mont = false) {
     uint32_t* hist = (uint32_t*)mb.counts.p;
     uint32_t* bsum = hist + (size_t)pl.S * pl.g.B;
     uint32_t* offsets = (uint32_t*)mb.offsets.p;
@@ -903,7 +934,21 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
     ProfScope ps(c, "msm_sort", st);
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
-    hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+    typedef typename Cv::Fr FrS;
+    if ((n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16) {
+        unsigned b2 = (unsigned)((n / 2 + T - 1) / T);
+        if (mont) hipLaunchKernelGGL((msm_digits2<FrS, true>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+        else hipLaunchKernelGGL((msm_digits2<FrS, false>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+    } else {
+        const void* canon = d_scalars;
+        if (mont) {   // odd length: separate into_repr pass, then the one-scalar-per-lane kernel
+            int rc = mb.scalars.ensure(n * 32);
+            if (rc) return rc;
+            if ((rc = fr_convert_stream(c, Cv::ID, d_scalars, n, mb.scalars.p, st))) return rc;
+            canon = mb.scalars.p;
+        }
+        hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)canon, (uint64_t)n, pl.g, dig);
+    }
     size_t lds = (size_t)pl.g.B * 4;
     if (lds > 48 * 1024) {
         ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1028,7 +1073,6 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     PrePlan pl[MAX_JOBS];
     for (uint32_t k = 0; k < n_polys; ++k) {
         if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[k], pl[k]))) return rc;
-        if ((rc = c->mb[k].scalars.ensure(lens[k] * 32))) return rc;
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
     }
     const size_t wb = pl[0].win_bytes;
@@ -1036,12 +1080,8 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     hipStream_t st = c->stream;
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[k];
-        const void* scal = d_coeffs[k];
-        if (!kinds || kinds[k] == 0) {
-            if ((rc = fr_convert_stream(c, s->curve, d_coeffs[k], lens[k], mb.scalars.p, st))) return rc;
-            scal = mb.scalars.p;
-        }
-        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, scal, lens[k], st))) return rc;
+        const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
+        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, d_coeffs[k], lens[k], st, mont))) return rc;
         if ((rc = pre_queue_accumulate<Cv>(c, pl[k], mb, s, 0, st))) return rc;
     }
     if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;

@@ -31,6 +31,7 @@ def jobs():
         ("api.o", "api.hip", [], HOST_HDRS),
         ("kzg.o", "kzg.hip", [], HOST_HDRS),
         ("grand_product.o", "grand_product.hip", [], HOST_HDRS),
+        ("quotient.o", "quotient.hip", [], HOST_HDRS),
         ("ntt.o", "ntt.hip", [], HOST_HDRS + ["ntt_pass.cuh"]),
         ("ntt_pass_table.o", "ntt_pass_table.hip", [], []),
         ("msm_dispatch.o", "msm_dispatch.hip", [], HOST_HDRS),

@@ -637,4 +637,13 @@ int zk_lookup_product_dev(zk_ctx* c, int curve_id, size_t n, const void* d_f, co
     return lookup_product_dev(c, curve_id, n, d_f, d_t, d_h1, d_h2, delta_mont, epsilon_mont, d_out, last_mont);
 }
 
+// ------------------------------------------------------------------------------ N1: quotient
+int zk_quotient_evals_dev(zk_ctx* c, int curve_id, uint32_t log_n, const zk_quotient_args* args, void* d_out) {
+    if (!c || !args || !d_out) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    if (log_n > 30) return ZK_ERR_DOMAIN_TOO_LARGE;
+    Guard g(c);
+    return quotient_evals_dev(c, curve_id, log_n, args, d_out);
+}
+
 }  // extern "C"

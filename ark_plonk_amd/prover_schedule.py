@@ -24,7 +24,7 @@ from .msm import CommitterKey, sum_partials_batch
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup: bool = False,
-                 grand_products: bool = False):
+                 grand_products: bool = False, quotient: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -39,6 +39,9 @@ class ProofSchedule:
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
         self.grand_products = grand_products
+        # the 4n quotient evaluations computed on the device from the 13 coset-FFT outputs
+        # and (synthetic) prover-key evaluations instead of taken as a synthetic input
+        self.quotient = quotient
         self._cache = {}
         self.msms_run = 0
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
@@ -60,6 +63,13 @@ class ProofSchedule:
         self.ev4n = torch.empty((4 * n, 4), dtype=torch.int64, device=dev)
         self.quot = rnd(4 * n)                            # quotient evaluations over the coset
         self.scratch_n = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        if quotient:
+            from .quotient import COLUMNS
+            self.key4n = {name: rnd(4 * n) for name in COLUMNS[12:]}     # selector evaluations of the prover key over the coset
+            self.sigma4n = [rnd(4 * n) for _ in range(4)]
+            self.cos = {name: torch.empty((4 * n, 4), dtype=torch.int64, device=dev) for name in COLUMNS[:12]}
+            self.q_chal = {name: np.array([0x1111 * (k + 1), 0x2222, 0x3333, 0x0444], dtype=np.uint64)
+                           for k, name in enumerate(__import__("ark_plonk_amd.quotient", fromlist=["CHALLENGES"]).CHALLENGES)}
         # shard of the SRS this rank owns
         self.lo = rank * n // world
         self.hi = (rank + 1) * n // world
@@ -134,11 +144,16 @@ class ProofSchedule:
         c[10] = d.ifft(self.aux_evals[6])         # pi
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         c[11] = d.ifft(self.aux_evals[7])         # l1
-        for poly in (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10]):
-            d4._run(2, poly, out=self.ev4n)       # coset_fft, n coefficients zero-extended to 4n
+        names = ("l1", "z", "w_l", "w_r", "w_o", "w_4", "z2", "f", "table", "h1", "h2", "pi")
+        for name, poly in zip(names, (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])):
+            d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)   # coset_fft, n coefficients zero-extended to 4n
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
-        t = d4.coset_ifft(self.quot)              # quotient polynomial, 4n coefficients
+        quot = self.quot
+        if self.quotient:
+            from .quotient import compute_quotient_evals
+            quot = compute_quotient_evals(d, {**self.cos, **self.key4n}, self.sigma4n, self.q_chal)
+        t = d4.coset_ifft(quot)                   # quotient polynomial, 4n coefficients
         out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)], labels=["t1", "t2", "t3", "t4"])   # t_1..t_4 (prover.rs:455-469)
         # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618).
         # All 16 MSMs depend only on polynomials and challenges known at the start of the round.

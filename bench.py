@@ -131,6 +131,8 @@ def main():
                     help="NOT the headline workload: commitments cached by polynomial label (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
     ap.add_argument("--grand-products", action="store_true",
                     help="also build the z / z2 evaluation vectors on the device (SURVEY.md 8f N2) inside each step")
+    ap.add_argument("--quotient", action="store_true",
+                    help="also compute the 4n quotient evaluations on the device (SURVEY.md 8f N1) inside each step")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     args = ap.parse_args()
@@ -199,9 +201,9 @@ def main():
                 if not args.no_precompute:
                     ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
                 if sharded:
-                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products)
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient)
                 else:
-                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products)
+                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient)
                 pts = None
                 for _ in range(args.warmup):
                     pts = sched.run_once()
@@ -245,7 +247,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product")}
+        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient")}
         digs = []
         if args.check:
             for ln in lanes:
@@ -320,6 +322,9 @@ def main():
         gp_ms, gp_n = r["prof"]["grand_product"]
         line["config"]["workload"] += " + z and z2 grand products on device"
         line["grand_product_ms_per_proof"] = gp_ms / kp
+    if args.quotient:
+        line["config"]["workload"] += " + pointwise quotient on device"
+        line["quotient_ms_per_proof"] = r["prof"]["quotient"][0] / kp
     if args.dedup:
         line["config"]["workload"] += " -- WITH commitment de-duplication: 17 MSMs computed, 12 served from the per-proof cache"
         line["msm_g1_adds_per_s"] = None

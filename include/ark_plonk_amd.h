@@ -201,6 +201,30 @@ int zk_perm_product_dev(zk_ctx* ctx, int curve_id, uint32_t log_n, const void* c
 int zk_lookup_product_dev(zk_ctx* ctx, int curve_id, size_t n, const void* d_f, const void* d_t, const void* d_h1, const void* d_h2,
                           const uint64_t* delta_mont, const uint64_t* epsilon_mont, void* d_out, uint64_t* last_mont);
 
+/* ---- N1: pointwise quotient over the 4n coset ------------------------------------- */
+/* Everything `quotient_poly::compute` (proof_system/quotient_poly.rs:34-178) does between its coset FFTs and
+ * its final coset_ifft: out[i] = (gate_constraints[i] + permutation[i] + lookup[i]) / v_h_coset_4n[i] with all
+ * widgets (arithmetic, range, logic, fixed-base scalar mul, curve addition), the permutation argument and the
+ * lookup argument.  Every pointer is a device vector of 4n Montgomery Fr evaluations over the coset
+ * g*<omega_4n> (the output of zk_ntt_dev kind 2); the "next row" of the reference (index i+4 of vectors it
+ * extends by e[0..4], quotient_poly.rs:75-118) is taken cyclically.  Challenges / coefficients: Montgomery Fr. */
+typedef struct zk_quotient_args {
+    const void *w_l, *w_r, *w_o, *w_4;    /* wire polynomials */
+    const void *z, *z2;                    /* permutation and lookup grand products */
+    const void *f, *table, *h1, *h2;       /* lookup: query, compressed table, sorted halves */
+    const void *pi;                        /* public inputs */
+    const void *l1;                        /* first Lagrange polynomial (quotient_poly.rs:68-69) */
+    /* prover key evaluations (preprocess.rs:144-212) */
+    const void *q_m, *q_l, *q_r, *q_o, *q_4, *q_c, *q_arith;
+    const void *q_range, *q_logic, *q_fixed_group_add, *q_variable_group_add, *q_lookup;
+    const void* sigma[4];                  /* left, right, out, fourth */
+    uint64_t alpha[4], beta[4], gamma[4], delta[4], epsilon[4], zeta[4];
+    uint64_t range_challenge[4], logic_challenge[4], fixed_base_challenge[4], var_base_challenge[4], lookup_challenge[4];
+    uint64_t coeff_a[4], coeff_d[4];       /* P::COEFF_A, P::COEFF_D of the embedded twisted Edwards curve */
+} zk_quotient_args;
+/* n = 2^log_n is the circuit domain size; vectors hold 4n elements.  d_out (4n elements) must not alias an input. */
+int zk_quotient_evals_dev(zk_ctx* ctx, int curve_id, uint32_t log_n, const zk_quotient_args* args, void* d_out);
+
 /* ---- utilities (synthetic SRS for tests/bench; stands in for PC::setup, out of scope) --------- */
 /* out[i] = scalars[i] * G1 generator, affine Montgomery, device buffers. */
 int zk_g1_fixed_base_batch_dev(zk_ctx* ctx, int curve_id, const void* d_scalars, size_t n, void* d_out_xy);

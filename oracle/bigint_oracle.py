@@ -27,6 +27,11 @@ What is restated, and the reference call site each function stands behind:
                          754-822) up to their final domain.ifft; this code IS in
                          the reference, and is restated line by line (row ratio, running product,
                          (n+1)-th value dropped).
+  * quotient_at / quotient_evals -- the pointwise quotient of proof_system/quotient_poly.rs:34-178 with
+                         every widget it sums (arithmetic.rs:51-63, range.rs:47-74, logic.rs:65-133,
+                         ecc/fixed_base_scalar_mul.rs:88-156, ecc/curve_addition.rs:62-97,
+                         proof_system/permutation.rs:62-153, widget/lookup.rs:97-151) and the division by
+                         the vanishing polynomial over the coset (preprocess.rs:429-452); SURVEY.md 8f row N1.
 External anchors used to pin constants (tests/test_oracle.py):
   * TWO_ADIC_ROOT_OF_UNITY of ark-bls12-381 Fr (decimal constant quoted in SURVEY.md 8a).
   * [2]G1 x-coordinate of BLS12-381 (the published compressed encoding a572cbea...f0f4e).
@@ -325,6 +330,94 @@ def lookup_product(curve: Curve, f, t, h1, h2, delta: int, epsilon: int):
             raise ZeroDivisionError("zero denominator (lookup_ratio: inverse().unwrap(), mod.rs:820)")
         state = state * num % p * pow(den, -1, p) % p
     return out, state
+
+
+# ----------------------------------------------------------------------------- quotient numerator / Z_H (N1)
+QUOTIENT_COLS = ("w_l", "w_r", "w_o", "w_4", "z", "z2", "f", "table", "h1", "h2", "pi", "l1",
+                 "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "q_arith", "q_range", "q_logic", "q_fixed", "q_var", "q_lookup",
+                 "sigma0", "sigma1", "sigma2", "sigma3")
+QUOTIENT_CHALLENGES = ("alpha", "beta", "gamma", "delta", "epsilon", "zeta", "range", "logic", "fixed", "var", "lookup",
+                       "coeff_a", "coeff_d")
+
+
+def _delta4(f, p):
+    """f(f-1)(f-2)(f-3): widget/range.rs:66-74, widget/logic.rs:94-102."""
+    return f * (f - 1) % p * (f - 2) % p * (f - 3) % p
+
+
+def quotient_at(curve: Curve, log_n: int, i: int, col, ch) -> int:
+    """One evaluation of the quotient over the 4n coset: plonk-core/src/proof_system/quotient_poly.rs:34-178
+    (`compute`) at index i, i.e. (gate_constraints[i] + permutation[i] + lookup[i]) / v_h_coset_4n[i].
+    col: dict name -> list of 4n canonical integers (coset evaluations; QUOTIENT_COLS); "next" = index i+4 cyclic
+    (the reference appends e[0..4], quotient_poly.rs:75-118).  ch: dict of challenges / curve coefficients."""
+    p = curve.r
+    n, n4 = 1 << log_n, 4 << log_n
+    nx = (i + 4) % n4
+    a, b, c, d = col["w_l"][i], col["w_r"][i], col["w_o"][i], col["w_4"][i]
+    a_n, b_n, d_n = col["w_l"][nx], col["w_r"][nx], col["w_4"][nx]
+    q_l, q_r, q_c = col["q_l"][i], col["q_r"][i], col["q_c"][i]
+    # -- gate constraints, quotient_poly.rs:182-268
+    arith = (a * b * col["q_m"][i] + a * q_l + b * q_r + c * col["q_o"][i] + d * col["q_4"][i] + q_c) % p * col["q_arith"][i] % p  # arithmetic.rs:51-63
+    s = ch["range"]                                                                                     # range.rs:47-63
+    k = s * s % p
+    rng = (_delta4((c - 4 * d) % p, p) + _delta4((b - 4 * c) % p, p) * k + _delta4((a - 4 * b) % p, p) * k * k
+           + _delta4((d_n - 4 * a) % p, p) * k * k * k) % p * s % p * col["q_range"][i] % p
+    s = ch["logic"]                                                                                     # logic.rs:65-133
+    k = s * s % p
+    la, lb, ld, w = (a_n - 4 * a) % p, (b_n - 4 * b) % p, (d_n - 4 * d) % p, c
+    F = w * (w * (4 * w - 18 * (la + lb) + 81) + 18 * (la * la + lb * lb) - 81 * (la + lb) + 83) % p
+    E = (3 * (la + lb + ld) - 2 * F) % p
+    B = q_c * (9 * ld - 3 * (la + lb)) % p
+    logic = (_delta4(la, p) + _delta4(lb, p) * k + _delta4(ld, p) * k * k + (w - la * lb) * k * k * k + (B + E) * k * k * k * k) % p * s % p \
+        * col["q_logic"][i] % p
+    s = ch["fixed"]                                                                                     # ecc/fixed_base_scalar_mul.rs:88-156
+    k = s * s % p
+    ca, cd = ch["coeff_a"], ch["coeff_d"]
+    bit = (d_n - d - d) % p
+    bit_cons = bit * (bit - 1) % p * (bit + 1) % p
+    y_alpha = (bit * bit * (q_r - 1) + 1) % p
+    x_alpha = q_l * bit % p
+    xy_cons = (bit * q_c - c) * k % p
+    x_acc = ((a_n + a_n * c * a * b * cd) - (x_alpha * b + y_alpha * a)) * k * k % p
+    y_acc = ((b_n - b_n * c * a * b * cd) - (y_alpha * b - ca * x_alpha * a)) * k * k * k % p
+    fixed = (bit_cons + x_acc + y_acc + xy_cons) % p * s % p * col["q_fixed"][i] % p
+    s = ch["var"]                                                                                       # ecc/curve_addition.rs:62-97
+    k = s * s % p
+    x1, x3, y1, y3, x2, y2, x1y2 = a, a_n, b, b_n, c, d, d_n
+    y1x2, y1y2, x1x2 = y1 * x2 % p, y1 * y2 % p, x1 * x2 % p
+    xy = (x1 * y2 - x1y2) % p
+    x3c = ((x1y2 + y1x2) - (x3 + x3 * cd * x1y2 * y1x2)) * k % p
+    y3c = ((y1y2 - ca * x1x2) - (y3 - y3 * cd * x1y2 * y1x2)) * k * k % p
+    var = (xy + x3c + y3c) % p * s % p * col["q_var"][i] % p
+    gate = (arith + col["pi"][i] + rng + logic + fixed + var) % p                                        # quotient_poly.rs:262-266
+    # -- permutation, proof_system/permutation.rs:62-153
+    al, be, ga = ch["alpha"], ch["beta"], ch["gamma"]
+    x = curve.fr_generator * pow(curve.root_of_unity(log_n + 2), i, p) % p                              # linear_evaluations, preprocess.rs:209-212
+    z_i, z_n = col["z"][i], col["z"][nx]
+    ident = (a + be * x + ga) * (b + be * PERM_K[1] * x + ga) % p * (c + be * PERM_K[2] * x + ga) % p * (d + be * PERM_K[3] * x + ga) % p * z_i % p * al % p
+    copy = (a + be * col["sigma0"][i] + ga) * (b + be * col["sigma1"][i] + ga) % p * (c + be * col["sigma2"][i] + ga) % p \
+        * (d + be * col["sigma3"][i] + ga) % p * z_n % p * al % p
+    l1a = al * al % p * col["l1"][i] % p                                                                # coset_fft(alpha^2 * L1), quotient_poly.rs:294
+    perm = (ident - copy + (z_i - 1) * l1a) % p
+    # -- lookup, widget/lookup.rs:97-151
+    de, ep, ze, ls = ch["delta"], ch["epsilon"], ch["zeta"], ch["lookup"]
+    opd = (1 + de) % p
+    e1d = ep * opd % p
+    tuple_ = (a + ze * (b + ze * (c + ze * d))) % p                                                     # util.rs lc()
+    t_i, t_n, h1_i, h1_n, h2_i = col["table"][i], col["table"][nx], col["h1"][i], col["h1"][nx], col["h2"][i]
+    z2_i, z2_n = col["z2"][i], col["z2"][nx]
+    la_ = col["q_lookup"][i] * (tuple_ - col["f"][i]) % p * ls % p
+    lb_ = z2_i * opd % p * (ep + col["f"][i]) % p * (e1d + t_i + de * t_n) % p * ls * ls % p
+    lc_ = -z2_n * (e1d + h1_i + de * h2_i) % p * (e1d + h2_i + de * h1_n) % p * ls * ls % p
+    ld_ = (z2_i - 1) * col["l1"][i] % p * ls * ls * ls % p
+    look = (la_ + lb_ + lc_ + ld_) % p
+    # -- / Z_H over the coset, preprocess.rs:429-452: v_h[i] = g^n * (w_4n^n)^i - 1
+    vh = (pow(curve.fr_generator, n, p) * pow(curve.root_of_unity(log_n + 2), n * i, p) - 1) % p
+    return (gate + perm + look) % p * pow(vh, -1, p) % p
+
+
+def quotient_evals(curve: Curve, log_n: int, col, ch) -> list:
+    return [quotient_at(curve, log_n, i, col, ch) for i in range(4 << log_n)]
 
 
 def ark_window_size(n: int) -> int:

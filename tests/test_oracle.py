@@ -138,3 +138,21 @@ def test_grand_product_oracle_matches_fixtures(cid):
     beta, gamma = ints(gp[f"{pre}_beta_gamma"])
     z, last = bo.perm_product(cv, 4, [ints(gp[f"{pre}_w{k}"]) for k in range(4)], [ints(gp[f"{pre}_s{k}"]) for k in range(4)], beta, gamma)
     assert z[0] == 1 and last == 1 and z == ints(gp[f"{pre}_z"]) and len(set(z)) > 8
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_quotient_oracle_matches_fixtures(cid):
+    """oracle/bigint_oracle.py quotient_evals (quotient_poly.rs:34-178 + widgets) vs tests/golden/quotient.npz."""
+    import ark_plonk_amd.curves as cvs
+    gq = np.load(os.path.join(ROOT, "tests", "golden", "quotient.npz"))
+    cv = bo.CURVES[cid]
+    ints = lambda a: cvs.fr_from_mont(cid, a)  # noqa: E731
+    col = {name: ints(gq[f"{cv.name}_col_{name}"]) for name in bo.QUOTIENT_COLS}
+    ch = dict(zip(bo.QUOTIENT_CHALLENGES, ints(gq[f"{cv.name}_challenges"])))
+    assert bo.quotient_evals(cv, 2, col, ch) == ints(gq[f"{cv.name}_quotient"])
+    # each widget is switched by its selector alone (widget/mod.rs:83-91): zeroing one selector changes the point
+    base = bo.quotient_at(cv, 2, 5, col, ch)
+    for sel in ("q_arith", "q_range", "q_logic", "q_fixed", "q_var", "q_lookup"):
+        c2 = dict(col)
+        c2[sel] = [0] * len(col[sel])
+        assert bo.quotient_at(cv, 2, 5, c2, ch) != base, sel

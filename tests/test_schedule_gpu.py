@@ -56,3 +56,15 @@ def test_schedule_with_device_grand_products(ctx):
     # rounds 1-2 (outputs 0..6) and the quotient commitments (9..12) do not involve z / z2 here
     assert all(same[:7]) and all(same[9:13]) and not same[7] and not same[8]
     ck.close()
+
+
+def test_schedule_with_device_quotient(ctx):
+    """N1 inside the schedule: only the four quotient commitments t_1..t_4 (outputs 9..12) depend on it."""
+    cv = zk.get_curve("bls12_381")
+    log_n = 11
+    ck = _ck(ctx, cv, 1 << log_n).precompute()
+    base = ProofSchedule(log_n, ctx, ck, cv).run_once()
+    q = ProofSchedule(log_n, ctx, ck, cv, quotient=True).run_once()
+    same = [a == b for a, b in zip(base, q)]
+    assert all(same[:9]) and not any(same[9:13]) and all(same[13:])
+    ck.close()

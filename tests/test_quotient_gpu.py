@@ -120,4 +120,41 @@ def test_compute_is_divisible_for_a_satisfied_arithmetic_circuit(ctx):
     c[7] = (c[7] + 1) % p
     polys["w_o"] = ifft(c)
     t_bad = quotient.compute(dom, dom4, polys, key, sig, chal).cpu().numpy().view(np.uint64)
-    assert t_bad[3 * n:].any()
+    assert all(t_bad[k].any() for k in range(4 * n - 4, 4 * n))
+
+
+def test_permutation_argument_end_to_end(ctx):
+    """N2 -> NTT -> N1 together on a circuit with real copy constraints: z is built on the device from the wire and
+    sigma columns (zk_perm_product_dev), interpolated, and fed with the sigma polynomials to the quotient kernel using
+    the same beta / gamma.  With all gate selectors off the numerator is the permutation argument alone, which
+    vanishes on the domain exactly when z is the right grand product.  The numerator has degree <= 5n-5 (four wire
+    factors and z), so an exact quotient has degree <= 4n-5: its last four coefficients are zero, while the interpolant
+    of a non-divisible numerator / Z_H has no reason to have any zero coefficient."""
+    from ark_plonk_amd import permutation
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden_gp import valid_permutation
+    cid, cv, log_n = 0, bo.CURVES[0], 5
+    n, p = 1 << log_n, cv.r
+    dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
+    dom4 = zk.Radix2EvaluationDomain.new(4 * n, cid, ctx)
+    wires, sigmas = valid_permutation(cv, log_n, 0xE00)
+    m = lambda xs: dev(zk.curves.fr_to_mont(cid, xs))   # noqa: E731
+    chv = dict(zip(quotient.CHALLENGES, bo.seeded_scalars(cv, 0xE10, len(quotient.CHALLENGES))))
+    chal = {k: zk.curves.fr_to_mont(cid, [v])[0] for k, v in chv.items()}
+    w_dev, s_dev = [m(w) for w in wires], [m(sg) for sg in sigmas]
+    z_evals, last = permutation.permutation_evals(dom, w_dev, s_dev, chal["beta"], chal["gamma"], return_last=True)
+    assert zk.curves.fr_from_mont(cid, last.reshape(1, 4))[0] == 1
+    zero, ones = [0] * n, [1] * n
+    ifft = lambda t: dom.ifft(t)                         # noqa: E731
+    polys = {"w_l": ifft(w_dev[0]), "w_r": ifft(w_dev[1]), "w_o": ifft(w_dev[2]), "w_4": ifft(w_dev[3]), "z": ifft(z_evals),
+             "z2": ifft(m(ones)), "f": ifft(m(zero)), "table": ifft(m(zero)), "h1": ifft(m(zero)), "h2": ifft(m(zero)), "pi": ifft(m(zero))}
+    cfz = dom4.coset_fft(ifft(m(zero)))
+    key = {name: cfz for name in quotient.COLUMNS[12:]}
+    sig = [dom4.coset_fft(ifft(sd)) for sd in s_dev]
+    t = quotient.compute(dom, dom4, polys, key, sig, chal).cpu().numpy().view(np.uint64)
+    assert not t[4 * n - 4:].any() and t[3 * n:4 * n - 4].any()
+    # a z built with another gamma is not the grand product of this argument
+    chal2 = dict(chal)
+    chal2["gamma"] = zk.curves.fr_to_mont(cid, [chv["gamma"] + 1])[0]
+    t_bad = quotient.compute(dom, dom4, polys, key, sig, chal2).cpu().numpy().view(np.uint64)
+    assert all(t_bad[k].any() for k in range(4 * n - 4, 4 * n))

@@ -2,7 +2,10 @@
 // interfaces of the hot path with the same names and argument meaning:
 //   zk::Radix2EvaluationDomain  <- ark_poly::EvaluationDomain (prover.rs:169-173,196-203; quotient_poly.rs:64-120)
 //   zk::VariableBaseMSM         <- ark_ec::msm::VariableBaseMSM (commitment.rs:45)
-//   zk::CommitterKey::commit    <- KZG10 PC::commit (prover.rs:213 ...)
+//   zk::CommitterKey::commit    <- KZG10 PC::commit (prover.rs:213 ...); commit_round for the polynomials of one call
+//   zk::DeviceVec               -- device-resident Fr vector (what stays on the GPU between fft and commit)
+//   zk::permutation_evals / lookup_permutation_evals / quotient_evals
+//                               <- permutation/mod.rs:652-822, quotient_poly.rs:34-178
 // The reference is Rust and infallible at these call sites; here failures throw zk::Error.
 #pragma once
 #include <cstdint>
@@ -39,6 +42,33 @@ class Context {
     zk_ctx* h_ = nullptr;
 };
 
+// n Fr elements (4 limbs each) in device memory
+class DeviceVec {
+  public:
+    DeviceVec(Context& ctx, size_t n) : ctx_(&ctx), n_(n) { check(zk_dev_alloc(ctx.handle(), (n ? n : 1) * 32, &p_), "zk_dev_alloc"); }
+    DeviceVec(Context& ctx, const std::vector<uint64_t>& host) : DeviceVec(ctx, host.size() / 4) {
+        if (n_) check(zk_dev_upload(ctx.handle(), p_, host.data(), n_ * 32), "zk_dev_upload");
+    }
+    ~DeviceVec() {
+        if (p_) zk_dev_free(ctx_->handle(), p_);
+    }
+    DeviceVec(const DeviceVec&) = delete;
+    DeviceVec& operator=(const DeviceVec&) = delete;
+    DeviceVec(DeviceVec&& o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+    void* data() const { return p_; }
+    size_t size() const { return n_; }
+    std::vector<uint64_t> to_host() const {
+        std::vector<uint64_t> h(4 * n_);
+        if (n_) check(zk_dev_download(ctx_->handle(), h.data(), p_, n_ * 32), "zk_dev_download");
+        return h;
+    }
+
+  private:
+    Context* ctx_;
+    void* p_ = nullptr;
+    size_t n_;
+};
+
 // GeneralEvaluationDomain::Radix2 over the scalar field of `curve`
 class Radix2EvaluationDomain {
   public:
@@ -66,6 +96,14 @@ class Radix2EvaluationDomain {
     std::vector<uint64_t> ifft(const std::vector<uint64_t>& e) const { auto v = e; ifft_in_place(v); return v; }
     std::vector<uint64_t> coset_fft(const std::vector<uint64_t>& c) const { auto v = c; coset_fft_in_place(v); return v; }
     std::vector<uint64_t> coset_ifft(const std::vector<uint64_t>& e) const { auto v = e; coset_ifft_in_place(v); return v; }
+    // device-resident form: `in` (<= size() elements, zero-extended) -> a new vector of size() elements
+    DeviceVec transform(int kind, const DeviceVec& in) const {
+        DeviceVec out(*ctx_, info_.size);
+        check(zk_ntt_dev(ctx_->handle(), curve_, kind, info_.log_size_of_group, in.data(), in.size(), out.data()), "zk_ntt_dev");
+        return out;
+    }
+    Context& context() const { return *ctx_; }
+    int curve() const { return curve_; }
 
   private:
     Radix2EvaluationDomain(Context& ctx, int curve, const zk_domain_info& i) : ctx_(&ctx), curve_(curve), info_(i) {}
@@ -116,6 +154,28 @@ class CommitterKey {
     CommitterKey(const CommitterKey&) = delete;
     CommitterKey& operator=(const CommitterKey&) = delete;
     size_t size() const { return zk_srs_len(h_); }
+    // window-multiples table (once per key, like PC::trim): enables the fused round batches
+    void precompute() { check(zk_srs_precompute(ctx_->handle(), h_), "zk_srs_precompute"); }
+    // PC::commit over the labeled polynomials of ONE call (prover.rs:213 passes four, :579 seven): one batch
+    std::vector<G1Affine> commit_round(const std::vector<const DeviceVec*>& polys) const {
+        const int L = fq_limbs(curve_);
+        const uint32_t k = (uint32_t)polys.size();
+        std::vector<const void*> ptrs(k);
+        std::vector<size_t> lens(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            ptrs[i] = polys[i]->data();
+            lens[i] = polys[i]->size();
+        }
+        std::vector<uint64_t> xy((size_t)k * 2 * L);
+        std::vector<uint8_t> inf(k ? k : 1);
+        check(zk_kzg_round_batch_dev(ctx_->handle(), h_, k, ptrs.data(), lens.data(), nullptr, xy.data(), inf.data()), "zk_kzg_round_batch_dev");
+        std::vector<G1Affine> out(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
+            out[i].infinity = inf[i] != 0;
+        }
+        return out;
+    }
     G1Affine commit(const std::vector<uint64_t>& coeffs_mont) const {
         G1Affine out;
         out.xy.assign(2 * fq_limbs(curve_), 0);
@@ -130,5 +190,36 @@ class CommitterKey {
     int curve_;
     zk_srs* h_ = nullptr;
 };
+
+// Permutation::compute_permutation_poly up to its ifft (permutation/mod.rs:652-747): z over the domain
+inline DeviceVec permutation_evals(const Radix2EvaluationDomain& d, const DeviceVec* const wires[4], const DeviceVec* const sigma_evals[4],
+                                   const uint64_t* beta_mont, const uint64_t* gamma_mont) {
+    const void* w[4];
+    const void* s[4];
+    for (int k = 0; k < 4; ++k) {
+        if (wires[k]->size() != d.size() || sigma_evals[k]->size() != d.size()) throw Error(ZK_ERR_BAD_ARG, "column length");
+        w[k] = wires[k]->data();
+        s[k] = sigma_evals[k]->data();
+    }
+    DeviceVec out(d.context(), d.size());
+    check(zk_perm_product_dev(d.context().handle(), d.curve(), d.log_size_of_group(), w, s, beta_mont, gamma_mont, out.data(), nullptr),
+          "zk_perm_product_dev");
+    return out;
+}
+// compute_lookup_permutation_poly up to its ifft (permutation/mod.rs:754-797)
+inline DeviceVec lookup_permutation_evals(Context& ctx, int curve, const DeviceVec& f, const DeviceVec& t, const DeviceVec& h1,
+                                          const DeviceVec& h2, const uint64_t* delta_mont, const uint64_t* epsilon_mont) {
+    DeviceVec out(ctx, f.size());
+    check(zk_lookup_product_dev(ctx.handle(), curve, f.size(), f.data(), t.data(), h1.data(), h2.data(), delta_mont, epsilon_mont, out.data(),
+                                nullptr),
+          "zk_lookup_product_dev");
+    return out;
+}
+// quotient_poly::compute between its coset FFTs and its coset iFFT (quotient_poly.rs:122-173); `d` = the size-n domain
+inline DeviceVec quotient_evals(const Radix2EvaluationDomain& d, const zk_quotient_args& args) {
+    DeviceVec out(d.context(), 4 * d.size());
+    check(zk_quotient_evals_dev(d.context().handle(), d.curve(), d.log_size_of_group(), &args, out.data()), "zk_quotient_evals_dev");
+    return out;
+}
 
 }  // namespace zk

@@ -24,7 +24,7 @@ from .msm import CommitterKey, sum_partials_batch
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup: bool = False,
-                 grand_products: bool = False, quotient: bool = False):
+                 grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -34,8 +34,14 @@ class ProofSchedule:
         self.ck = ck
         self.rank, self.world, self.dist = rank, world, dist
         # commitments cached by polynomial label, so the 12 polynomials the reference
-        # commits a second time in round 5 (prover.rs:569-607) cost no MSM: 29 -> 17 per proof, same outputs
+        # commits a second time in round 5 (prover.rs:569-607) cost no MSM: 29 -> 17 per proof (20 on the first,
+        # which also commits the prover key's sigma polynomials), same outputs
         self.dedup = dedup
+        # prover.rs:579-618 issues PC::commit(aw) / PC::open / PC::commit(saw) / PC::open as four calls.  The default
+        # replays them as four batches -- what a drop-in PC implementation sees.  All 16 MSMs depend only on values
+        # known before the first call (both opening challenges are drawn with no transcript append in between), so
+        # a prover that merges the four calls can run them as ONE batch: fuse_round5=True (needs that caller change).
+        self.fuse_round5 = fuse_round5
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
         self.grand_products = grand_products
@@ -114,7 +120,8 @@ class ProofSchedule:
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
         d, d4, n = self.dom_n, self.dom_4n, self.n
         out = []
-        self._cache = {}
+        # commitments of prover-key polynomials (sigma_1..3) outlive a proof; everything else is per proof
+        self._cache = {k: v for k, v in self._cache.items() if k.startswith("sigma")}
         self.msms_run = 0
         c = self.coef
         # Round 1: 4 ifft + 4 commits (prover.rs:196-203, 213)
@@ -155,17 +162,27 @@ class ProofSchedule:
             quot = compute_quotient_evals(d, {**self.cos, **self.key4n}, self.sigma4n, self.q_chal)
         t = d4.coset_ifft(quot)                   # quotient polynomial, 4n coefficients
         out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)], labels=["t1", "t2", "t3", "t4"])   # t_1..t_4 (prover.rs:455-469)
-        # Round 5: aw commits (7), opening at z, saw commits (7), opening at z*w (prover.rs:569-618).
-        # All 16 MSMs depend only on polynomials and challenges known at the start of the round.
-        aw = [c[5], c[6], c[7], c[8], c[9], c[4], c[11]]
-        aw_open = aw + [c[0], c[1], c[2], c[3]]   # PC::open of the 7 aw polys + 4 wire polys at z (prover.rs:582-591)
+        # Round 5 (prover.rs:569-618): aw commits (7), opening of the 7 + 4 wire polynomials at z, saw commits (7),
+        # opening at z*omega.  aw = [lin, sigma_1..3 of the prover key, f, h_2, table]; saw = [z, w_l, w_r, w_4, h_1, z_2, table]
+        aw = [c[11], self.sigma[0], self.sigma[1], self.sigma[2], c[5], c[7], c[4]]      # c[11] stands in for lin_poly
+        aw_labels = ["lin", "sigma1", "sigma2", "sigma3", "f", "h2", "table"]
+        aw_open = aw + [c[0], c[1], c[2], c[3]]   # prover.rs:582-591
         saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]
+        saw_labels = ["z", "w_l", "w_r", "w_4", "h1", "z2", "table"]
         from .msm import kzg_witness
         # the witness polynomials are computed by every rank (replicated, like the NTTs); their MSMs shard
-        w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
-        w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
-        out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True],
-                                  labels=["f", "h1", "h2", "z", "z2", "table", "l1", "W_z", "z", "w_l", "w_r", "w_4", "h1", "z2", "table", "W_zw"])
+        if self.fuse_round5:
+            w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+            w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)   # at z*omega (prover.rs:609-618)
+            out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True],
+                                      labels=aw_labels + ["W_z"] + saw_labels + ["W_zw"])
+        else:
+            out += self._commit_round(aw, labels=aw_labels)                                  # PC::commit(aw_polys)
+            w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+            out += self._commit_round([w1], canonical=[True], labels=["W_z"])                # PC::open
+            out += self._commit_round(saw, labels=saw_labels)                                # PC::commit(saw_polys)
+            w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+            out += self._commit_round([w2], canonical=[True], labels=["W_zw"])               # PC::open
         assert len(out) == 29
         return out
 

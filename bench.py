@@ -131,6 +131,8 @@ def main():
                     help="NOT the headline workload: commitments cached by polynomial label (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
     ap.add_argument("--grand-products", action="store_true",
                     help="also build the z / z2 evaluation vectors on the device (SURVEY.md 8f N2) inside each step")
+    ap.add_argument("--fuse-round5", action="store_true",
+                    help="the 16 MSMs of prover.rs:579-618 as ONE batch instead of the reference's four calls (needs those calls merged in the caller)")
     ap.add_argument("--quotient", action="store_true",
                     help="also compute the 4n quotient evaluations on the device (SURVEY.md 8f N1) inside each step")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
@@ -201,9 +203,9 @@ def main():
                 if not args.no_precompute:
                     ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
                 if sharded:
-                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient)
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5)
                 else:
-                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient)
+                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5)
                 pts = None
                 for _ in range(args.warmup):
                     pts = sched.run_once()
@@ -322,6 +324,8 @@ def main():
         gp_ms, gp_n = r["prof"]["grand_product"]
         line["config"]["workload"] += " + z and z2 grand products on device"
         line["grand_product_ms_per_proof"] = gp_ms / kp
+    if args.fuse_round5:
+        line["config"]["workload"] += "; round 5's four PC calls merged into one batch"
     if args.quotient:
         line["config"]["workload"] += " + pointwise quotient on device"
         line["quotient_ms_per_proof"] = r["prof"]["quotient"][0] / kp
@@ -352,7 +356,7 @@ def main():
             line["msm_sharded"] = {
                 "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
                 "speedup_vs_one_gpu_replica": (dt / steps) / (rs["dt"] / steps),
-                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per prover round (7 per proof)",
+                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (10 per proof)",
                 "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
                 "commitments_match_replicas": (rs["digest"] == r["digest"]) if args.check else None,
             }

@@ -35,11 +35,14 @@ def test_schedule_table_path_matches_plain_path_and_dedup(ctx, log_n):
     assert s_tab.msms_run == 29
     s_dd = ProofSchedule(log_n, ctx, ck, cv, dedup=True)
     dd = s_dd.run_once()
-    assert s_dd.msms_run == 17
-    for a, b, c in zip(plain, tab, dd):
-        assert a == b and a == c
-    # round 5 re-commits polynomials of rounds 1-3 (prover.rs:569-607): outputs 13..19 and 21..27 repeat earlier ones
-    assert tab[13] == tab[4] and tab[16] == tab[7] and tab[21] == tab[7] and tab[22] == tab[0]
+    assert s_dd.msms_run == 20          # first proof: the prover key's sigma commitments are computed once ...
+    dd2 = s_dd.run_once()
+    assert s_dd.msms_run == 17          # ... and stay cached: lin, table, W_z, W_zw + the 13 of rounds 1-4
+    fused = ProofSchedule(log_n, ctx, ck, cv, fuse_round5=True).run_once()
+    for a, b, c, e, f in zip(plain, tab, dd, dd2, fused):
+        assert a == b and a == c and a == e and a == f
+    # round 5 re-commits polynomials of rounds 1-3 (prover.rs:569-607): f, h2 in aw; z, w_l, ... in saw
+    assert tab[17] == tab[4] and tab[18] == tab[6] and tab[21] == tab[7] and tab[22] == tab[0] and tab[27] == tab[19]
     ck.close()
 
 

@@ -3,10 +3,14 @@ prover.rs:163-638), replayed through the C ABI on device-resident data.
 
 Only the transforms and commitments are reproduced -- the same kinds, sizes and order the reference
 issues them: 13 ifft(n) + 4 fft(n) + 13 coset_fft(4n) + 1 coset_ifft(4n) and 29 MSMs
-of ~n points.  The serial CPU glue between them (transcript, grand products, quotient evaluation,
-linearisation) is out of scope (SURVEY.md 8f rows N1-N4), so polynomial *values* here are synthetic;
-what is preserved is which buffers feed which call and their lengths, e.g. the coset_fft inputs have
-n coefficients zero-extended to 4n (quotient_poly.rs:72-120) and the openings are MSMs of n-1.
+of ~n points, in the reference's eleven PC::commit / PC::open calls (4 | 1 | 1 | 1 | 1 | 1 | 4 | 7 | 1 | 7 | 1
+polynomials, prover.rs:213,289,312,315,361,387,459,579,582,606,609): a batch never crosses a call
+boundary, because a drop-in PC implementation could not do that either.  The serial CPU glue between
+the calls (transcript, linearisation) is out of scope, so polynomial *values* are synthetic unless the
+optional device builders of SURVEY.md 8f are switched on (grand_products: z / z2; quotient: the 4n
+quotient evaluations); what is preserved is which buffers feed which call and their lengths, e.g. the
+coset_fft inputs have n coefficients zero-extended to 4n (quotient_poly.rs:72-120) and the openings
+are MSMs of n-1.
 
 Multi-GPU (one process per GPU): every MSM is sharded by points over the ranks -- rank g owns
 SRS[g*n/G, (g+1)*n/G) -- and combined by an all-gather of the 3L-limb Jacobian partials (RCCL over
@@ -134,7 +138,8 @@ class ProofSchedule:
         out += self._commit_round([c[5]], labels=["f"])
         c[6] = d.ifft(self.aux_evals[2])          # h1
         c[7] = d.ifft(self.aux_evals[3])          # h2
-        out += self._commit_round([c[6], c[7]], labels=["h1", "h2"])
+        out += self._commit_round([c[6]], labels=["h1"])     # two PC::commit calls of one polynomial each (prover.rs:312-317)
+        out += self._commit_round([c[7]], labels=["h2"])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         sig = [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]

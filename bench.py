@@ -356,7 +356,7 @@ def main():
             line["msm_sharded"] = {
                 "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
                 "speedup_vs_one_gpu_replica": (dt / steps) / (rs["dt"] / steps),
-                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (10 per proof)",
+                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (11 per proof)",
                 "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
                 "commitments_match_replicas": (rs["digest"] == r["digest"]) if args.check else None,
             }

@@ -372,8 +372,10 @@ ZK_D XYZZu<F> wave_sum(XYZZu<F> acc) {
 // One lane per bucket: a bucket whose entries span p >= 2 chunks has exactly p partials at slots
 // known from the offsets (see msm_accumulate).  Small p is summed here; larger p is queued.
 // queues: q[0] = medium count, q[1] = large count, q[2 ..] medium ids (grow up), q[.. 2+nb) large ids (grow down)
-constexpr uint32_t COMBINE_SG = 4;         // lanes cooperating on one small bucket
-template <class F>
+// COMBINE_SG lanes cooperate on one small bucket: 4 shortens the dependent chain when the launch is
+// latency-bound (1-2 jobs: 0.25 -> 0.19 ms); with more jobs the launch is throughput-bound and the idle
+// lanes of the shuffle tree cost more than they save (7 jobs: 1.0 ms at 4 lanes), so 1 is used there.
+template <class F, uint32_t COMBINE_SG>
 __global__ void __launch_bounds__(128) msm_combine(RJobs jobs, uint32_t nb) {
     const void* part_pt = jobs.part_pt[blockIdx.y];
     const uint32_t* offsets = jobs.offsets[blockIdx.y];
@@ -634,8 +636,13 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
     for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
-    unsigned blocks = (unsigned)(((uint64_t)nb * COMBINE_SG + T - 1) / T);
-    hipLaunchKernelGGL(msm_combine<F>, dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+    if (n_jobs <= 2) {
+        unsigned blocks = (unsigned)(((uint64_t)nb * 4 + T - 1) / T);
+        hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+    } else {
+        unsigned blocks = (unsigned)(((uint64_t)nb + T - 1) / T);
+        hipLaunchKernelGGL((msm_combine<F, 1>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+    }
     hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
     hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);
     unsigned sblocks = (gr.W * gr.ns + T - 1) / T;

@@ -52,6 +52,13 @@ void zk_prof_collect(zk_ctx* c) {
     }
 }
 
+void host_parallel_for(uint32_t n, const std::function<void(uint32_t)>& fn) {
+    static std::mutex mu;                     // HostPool::run is one batch at a time
+    static HostPool pool(7);
+    std::lock_guard<std::mutex> lk(mu);
+    pool.run(n, fn);
+}
+
 namespace {
 
 inline int fq_limbs64(int curve) { return curve == ZK_CURVE_BLS12_381 ? 6 : curve == ZK_CURVE_BN254 ? 4 : 0; }
@@ -142,6 +149,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
         return ZK_ERR_HIP;
     }
     c->stream = c->own_stream;
+    c->pool.reset(new HostPool(7));
     for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
@@ -529,15 +537,8 @@ int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* c
     }
     Guard g(c);
     uint64_t xyz[16 * 18];
-    int rc = msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz, kinds);
-    if (rc) return rc;
-    int rcs[16] = {0};
-    host_parallel_for(n_polys, [&](uint32_t k) {
-        rcs[k] = finish_point(s->curve, xyz + (size_t)k * 3 * L, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
-    });
-    for (uint32_t k = 0; k < n_polys; ++k)
-        if (rcs[k]) return rcs[k];
-    return ZK_OK;
+    // window combine and affine normalisation of a job run back to back on one pool thread
+    return msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz, kinds, out_xy, out_inf);
 }
 
 int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {

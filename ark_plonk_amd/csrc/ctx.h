@@ -7,6 +7,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <vector>
 #include <utility>
 
@@ -51,17 +54,85 @@ struct CurveBn {
 void zk_note_hip_error(hipError_t e, const char* what, const char* file, int line);
 
 // device buffer that grows on demand and is reused across calls (no hipMalloc in steady state)
-// fn(k) for k in [0, n): helper threads + the caller.  For the host-side tails of a batch (window
-// combine, affine normalisation: ~0.1 ms of serial field arithmetic per job while the GPU waits).
-template <class Fn>
-inline void host_parallel_for(uint32_t n, Fn fn) {
-    if (n == 0) return;
-    std::vector<std::thread> th;
-    th.reserve(n - 1);
-    for (uint32_t k = 1; k < n; ++k) th.emplace_back([&fn, k] { fn(k); });
-    fn(0);
-    for (auto& t : th) t.join();
-}
+// Persistent helper threads for the host-side tails of a batch (window combine + affine normalisation:
+// ~70 us of serial field arithmetic per job while the GPU waits).  Creating a std::thread costs ~35 us on
+// these hosts -- as much as half a job -- so the workers are started once and woken per call; the caller
+// takes items too.  run() is not re-entrant (one batch at a time per pool; zk_ctx calls hold its mutex).
+class HostPool {
+  public:
+    explicit HostPool(unsigned workers) {
+        for (unsigned i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    HostPool(const HostPool&) = delete;
+    HostPool& operator=(const HostPool&) = delete;
+    void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || th_.empty()) {
+            for (uint32_t k = 0; k < n; ++k) fn(k);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_ = 0;
+            pending_ = n;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work() {   // take items until none is left
+        for (;;) {
+            uint32_t k;
+            const std::function<void(uint32_t)>* f;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= n_) return;
+                k = next_++;
+                f = fn_;
+            }
+            (*f)(k);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    uint32_t n_ = 0, next_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
+// fn(k) for k in [0, n) on the process-wide pool (host-only entry points without a ctx)
+void host_parallel_for(uint32_t n, const std::function<void(uint32_t)>& fn);
 
 struct DevBuf {
     void* p = nullptr;
@@ -121,6 +192,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::recursive_mutex mu;
+    std::unique_ptr<HostPool> pool;   // created with the ctx (7 workers + the calling thread)
     int msm_window = 0;  // 0 = auto
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -185,8 +257,9 @@ int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, vo
 int msm_precompute_dev(zk_ctx* c, zk_srs* s);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 // a batch of commitments over one SRS, queued back to back; the host blocks once per result
+// out_xy / out_inf (optional): also normalise every result to affine (n_polys x 2L limbs, n_polys flags)
 int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
-                      const uint8_t* kinds = nullptr);
+                      const uint8_t* kinds = nullptr, uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points

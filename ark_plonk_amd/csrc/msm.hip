@@ -1063,6 +1063,9 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     return ZK_OK;
 }
 
+template <class Fq>
+int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
+
 // A batch of commitments over the same SRS (the polynomials of one prover round): Montgomery
 // coefficients in, Jacobian results out.  Every job has its own buffer set; the jobs' sorts and
 // accumulations are queued back to back and their combine / segmented-reduction steps run as ONE
@@ -1071,7 +1074,8 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
 // neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md).
 template <class Cv>
 int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
-                  const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */) {
+                  const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
+                  uint64_t* out_xy /* optional: n_polys x 2L affine */, uint8_t* out_inf /* optional flags */) {
     typedef typename Cv::Fq Fq;
     constexpr int L64 = Fq::N / 2;
     if (n_polys == 0) return ZK_OK;
@@ -1094,9 +1098,14 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(st));
     const char* h_win = (const char*)c->pinned;
-    host_parallel_for(n_polys, [&](uint32_t k) {
-        pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, out_xyz + (size_t)k * 3 * L64);
+    int rcs[MAX_JOBS] = {0};
+    c->pool->run(n_polys, [&](uint32_t k) {
+        uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
+        pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, xyz);
+        if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
     });
+    for (uint32_t k = 0; k < n_polys; ++k)
+        if (rcs[k]) return rcs[k];
     return ZK_OK;
 }
 
@@ -1200,8 +1209,8 @@ int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
 }
 int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
-                              const uint8_t* kinds) {
-    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds);
+                              const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf) {
+    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

@@ -325,3 +325,27 @@ def test_commit_batch_equals_single_commits(ctx):
     again = ck.commit_batch(polys[:3])
     ck.close()
     assert single == plain and batch == plain and again == plain[:3]
+
+
+def test_round_batch_with_very_different_lengths(ctx):
+    """One PC::commit call may hold polynomials of different degree (prover.rs:459-469: t_4 is shorter; a linearisation
+    polynomial next to sigma polynomials): lengths from the table-path threshold to the full SRS, odd lengths
+    (single-scalar digit kernel) and one below the threshold (whole batch falls back to one-at-a-time)."""
+    import torch
+    cid, n = 0, 1 << 16
+    cv = bo.CURVES[cid]
+    g = torch.Generator(device="cuda").manual_seed(123)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, ks.data_ptr(), n, bases.data_ptr()))
+    ck = zk.CommitterKey(bases, cid, ctx)
+    lens = (n, 8192, n - 1, n // 2 + 3, 8193, 3 * n // 4)
+    polys = [torch.randint(0, 1 << 62, (ln, 4), dtype=torch.int64, device="cuda", generator=g) for ln in lens]
+    plain = [ck.commit(p) for p in polys]                       # per-window path, one at a time
+    ck.precompute()
+    assert ck.commit_batch(polys) == plain                      # fused table path, mixed geometry inputs
+    mixed = polys + [polys[0][:100]]                            # one job below the threshold
+    assert ck.commit_batch(mixed) == plain + [ck.commit(polys[0][:100])]
+    ck.close()

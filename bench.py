@@ -111,8 +111,8 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"],
                     help="bn254 = BASELINE.json's second-curve config (same kernels, 4-limb base field); the headline is bls12_381")

@@ -159,9 +159,9 @@ struct DevBuf {
 };
 
 struct MsmBufs {
-    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars;
+    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars, stage;
     void release() {
-        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars};
+        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars, &stage};
         for (DevBuf* b : all) b->release();
     }
 };

@@ -276,7 +276,7 @@ __global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t 
 // the two placement kernels touches.
 constexpr uint32_t PS_LOB = 7;        // low bucket bits ordered inside a partition
 constexpr uint32_t PS_T = 1024;
-constexpr uint32_t PS_SLABS = 512;    // workgroups of the partition passes
+constexpr uint32_t PS_SLABS = 1024;   // workgroups of the partition passes
 
 __global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t nf, uint32_t P, uint32_t* hist /* [P][PS_SLABS] */) {
     extern __shared__ uint32_t lc[];
@@ -326,54 +326,169 @@ __global__ void __launch_bounds__(1024) psort_scan_parts(const uint32_t* part_to
     if (t == 1023) part_start[P] = part[1023];
 }
 
-// references (sign<<31 | window<<26 | index, as msm_scatter writes them) + their low bucket bits -> partition order
+// exclusive scan of 256 values held by lanes 0..255 of a workgroup (every lane calls it); tmp: 4 LDS words
+ZK_D uint32_t scan256_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((t & 63) >= d) inc += o;
+    }
+    if (t < 256 && (t & 63) == 63) tmp[t >> 6] = inc;
+    __syncthreads();
+    uint32_t add = 0;
+    for (uint32_t w = 0; w < (t >> 6) && w < 4; ++w) add += tmp[w];
+    __syncthreads();
+    return inc + add - v;
+}
+
+// references (sign<<31 | window<<26 | index, as msm_scatter writes them) + their low bucket bits -> partition order.
+// A tile of PS_STILE digits is ordered by partition in LDS first (packed: position in the tile, sign, low bits,
+// partition), so the 8-byte records leave as runs of consecutive addresses, one run per partition and tile.
+constexpr uint32_t PS_STILE = 16384;   // 16 digits per lane
 __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t nf, uint32_t P, const uint32_t* cursors,
                                                       const uint32_t* part_start, uint2* stage, uint32_t n_real) {
-    extern __shared__ uint32_t lc[];
-    for (uint32_t j = threadIdx.x; j < P; j += PS_T) lc[j] = part_start[j] + cursors[(uint64_t)j * PS_SLABS + blockIdx.x];
-    __syncthreads();
+    constexpr uint32_t PER = PS_STILE / PS_T, LOM = (1u << PS_LOB) - 1u;
+    __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
+    __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | low bits << 15 | partition << 22
+    const uint32_t t = threadIdx.x;
+    if (t < 256) gcur[t] = t < P ? part_start[t] + cursors[(uint64_t)t * PS_SLABS + blockIdx.x] : 0u;
     uint64_t lo, hi;
     slab_range(nf, PS_SLABS, blockIdx.x, lo, hi);
-#pragma unroll 4
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += PS_T) {
-        const int32_t d = dig[i];
-        if (d == 0) continue;
-        const uint32_t neg = d < 0 ? 1u : 0u;
-        const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
-        const uint32_t pos = atomicAdd(&lc[b >> PS_LOB], 1u);
-        const uint32_t wq = (uint32_t)i / n_real;
-        stage[pos] = make_uint2((wq << 26) | ((uint32_t)i - wq * n_real) | (neg << 31), b & ((1u << PS_LOB) - 1u));
+    for (uint64_t base = lo; base < hi; base += PS_STILE) {
+        const uint32_t m = hi - base < PS_STILE ? (uint32_t)(hi - base) : PS_STILE;
+        __syncthreads();
+        if (t < 256) cnt[t] = 0;
+        __syncthreads();
+        uint32_t pk[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            pk[k] = 0xffffffffu;
+            if (i < m) {
+                const int32_t d = dig[base + i];
+                if (d != 0) {
+                    const uint32_t neg = d < 0 ? 1u : 0u;
+                    const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
+                    pk[k] = i | (neg << 14) | ((b & LOM) << 15) | ((b >> PS_LOB) << 22);
+                    atomicAdd(&cnt[b >> PS_LOB], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t c = t < 256 ? cnt[t] : 0u;
+            const uint32_t ex = scan256_excl(c, t, stmp);
+            if (t < 256) toff[t] = ex;
+            if (t == 255) toff[256] = ex + c;
+        }
+        __syncthreads();
+        if (t < 256) cnt[t] = toff[t];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k)
+            if (pk[k] != 0xffffffffu) rec[atomicAdd(&cnt[pk[k] >> 22], 1u)] = pk[k];
+        __syncthreads();
+        const uint32_t total = toff[256];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t q = k * PS_T + t;   // consecutive lanes -> consecutive records of a partition's run
+            if (q < total) {
+                const uint32_t r = rec[q];
+                const uint32_t pp = r >> 22;
+                const uint64_t gi = base + (r & 0x3fffu);
+                const uint32_t wq = (uint32_t)(gi / n_real);
+                const uint32_t ref = (wq << 26) | (uint32_t)(gi - (uint64_t)wq * n_real) | (((r >> 14) & 1u) << 31);
+                stage[gcur[pp] + (q - toff[pp])] = make_uint2(ref, (r >> 15) & LOM);
+            }
+        }
+        __syncthreads();
+        if (t < 256) gcur[t] += toff[t + 1] - toff[t];
     }
 }
 
-// one workgroup per partition: count the low bits, publish the bucket offsets, place the references.
-// (Wave-private counters were tried: 16 x 128 write streams per workgroup instead of 128 made it slower.)
+// one workgroup per partition: count the low bits, publish the bucket offsets, then place the references
+// tile by tile: a tile of PS_TILE references is ordered in LDS first, so that the global stores are runs
+// of consecutive addresses (one run per bucket and tile) instead of 64 different cache lines per wave-store.
+// (Wave-private counters were tried for the counting: 16 x 128 write streams per workgroup made it slower.)
+constexpr uint32_t PS_TILE = 16384;   // references ordered in LDS at a time (64 KiB) -- 16 per lane
+
+// exclusive scan of 128 values held by lanes 0..127 of a workgroup (every lane calls it); tmp: one LDS word
+ZK_D uint32_t scan128_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((t & 63) >= d) inc += o;
+    }
+    if (t == 63) *tmp = inc;
+    __syncthreads();
+    if (t >= 64 && t < 128) inc += *tmp;
+    return inc - v;
+}
 __global__ void __launch_bounds__(PS_T) psort_final(const uint2* stage, const uint32_t* part_start, uint32_t P, uint32_t* entries,
                                                     uint32_t* offsets) {
-    constexpr uint32_t NB = 1u << PS_LOB;
-    __shared__ uint32_t cnt[NB], cur[NB];
+    constexpr uint32_t NB = 1u << PS_LOB, PER = PS_TILE / PS_T;
+    __shared__ uint32_t cnt[NB], cur[NB], toff[NB + 1], stmp;
+    __shared__ uint32_t sorted[PS_TILE];
+    __shared__ uint8_t skey[PS_TILE];
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t s = part_start[p], e = part_start[p + 1];
     if (t < NB) cnt[t] = 0;
     __syncthreads();
-#pragma unroll 4
     for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage[i].y], 1u);
     __syncthreads();
-    if (t == 0) {
-        uint32_t run = s;
-        for (uint32_t j = 0; j < NB; ++j) {
-            cur[j] = run;
-            run += cnt[j];
-        }
+    {
+        const uint32_t ex = scan128_excl(t < NB ? cnt[t] : 0u, t, &stmp);
+        if (t < NB) cur[t] = s + ex;
     }
     __syncthreads();
     if (t < NB) offsets[p * NB + t] = cur[t];
     if (p == P - 1 && t == 0) offsets[P * NB] = e;
-    __syncthreads();
-#pragma unroll 4
-    for (uint32_t i = s + t; i < e; i += PS_T) {
-        const uint2 v = stage[i];
-        entries[atomicAdd(&cur[v.y], 1u)] = v.x;
+    for (uint32_t base = s; base < e; base += PS_TILE) {
+        const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;   // references in this tile
+        __syncthreads();
+        if (t < NB) cnt[t] = 0;
+        __syncthreads();
+        uint2 v[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                v[k] = stage[base + i];
+                atomicAdd(&cnt[v[k].y], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t c = t < NB ? cnt[t] : 0u;
+            const uint32_t ex = scan128_excl(c, t, &stmp);
+            if (t < NB) toff[t] = ex;
+            if (t == NB - 1) toff[NB] = ex + c;
+        }
+        __syncthreads();
+        if (t < NB) cnt[t] = toff[t];      // running position inside the tile
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                const uint32_t q = atomicAdd(&cnt[v[k].y], 1u);
+                sorted[q] = v[k].x;
+                skey[q] = (uint8_t)v[k].y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;   // consecutive lanes -> consecutive positions of a bucket's run
+            if (i < m) {
+                const uint32_t j = skey[i];
+                entries[cur[j] + (i - toff[j])] = sorted[i];
+            }
+        }
+        __syncthreads();
+        if (t < NB) cur[t] += toff[t + 1] - toff[t];
     }
 }
 
@@ -1068,7 +1183,7 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         }
         hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)canon, (uint64_t)n, pl.g, dig);
     }
-    if (pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 1024) {
+    if (pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256) {
         const uint32_t P = pl.g1.nb >> PS_LOB;
         int rc = mb.stage.ensure((size_t)pl.nf * 8);
         if (rc) return rc;
@@ -1079,7 +1194,7 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         uint32_t* part_total = part_start + P + 1;
         hipLaunchKernelGGL(psort_scan_local, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total);
         hipLaunchKernelGGL(psort_scan_parts, dim3(1), dim3(1024), 0, st, part_total, P, part_start);
-        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist, part_start, (uint2*)mb.stage.p,
+        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, pl.nf, P, hist, part_start, (uint2*)mb.stage.p,
                            (uint32_t)n);
         hipLaunchKernelGGL(psort_final, dim3(P), dim3(PS_T), 0, st, (const uint2*)mb.stage.p, part_start, P, entries, offsets);
         ZK_HIP_TRY(hipGetLastError());

@@ -347,7 +347,7 @@ ZK_D uint32_t scan256_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
 // partition), so the 8-byte records leave as runs of consecutive addresses, one run per partition and tile.
 constexpr uint32_t PS_STILE = 16384;   // 16 digits per lane
 __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t nf, uint32_t P, const uint32_t* cursors,
-                                                      const uint32_t* part_start, uint2* stage, uint32_t n_real) {
+                                                      const uint32_t* part_start, uint32_t* stage_ref, uint8_t* stage_lo, uint32_t n_real) {
     constexpr uint32_t PER = PS_STILE / PS_T, LOM = (1u << PS_LOB) - 1u;
     __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
     __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | low bits << 15 | partition << 22
@@ -399,7 +399,9 @@ __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64
                 const uint64_t gi = base + (r & 0x3fffu);
                 const uint32_t wq = (uint32_t)(gi / n_real);
                 const uint32_t ref = (wq << 26) | (uint32_t)(gi - (uint64_t)wq * n_real) | (((r >> 14) & 1u) << 31);
-                stage[gcur[pp] + (q - toff[pp])] = make_uint2(ref, (r >> 15) & LOM);
+                const uint32_t dst = gcur[pp] + (q - toff[pp]);
+                stage_ref[dst] = ref;
+                stage_lo[dst] = (uint8_t)((r >> 15) & LOM);
             }
         }
         __syncthreads();
@@ -426,8 +428,8 @@ ZK_D uint32_t scan128_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
     if (t >= 64 && t < 128) inc += *tmp;
     return inc - v;
 }
-__global__ void __launch_bounds__(PS_T) psort_final(const uint2* stage, const uint32_t* part_start, uint32_t P, uint32_t* entries,
-                                                    uint32_t* offsets) {
+__global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, const uint8_t* stage_lo, const uint32_t* part_start, uint32_t P,
+                                                    uint32_t* entries, uint32_t* offsets) {
     constexpr uint32_t NB = 1u << PS_LOB, PER = PS_TILE / PS_T;
     __shared__ uint32_t cnt[NB], cur[NB], toff[NB + 1], stmp;
     __shared__ uint32_t sorted[PS_TILE];
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint2* stage, const ui
     const uint32_t s = part_start[p], e = part_start[p + 1];
     if (t < NB) cnt[t] = 0;
     __syncthreads();
-    for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage[i].y], 1u);
+    for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage_lo[i]], 1u);
     __syncthreads();
     {
         const uint32_t ex = scan128_excl(t < NB ? cnt[t] : 0u, t, &stmp);
@@ -455,7 +457,7 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint2* stage, const ui
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = k * PS_T + t;
             if (i < m) {
-                v[k] = stage[base + i];
+                v[k] = make_uint2(stage_ref[base + i], stage_lo[base + i]);
                 atomicAdd(&cnt[v[k].y], 1u);
             }
         }
@@ -1185,7 +1187,7 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
     }
     if (pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256) {
         const uint32_t P = pl.g1.nb >> PS_LOB;
-        int rc = mb.stage.ensure((size_t)pl.nf * 8);
+        int rc = mb.stage.ensure((size_t)pl.nf * 5);
         if (rc) return rc;
         if ((rc = mb.counts.ensure((size_t)P * PS_SLABS * 4))) return rc;
         hist = (uint32_t*)mb.counts.p;
@@ -1194,9 +1196,11 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         uint32_t* part_total = part_start + P + 1;
         hipLaunchKernelGGL(psort_scan_local, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total);
         hipLaunchKernelGGL(psort_scan_parts, dim3(1), dim3(1024), 0, st, part_total, P, part_start);
-        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, pl.nf, P, hist, part_start, (uint2*)mb.stage.p,
-                           (uint32_t)n);
-        hipLaunchKernelGGL(psort_final, dim3(P), dim3(PS_T), 0, st, (const uint2*)mb.stage.p, part_start, P, entries, offsets);
+        uint32_t* stage_ref = (uint32_t*)mb.stage.p;                       // references | their low bucket bits (nf bytes)
+        uint8_t* stage_lo = (uint8_t*)mb.stage.p + (size_t)pl.nf * 4;
+        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, pl.nf, P, hist, part_start, stage_ref, stage_lo, (uint32_t)n);
+        hipLaunchKernelGGL(psort_final, dim3(P), dim3(PS_T), 0, st, (const uint32_t*)stage_ref, (const uint8_t*)stage_lo, part_start, P, entries,
+                           offsets);
         ZK_HIP_TRY(hipGetLastError());
         return ZK_OK;
     }

@@ -4,19 +4,21 @@
 // reference at plonk-core/src/commitment.rs:45,83 and through every `PC::commit` / `PC::open`
 // (proof_system/prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,582-591,606,609-618).
 //
-// Pipeline (all on the ctx stream; no host round trip until the W window sums are read back):
-//   1. msm_digits     signed c-bit digits of every scalar (window-major int16)
-//   2. msm_hist       per-(window, slab) LDS histograms; msm_scan1/2/3 exclusive scan -> bucket
-//                     offsets and per-slab cursors (no global atomics anywhere in the sort)
-//   3. msm_scatter    counting-sort the (point, sign) references by (window, bucket) via LDS cursors
-//   4. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
-//                     additions (8M+2S, no inversion); runs that cross a chunk edge are emitted
+// Pipeline (all on the ctx stream; no host round trip until the window sums are read back):
+//   1. msm_digits(2)  signed c-bit digits of every scalar (window-major int16; into_repr fused for commits)
+//   2. sort           the (point, sign) references by bucket, no global atomics:
+//                       window-table path: psort_hist / psort_scan_* / psort_scatter / psort_final -- two-pass
+//                       partition sort over the one shared bucket set;
+//                       per-window path:   msm_hist / msm_scan1/2/3 / msm_scatter -- LDS counting sort
+//   3. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
+//                     additions (no inversion); runs that cross a chunk edge are emitted
 //                     as partials (load-balanced regardless of the scalar distribution)
-//   5. msm_combine*   joins the chunk-edge partials of each bucket: lane / wavefront (shuffle tree) /
+//   4. msm_combine*   joins the chunk-edge partials of each bucket: lane(s) / wavefront (shuffle tree) /
 //                     workgroup per bucket by size class
-//   6. msm_seg_reduce per-window segmented running-sum reduction (sum_j j*B_j), level 1
-//   7. msm_win_finish per-window LDS suffix-scan + tree reduction -> W window sums (arkworks layout)
-//   host: Horner over the W window sums (W*c doublings) and affine normalisation.
+//   5. msm_seg_reduce segmented running-sum reduction (sum_j j*B_j), level 1
+//   6. msm_win_finish LDS suffix-scan + tree reduction per (virtual) window -> window sums (arkworks layout)
+//   host: the few window sums are combined (table path: sum of 32 virtual windows; per-window path:
+//         Horner with W*c doublings) and normalised to affine.
 // Device arithmetic is the unsaturated 29-bit-limb Montgomery field of fieldu.cuh with the lazy XYZZ
 // group law of ecu.cuh; bases are converted once, at SRS registration, into that form.
 // The group sum is order-independent, so the non-deterministic order inside a bucket (atomic

@@ -73,6 +73,7 @@ SYMBOLS = {
     "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_msm_g1_srs_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_msm_g1_srs_partial_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "zk_selftest_quad_dev": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_void_p]),
     "zk_quotient_evals_dev": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_void_p]),
     "zk_perm_product_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -32,6 +32,7 @@ def jobs():
         ("kzg.o", "kzg.hip", [], HOST_HDRS),
         ("grand_product.o", "grand_product.hip", [], HOST_HDRS),
         ("quotient.o", "quotient.hip", [], HOST_HDRS),
+        ("quadtest.o", "quadtest.hip", [], HOST_HDRS + ["ecq.cuh"]),
         ("ntt.o", "ntt.hip", [], HOST_HDRS + ["ntt_pass.cuh"]),
         ("ntt_pass_table.o", "ntt_pass_table.hip", [], []),
         ("msm_dispatch.o", "msm_dispatch.hip", [], HOST_HDRS),

@@ -647,4 +647,16 @@ int zk_quotient_evals_dev(zk_ctx* c, int curve_id, uint32_t log_n, const zk_quot
     return quotient_evals_dev(c, curve_id, log_n, args, d_out);
 }
 
+// ------------------------------------------------------------------------------ device self-test
+int zk_selftest_quad_dev(zk_ctx* c, int curve_id, uint32_t n_quads, uint32_t* mismatches, uint32_t* case_mask) {
+    if (!c || !mismatches) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    uint32_t out[2] = {0, 0};
+    int rc = quad_selftest_dev(c, curve_id, n_quads, out);
+    if (rc) return rc;
+    *mismatches = out[0];
+    if (case_mask) *case_mask = out[1];
+    return ZK_OK;
+}
+
 }  // extern "C"

@@ -25,6 +25,7 @@
 // cursors) does not change the (canonical, affine) result.
 // Algorithmic bytes per MSM: N * (32 + 2*Fq bytes); the kernel is integer-VALU bound.
 #include "ctx.h"
+#include "ecq.cuh"
 
 namespace {
 
@@ -84,6 +85,16 @@ ZK_D void st_xyzz(void* arr, uint64_t idx, const XYZZu<F>& p) {
     st_fu<F>(q + Store<F>::U4, p.y);
     st_fu<F>(q + 2 * Store<F>::U4, p.zz);
     st_fu<F>(q + 3 * Store<F>::U4, p.zzz);
+}
+
+// one coordinate (role 0..3 = X, Y, ZZ, ZZZ) of a stored XYZZ point: the quad-cooperative kernels (ecq.cuh)
+template <class F>
+ZK_D F ld_coord(const void* arr, uint64_t idx, uint32_t role) {
+    return ld_fu<F>(reinterpret_cast<const uint4*>(arr) + idx * (4 * Store<F>::U4) + role * Store<F>::U4);
+}
+template <class F>
+ZK_D void st_coord(void* arr, uint64_t idx, uint32_t role, const F& c) {
+    st_fu<F>(reinterpret_cast<uint4*>(arr) + idx * (4 * Store<F>::U4) + role * Store<F>::U4, c);
 }
 
 struct MsmGeom {
@@ -806,6 +817,134 @@ __global__ void __launch_bounds__(256) msm_win_finish(RJobs jobs, MsmGeom g) {
     }
 }
 
+// ---- quad-cooperative forms of the three reduction kernels (ecq.cuh): four lanes per dependent chain,
+// an addition in 4.5 product-times instead of 13.5.  Same inputs, outputs and arithmetic results.
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_combine_q(RJobs jobs, uint32_t nb) {
+    const void* part_pt = jobs.part_pt[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* buckets = jobs.buckets[blockIdx.y];
+    uint32_t* q = jobs.q[blockIdx.y];
+    const uint32_t L = jobs.L[blockIdx.y];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = id >> 2, role = id & 3;
+    uint32_t s = 0, ta = 0, np = 0;     // np = partials this quad sums itself (0: nothing to do)
+    if (b < nb) {
+        s = offsets[b];
+        const uint32_t e = offsets[b + 1];
+        if (e != s) {
+            ta = s / L;
+            const uint32_t p = (e - 1) / L - ta + 1;
+            if (p > COMBINE_MEDIUM) {
+                if (role == 0) q[2 + nb - 1 - atomicAdd(&q[1], 1u)] = b;
+            } else if (p > COMBINE_SMALL) {
+                if (role == 0) q[2 + atomicAdd(&q[0], 1u)] = b;
+            } else if (p > 1) {
+                np = p;
+            }
+        }
+    }
+    // the quads of a wavefront run in lock step to the longest bucket among them; shorter ones add infinity
+    uint32_t steps = np;
+#pragma unroll
+    for (int d = 32; d >= 4; d >>= 1) {
+        const uint32_t o = __shfl_xor(steps, d, 64);
+        steps = o > steps ? o : steps;
+    }
+    F acc = F::zero();
+#pragma unroll 1
+    for (uint32_t k = 0; k < steps; ++k) {
+        F v = F::zero();
+        if (k < np) v = ld_coord<F>(part_pt, partial_slot(ta + k, ta, s, L), role);
+        acc = qadd<F>(acc, v, role);
+    }
+    if (np) st_coord<F>(buckets, b, role, acc);
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_seg_reduce_q(RJobs jobs, MsmGeom g) {
+    const void* buckets = jobs.buckets[blockIdx.y];
+    const uint32_t* offsets = jobs.offsets[blockIdx.y];
+    void* seg_run = jobs.seg_run[blockIdx.y];
+    void* seg_acc = jobs.seg_acc[blockIdx.y];
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t id = tid >> 2, role = tid & 3;
+    const bool live = id < g.W * g.ns;              // no early exit: wave shuffles inside qadd
+    const uint32_t w = live ? id / g.ns : 0, sg = live ? id % g.ns : 0;
+    const uint32_t G = 1u << g.logG;
+    F run = F::zero(), acc = F::zero();
+#pragma unroll 1
+    for (int i = (int)G - 1; i >= 0; --i) {
+        const uint32_t bi = w * g.B + sg * G + (uint32_t)i;
+        F v = F::zero();
+        if (live && offsets[bi + 1] != offsets[bi]) v = ld_coord<F>(buckets, bi, role);
+        run = qadd<F>(run, v, role);
+        acc = qadd<F>(acc, run, role);
+    }
+    if (live) {
+        st_coord<F>(seg_run, id, role, run);
+        st_coord<F>(seg_acc, id, role, acc);
+    }
+}
+
+// msm_win_finish for logq == 0 (one segment per chain): 4 * ns lanes per workgroup, ns <= 256
+template <class F>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_win_finish_q(RJobs jobs, MsmGeom g) {
+    extern __shared__ uint4 sh[];
+    const void* seg_run = jobs.seg_run[blockIdx.y];
+    const void* seg_acc = jobs.seg_acc[blockIdx.y];
+    uint32_t* win_out = jobs.win_s[blockIdx.y];
+    uint32_t* tot_out = jobs.win_t[blockIdx.y];
+    const uint32_t w = blockIdx.x, u = threadIdx.x >> 2, role = threadIdx.x & 3;
+    const uint32_t T = blockDim.x >> 2;             // chains = power of two >= ns
+    F R = F::zero(), Y = F::zero();
+    if (u < g.ns) {
+        R = ld_coord<F>(seg_run, (uint64_t)w * g.ns + u, role);
+        Y = ld_coord<F>(seg_acc, (uint64_t)w * g.ns + u, role);
+    }
+    // suffix sums Q_u = sum_{u' >= u} R_u'  (Hillis-Steele in LDS)
+    st_coord<F>(sh, u, role, R);
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        __syncthreads();
+        F o = F::zero();
+        if (u + d < T) o = ld_coord<F>(sh, u + d, role);
+        __syncthreads();
+        R = qadd<F>(R, o, role);
+        st_coord<F>(sh, u, role, R);
+    }
+    const bool r_inf = quad_is_inf(R, role);
+    if (tot_out && u == 0) {
+        uint32_t* o = tot_out + (size_t)w * 4 * F::SAT + role * F::SAT;
+        if (r_inf) {
+            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        } else {
+            R.to_sat(o);
+        }
+    }
+    // Z = Y + G * Q_u   (u >= 1)
+    F Qm = R;
+    for (uint32_t k = 0; k < g.logG; ++k) Qm = qdbl<F>(Qm, role);
+    F Z = qadd<F>(Y, u >= 1 ? Qm : F::zero(), role);
+    __syncthreads();
+    st_coord<F>(sh, u, role, Z);
+    for (uint32_t d = T / 2; d >= 1; d >>= 1) {
+        __syncthreads();
+        if (u < d) {                                 // quad-uniform: all four lanes of a chain agree
+            Z = qadd<F>(Z, ld_coord<F>(sh, u + d, role), role);
+            st_coord<F>(sh, u, role, Z);
+        }
+    }
+    const bool z_inf = quad_is_inf(Z, role);
+    if (u == 0) {
+        uint32_t* o = win_out + (size_t)w * 4 * F::SAT + role * F::SAT;
+        if (z_inf) {
+            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        } else {
+            Z.to_sat(o);
+        }
+    }
+}
+
 // arkworks-layout affine (x||y Montgomery words; x = y = 0 or flagged = infinity) -> internal points
 template <class F>
 __global__ void bases_to_internal(const uint32_t* xy_sat, const uint8_t* inf, uint64_t n, void* out) {
@@ -867,21 +1006,39 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
     for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
+    // quad-cooperative kernels where the geometry allows (one segment per chain, <= 256 chains per window)
+    const bool quad = gr.logq == 0 && gr.ns <= 256;
     if (n_jobs <= 2) {
-        unsigned blocks = (unsigned)(((uint64_t)nb * 4 + T - 1) / T);
-        hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+        if (quad) {
+            unsigned blocks = (unsigned)(((uint64_t)nb * 4 + 255) / 256);
+            hipLaunchKernelGGL(msm_combine_q<F>, dim3(blocks, n_jobs), dim3(256), 0, st, jobs, nb);
+        } else {
+            unsigned blocks = (unsigned)(((uint64_t)nb * 4 + T - 1) / T);
+            hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+        }
     } else {
         unsigned blocks = (unsigned)(((uint64_t)nb + T - 1) / T);
         hipLaunchKernelGGL((msm_combine<F, 1>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
     }
     hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
     hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);
-    unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
-    hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
-    size_t shmem = 256 * PT;
-    if (shmem > 48 * 1024)
-        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(msm_win_finish<F>, dim3(gr.W, n_jobs), dim3(256), shmem, st, jobs, gr);
+    if (quad) {
+        unsigned sblocks = (unsigned)(((uint64_t)gr.W * gr.ns * 4 + 255) / 256);
+        hipLaunchKernelGGL(msm_seg_reduce_q<F>, dim3(sblocks, n_jobs), dim3(256), 0, st, jobs, gr);
+        uint32_t chains = 1;
+        while (chains < gr.ns) chains <<= 1;
+        size_t shmem = (size_t)chains * PT;
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(gr.W, n_jobs), dim3(4 * chains), shmem, st, jobs, gr);
+    } else {
+        unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
+        size_t shmem = 256 * PT;
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish<F>, dim3(gr.W, n_jobs), dim3(256), shmem, st, jobs, gr);
+    }
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
@@ -1075,7 +1232,8 @@ __global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, u
 
 constexpr uint32_t PRE_C = 16;        // window of the precomputed table (largest the LDS sort handles)
 constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
-constexpr uint32_t PRE_VW = 32;       // virtual windows for the final bucket reduction
+constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket reduction: 128 chains x 4 lanes per workgroup
+                                      // (256 registers per lane; with 32 windows the 1024-lane workgroup spilled at 128)
 
 template <class Cv>
 int msm_precompute_run(zk_ctx* c, zk_srs* s) {

@@ -225,6 +225,12 @@ typedef struct zk_quotient_args {
 /* n = 2^log_n is the circuit domain size; vectors hold 4n elements.  d_out (4n elements) must not alias an input. */
 int zk_quotient_evals_dev(zk_ctx* ctx, int curve_id, uint32_t log_n, const zk_quotient_args* args, void* d_out);
 
+/* ---- device self-test ------------------------------------------------------------------------------ */
+/* Runs the quad-cooperative point arithmetic of the bucket-reduction kernels (csrc/ecq.cuh) against the
+ * single-lane group law on n_quads point pairs incl. doubling, cancellation and infinity cases.
+ * *mismatches = number of disagreeing pairs (0 expected); *case_mask (optional) = which cases failed. */
+int zk_selftest_quad_dev(zk_ctx* ctx, int curve_id, uint32_t n_quads, uint32_t* mismatches, uint32_t* case_mask);
+
 /* ---- utilities (synthetic SRS for tests/bench; stands in for PC::setup, out of scope) --------- */
 /* out[i] = scalars[i] * G1 generator, affine Montgomery, device buffers. */
 int zk_g1_fixed_base_batch_dev(zk_ctx* ctx, int curve_id, const void* d_scalars, size_t n, void* d_out_xy);

@@ -349,3 +349,14 @@ def test_round_batch_with_very_different_lengths(ctx):
     mixed = polys + [polys[0][:100]]                            # one job below the threshold
     assert ck.commit_batch(mixed) == plain + [ck.commit(polys[0][:100])]
     ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_quad_cooperative_group_law(cid, ctx):
+    """csrc/ecq.cuh (a point spread over four lanes, four product rounds per addition) against the single-lane law of
+    ecu.cuh on the device: generic pairs, doubling, cancellation, infinities and a fed-back chain."""
+    import ctypes
+    bad = ctypes.c_uint32(123)
+    mask = ctypes.c_uint32(0)
+    _lib.check(_lib.lib().zk_selftest_quad_dev(ctx.handle, cid, 6000, ctypes.byref(bad), ctypes.byref(mask)))
+    assert bad.value == 0, f"{bad.value} mismatching quads, case mask {mask.value:#x}"

@@ -1419,20 +1419,49 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
     return ZK_OK;
 }
 
-// host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index)
+// host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index).
+// The sum over v is cut into HOST_CHUNKS ranges that can run on different pool threads:
+//   range [lo, hi): s = sum S_v, t = sum T_v, w = sum (v - lo) * T_v     (running sums, 3 additions per window)
+//   S = sum_c s_c + B_v * sum_c (w_c + lo_c * t_c),  lo_c = c * (VW / HOST_CHUNKS)
+constexpr uint32_t HOST_CHUNKS = 4;
+template <class Fq>
+struct HostPartial {
+    XYZZ<Fq> s, t, w;
+};
 template <class Cv>
-void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
+void pre_host_partial(const void* h_win, uint32_t VW, uint32_t lo, uint32_t hi, HostPartial<typename Cv::Fq>& out) {
+    typedef XYZZ<typename Cv::Fq> PH;
+    const PH* win = (const PH*)h_win;
+    PH s = PH::infinity(), run = PH::infinity(), w = PH::infinity();
+    for (int v = (int)hi - 1; v >= (int)lo; --v) {
+        s = PH::add(s, win[v]);
+        if (v > (int)lo) {
+            run = PH::add(run, win[VW + v]);
+            w = PH::add(w, run);
+        }
+    }
+    out.s = s;
+    out.t = PH::add(run, win[VW + lo]);
+    out.w = w;
+}
+template <class Cv>
+void pre_host_final(const HostPartial<typename Cv::Fq>* part, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
     typedef typename Cv::Fq Fq;
     typedef XYZZ<Fq> PH;
     constexpr int L64 = Fq::N / 2;
-    const PH* win = (const PH*)h_win;
-    PH total = PH::infinity(), run = PH::infinity(), wsum = PH::infinity();
-    for (int v = (int)VW - 1; v >= 1; --v) {
-        run = PH::add(run, win[VW + v]);
-        wsum = PH::add(wsum, run);
+    // sum_c c * t_c by running sums, then times the chunk length (a power of two), plus the local weights
+    PH total = PH::infinity(), run = PH::infinity(), ct = PH::infinity(), wsum = PH::infinity();
+    for (int c = (int)HOST_CHUNKS - 1; c >= 0; --c) {
+        total = PH::add(total, part[c].s);
+        wsum = PH::add(wsum, part[c].w);
+        if (c >= 1) {
+            run = PH::add(run, part[c].t);
+            ct = PH::add(ct, run);
+        }
     }
+    for (uint32_t k = 0; (1u << k) < VW / HOST_CHUNKS; ++k) ct = PH::dbl(ct);
+    wsum = PH::add(wsum, ct);
     for (uint32_t k = 0; (1u << k) < VB; ++k) wsum = PH::dbl(wsum);
-    for (uint32_t v = 0; v < VW; ++v) total = PH::add(total, win[v]);
     total = PH::add(total, wsum);
     Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
     if (!total.is_inf()) {
@@ -1443,6 +1472,12 @@ void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out
     memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
     memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
     memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
+}
+template <class Cv>
+void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
+    HostPartial<typename Cv::Fq> part[HOST_CHUNKS];
+    for (uint32_t c = 0; c < HOST_CHUNKS; ++c) pre_host_partial<Cv>(h_win, VW, c * (VW / HOST_CHUNKS), (c + 1) * (VW / HOST_CHUNKS), part[c]);
+    pre_host_final<Cv>(part, VW, VB, out_xyz);
 }
 
 int ensure_pinned(zk_ctx* c, size_t bytes) {
@@ -1507,11 +1542,25 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     ZK_HIP_TRY(hipStreamSynchronize(st));
     const char* h_win = (const char*)c->pinned;
     int rcs[MAX_JOBS] = {0};
-    c->pool->run(n_polys, [&](uint32_t k) {
-        uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
-        pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, xyz);
-        if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
-    });
+    if (n_polys <= 2) {
+        // few jobs: the window ranges of a job go to different pool threads as well
+        HostPartial<Fq> part[2 * HOST_CHUNKS];
+        c->pool->run(n_polys * HOST_CHUNKS, [&](uint32_t i) {
+            const uint32_t k = i / HOST_CHUNKS, ch = i % HOST_CHUNKS, VW = pl[k].gv.W;
+            pre_host_partial<Cv>(h_win + (size_t)k * wb, VW, ch * (VW / HOST_CHUNKS), (ch + 1) * (VW / HOST_CHUNKS), part[i]);
+        });
+        for (uint32_t k = 0; k < n_polys; ++k) {
+            uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
+            pre_host_final<Cv>(part + k * HOST_CHUNKS, pl[k].gv.W, pl[k].gv.B, xyz);
+            if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
+        }
+    } else {
+        c->pool->run(n_polys, [&](uint32_t k) {
+            uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
+            pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, xyz);
+            if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
+        });
+    }
     for (uint32_t k = 0; k < n_polys; ++k)
         if (rcs[k]) return rcs[k];
     return ZK_OK;

@@ -9,6 +9,7 @@
 // field (fieldu.cuh): data stay in the arkworks Montgomery domain (R = 2^256) because every twiddle
 // table holds w * 2^261 mod r, and DIT butterflies (t = w*b; a + t, a - t + 2r) grow the lazily
 // reduced values only additively (< 20 r after 9 stages), so no reduction is needed inside a pass.
+// The first stage of every pass has the twiddle 1 throughout and skips the product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_params.h"
@@ -93,6 +94,16 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
         for (int e = 0; e < 8; ++e) {
             if (e & (1 << lb)) continue;
             const int eo = e | (1 << lb);
+            if constexpr (B0 == 0 && LB_LO == 0) {
+                // first stage of a pass (t = 0): every twiddle is w^0 = 1 and the operands are still < 2r
+                // (fresh loads / products), so the butterfly is a + b, a - b + 2r with no product at all
+                if (lb == 0) {
+                    const F b = x[eo];
+                    x[eo] = F::sub2(x[e], b);
+                    x[e] = F::add(x[e], b);
+                    continue;
+                }
+            }
             const uint32_t plow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
             const uint32_t j = plow << (S - 1 - t);
             F w = ld_u<F>(tw, j);

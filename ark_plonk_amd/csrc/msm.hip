@@ -7,7 +7,7 @@
 // Pipeline (all on the ctx stream; no host round trip until the window sums are read back):
 //   1. msm_digits(2)  signed c-bit digits of every scalar (window-major int16; into_repr fused for commits)
 //   2. sort           the (point, sign) references by bucket, no global atomics:
-//                       window-table path: psort_hist / psort_scan_* / psort_scatter / psort_final -- two-pass
+//                       window-table path: psort_hist / psort_scan / psort_scatter / psort_final -- two-pass
 //                       partition sort over the one shared bucket set;
 //                       per-window path:   msm_hist / msm_scan1/2/3 / msm_scatter -- LDS counting sort
 //   3. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
@@ -283,7 +283,7 @@ __global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t 
 // writes 16-byte runs at random places (measured: 513 MB leaving L2 per launch for 67 MB of output).
 // Here the references first go to P = nb/128 partitions by the high bucket bits -- every (slab, partition)
 // run is ~1 KiB contiguous -- and one workgroup per partition then orders its ~nf/P references by the low
-// 7 bits out of L2.  psort_hist / psort_scan_local / psort_scan_parts / psort_scatter / psort_final; order
+// 7 bits out of L2.  psort_hist / psort_scan / psort_scatter / psort_final; order
 // inside a bucket is arbitrary (the sums are commutative).  Measured at 2^20: 0.23 ms against 0.33 ms for
 // msm_hist + msm_scan1/2/3 + msm_scatter; what is left is the ~64 distinct cache lines every wave-store of
 // the two placement kernels touches.
@@ -291,8 +291,10 @@ constexpr uint32_t PS_LOB = 7;        // low bucket bits ordered inside a partit
 constexpr uint32_t PS_T = 1024;
 constexpr uint32_t PS_SLABS = 1024;   // workgroups of the partition passes
 
-__global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t nf, uint32_t P, uint32_t* hist /* [P][PS_SLABS] */) {
+__global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t nf, uint32_t P, uint32_t* hist /* [P][PS_SLABS] */,
+                                                   uint32_t* scan_counter) {
     extern __shared__ uint32_t lc[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scan_counter = 0;
     for (uint32_t j = threadIdx.x; j < P; j += PS_T) lc[j] = 0;
     __syncthreads();
     uint64_t lo, hi;
@@ -305,9 +307,13 @@ __global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t 
     for (uint32_t j = threadIdx.x; j < P; j += PS_T) hist[(uint64_t)j * PS_SLABS + blockIdx.x] = lc[j];
 }
 
-// per partition: exclusive scan of its PS_SLABS slab counts in place (coalesced), partition total out
-__global__ void __launch_bounds__(PS_SLABS) psort_scan_local(uint32_t* hist, uint32_t* part_total) {
+// per partition: exclusive scan of its PS_SLABS slab counts in place (coalesced); the workgroup that finishes
+// last (a counter, no waiting) then scans the P (<= 256) partition totals into part_start[0..P].
+// `counter` must be 0 on entry (psort_hist clears it) and is left 0.
+__global__ void __launch_bounds__(PS_SLABS) psort_scan(uint32_t* hist, uint32_t* part_total, uint32_t P, uint32_t* part_start,
+                                                       uint32_t* counter) {
     __shared__ uint32_t part[PS_SLABS];
+    __shared__ uint32_t last_block;
     const uint32_t t = threadIdx.x;
     uint32_t* row = hist + (uint64_t)blockIdx.x * PS_SLABS;
     const uint32_t v = row[t];
@@ -320,23 +326,27 @@ __global__ void __launch_bounds__(PS_SLABS) psort_scan_local(uint32_t* hist, uin
         __syncthreads();
     }
     row[t] = part[t] - v;
-    if (t == PS_SLABS - 1) part_total[blockIdx.x] = part[t];
-}
-// exclusive scan of the P (<= 1024) partition totals -> part_start[0..P]
-__global__ void __launch_bounds__(1024) psort_scan_parts(const uint32_t* part_total, uint32_t P, uint32_t* part_start) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t v = t < P ? part_total[t] : 0u;
-    part[t] = v;
+    if (t == PS_SLABS - 1) {
+        part_total[blockIdx.x] = part[t];
+        __threadfence();
+        last_block = atomicAdd(counter, 1u) == P - 1 ? 1u : 0u;
+    }
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    if (!last_block) return;
+    const uint32_t tv = t < P ? ((volatile uint32_t*)part_total)[t] : 0u;
+    part[t] = tv;
+    __syncthreads();
+    for (uint32_t d = 1; d < PS_SLABS; d <<= 1) {
         uint32_t o = t >= d ? part[t - d] : 0u;
         __syncthreads();
         part[t] += o;
         __syncthreads();
     }
-    if (t < P) part_start[t] = part[t] - v;
-    if (t == 1023) part_start[P] = part[1023];
+    if (t < P) part_start[t] = part[t] - tv;
+    if (t == PS_SLABS - 1) {
+        part_start[P] = part[t];
+        *counter = 0;
+    }
 }
 
 // exclusive scan of 256 values held by lanes 0..255 of a workgroup (every lane calls it); tmp: 4 LDS words
@@ -1352,10 +1362,10 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         if ((rc = mb.counts.ensure((size_t)P * PS_SLABS * 4))) return rc;
         hist = (uint32_t*)mb.counts.p;
         uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 values (the buffer holds nb + 2)
-        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist);
         uint32_t* part_total = part_start + P + 1;
-        hipLaunchKernelGGL(psort_scan_local, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total);
-        hipLaunchKernelGGL(psort_scan_parts, dim3(1), dim3(1024), 0, st, part_total, P, part_start);
+        uint32_t* scan_counter = part_total + P;
+        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist, scan_counter);
+        hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
         uint32_t* stage_ref = (uint32_t*)mb.stage.p;                       // references | their low bucket bits (nf bytes)
         uint8_t* stage_lo = (uint8_t*)mb.stage.p + (size_t)pl.nf * 4;
         hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, pl.nf, P, hist, part_start, stage_ref, stage_lo, (uint32_t)n);

@@ -323,6 +323,7 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
             a.log_mprev = log_mprev;
             a.tw_pass = pl->tw_pass[p];
             a.n_tiles = (uint32_t)(N >> ((uint32_t)s + logc));
+            a.quarter = (p == 0 && s >= 3 && (uint64_t)in_len * 4 <= N) ? 1u : 0u;
             log_mprev = log_m;
         } else {
             uint32_t s1 = (pl->n_pass > 1) ? (uint32_t)pl->s[0] : 0;

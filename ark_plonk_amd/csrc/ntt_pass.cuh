@@ -33,6 +33,8 @@ struct NttPassArgs {
     uint32_t log_mprev;     // non-final: log2 of the block this pass transforms (M * L)
     uint32_t s1;            // final: size (bits) of the most significant digit of the block index
     uint32_t n_tiles;
+    uint32_t quarter;       // first pass of a multi-pass transform whose input fills at most N/4 (coset_fft of n coefficients on
+                            // the 4n domain): only rows < 2^S / 4 are non-zero, so the first two stages are plain copies
 };
 
 __host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
@@ -85,7 +87,7 @@ ZK_D void wave_exchange(F (&x)[8], lds_u32* sc, const uint32_t (&widx)[8], const
 // DIT stages for the position bits B0+LB_LO .. B0+LB_HI-1 on the 8 registers of a lane
 // (register e <-> position bits [B0, B0+3) ; v = the other position bits)
 template <class F, int S, int B0, int LB_LO, int LB_HI>
-ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
+ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw, bool quarter) {
     const uint32_t vlow = v & ((1u << B0) - 1u);
 #pragma unroll
     for (int lb = LB_LO; lb < LB_HI; ++lb) {
@@ -97,6 +99,10 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
             if constexpr (B0 == 0 && LB_LO == 0) {
                 // first stage of a pass (t = 0): every twiddle is w^0 = 1 and the operands are still < 2r
                 // (fresh loads / products), so the butterfly is a + b, a - b + 2r with no product at all
+                if (lb < 2 && quarter) {   // the partner is zero (or a copy of a zero-partnered value): a + w*0, a - w*0
+                    x[eo] = x[e];
+                    continue;
+                }
                 if (lb == 0) {
                     const F b = x[eo];
                     x[eo] = F::sub2(x[e], b);
@@ -117,10 +123,10 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw) {
 // all windows of a 2^S-point DIT; on entry x[e] holds position 8v+e (window B0 = 0), on exit the
 // top-window layout: position (e << (S-3)) | v  (S >= 3)
 template <class F, int S, int B0>
-ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw, lds_u32* sc) {
+ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw, lds_u32* sc, bool quarter = false) {
     constexpr int REM = S - B0;          // position bits not yet processed
     if constexpr (REM >= 3) {
-        dit_window<F, S, B0, 0, 3>(x, v, tw);
+        dit_window<F, S, B0, 0, 3>(x, v, tw, quarter);
         if constexpr (REM > 3) {
             constexpr int NB0 = (REM - 3 >= 3) ? B0 + 3 : S - 3;
             uint32_t wi[8], ri[8];
@@ -134,7 +140,7 @@ ZK_D void dit_all(F (&x)[8], uint32_t v, uint32_t c, uint32_t LC, const void* tw
                 dit_all<F, S, B0 + 3>(x, v, c, LC, tw, sc);
             } else {
                 // last, partial window: registers cover position bits [S-3, S); only the top REM-3 are new
-                dit_window<F, S, S - 3, 3 - (REM - 3), 3>(x, v, tw);
+                dit_window<F, S, S - 3, 3 - (REM - 3), 3>(x, v, tw, false);
             }
         }
     }
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
             x[e] = F::zero();
         }
     }
-    dit_all<F, S, 0>(x, v, c, LC, a.tw_inner, sc);
+    dit_all<F, S, 0>(x, v, c, LC, a.tw_inner, sc, a.quarter != 0);
     if (!active) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

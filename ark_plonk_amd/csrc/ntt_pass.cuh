@@ -8,8 +8,10 @@
 // tile, so occupancy is bounded by VGPRs only).  Arithmetic is the unsaturated 29-bit-limb Montgomery
 // field (fieldu.cuh): data stay in the arkworks Montgomery domain (R = 2^256) because every twiddle
 // table holds w * 2^261 mod r, and DIT butterflies (t = w*b; a + t, a - t + 2r) grow the lazily
-// reduced values only additively (< 20 r after 9 stages), so no reduction is needed inside a pass.
-// The first stage of every pass has the twiddle 1 throughout and skips the product.
+// reduced values only additively, so no reduction is needed inside a pass (a Montgomery product accepts
+// a * b < 69 r^2; the data stay below 40r and every twiddle below r).
+// The butterflies of the first window whose twiddle is w^0 = 1 (all of stage 0, half of stage 1, a quarter
+// of stage 2) are done without a product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_params.h"
@@ -106,6 +108,15 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw, bool quarter) {
                 if (lb == 0) {
                     const F b = x[eo];
                     x[eo] = F::sub2(x[e], b);
+                    x[e] = F::add(x[e], b);
+                    continue;
+                }
+                // stages 1 and 2 of the first window: the twiddle index is (e mod 2^lb) << (S-1-lb), i.e. w^0 = 1
+                // for the pairs with e mod 2^lb == 0.  Their operands are no longer < 2r (< 4r after stage 0,
+                // < 12r after stage 1), hence the larger offsets; the pass still ends below 40r < 2^261.
+                if ((e & ((1 << lb) - 1)) == 0) {
+                    const F b = x[eo];
+                    x[eo] = lb == 1 ? F::sub8(x[e], b) : F::sub16(x[e], b);
                     x[e] = F::add(x[e], b);
                     continue;
                 }

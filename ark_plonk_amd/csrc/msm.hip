@@ -1418,15 +1418,13 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         jobs.q[k] = (uint32_t*)mb.part_key.p;
         jobs.seg_run[k] = mb.seg.p;
         jobs.seg_acc[k] = (char*)mb.seg.p + (size_t)p0.gv.W * p0.gv.ns * PT;
-        jobs.win_s[k] = (uint32_t*)mb.win.p;
-        jobs.win_t[k] = (uint32_t*)mb.win.p + (size_t)p0.gv.W * 4 * F::SAT;
+        // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
+        // buffer (hipHostMalloc memory is device-visible): no copy launches at the tail of the call
+        jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
+        jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
         jobs.L[k] = pls[k].chunk_l;
     }
-    int rc = queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st);
-    if (rc) return rc;
-    for (uint32_t k = 0; k < n_jobs; ++k)
-        ZK_HIP_TRY(hipMemcpyAsync((char*)h_win + (size_t)k * p0.win_bytes, mbs[k].win.p, p0.win_bytes, hipMemcpyDeviceToHost, st));
-    return ZK_OK;
+    return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st);
 }
 
 // host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index).

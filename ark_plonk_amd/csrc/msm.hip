@@ -292,9 +292,13 @@ constexpr uint32_t PS_T = 1024;
 constexpr uint32_t PS_SLABS = 1024;   // workgroups of the partition passes
 
 __global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t nf, uint32_t P, uint32_t* hist /* [P][PS_SLABS] */,
-                                                   uint32_t* scan_counter) {
+                                                   uint32_t* scan_counter, uint32_t* combine_q) {
     extern __shared__ uint32_t lc[];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *scan_counter = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scan_counter[0] = 0;
+        combine_q[0] = 0;      // counters of the combine queues of this job (msm_combine*)
+        combine_q[1] = 0;
+    }
     for (uint32_t j = threadIdx.x; j < P; j += PS_T) lc[j] = 0;
     __syncthreads();
     uint64_t lo, hi;
@@ -1011,11 +1015,12 @@ __global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, ui
 // ---------------------------------------------------------------------------------------- host side
 // combine + segmented reduction of n_jobs MSMs that share the geometry (nb buckets, reduction geometry gr)
 template <class F>
-int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st) {
+int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st, bool queues_cleared = false) {
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
-    for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
+    if (!queues_cleared)
+        for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
     // quad-cooperative kernels where the geometry allows (one segment per chain, <= 256 chains per window)
     const bool quad = gr.logq == 0 && gr.ns <= 256;
     if (n_jobs <= 2) {
@@ -1242,6 +1247,7 @@ __global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, u
 
 constexpr uint32_t PRE_C = 16;        // window of the precomputed table (largest the LDS sort handles)
 constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
+constexpr uint32_t PRE_Q_OFF = 1024;  // words of part_key in front of the combine queues (partition starts, totals, counter)
 constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket reduction: 128 chains x 4 lanes per workgroup
                                       // (256 registers per lane; with 32 windows the 1024-lane workgroup spilled at 128)
 
@@ -1324,7 +1330,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
     if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
-    if ((rc = mb.part_key.ensure((size_t)(pl.g.B + 2) * 4))) return rc;
+    if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
     if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
     if ((rc = mb.win.ensure(pl.win_bytes))) return rc;
     return ZK_OK;
@@ -1364,7 +1370,8 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 values (the buffer holds nb + 2)
         uint32_t* part_total = part_start + P + 1;
         uint32_t* scan_counter = part_total + P;
-        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist, scan_counter);
+        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist, scan_counter,
+                           (uint32_t*)mb.part_key.p + PRE_Q_OFF);
         hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
         uint32_t* stage_ref = (uint32_t*)mb.stage.p;                       // references | their low bucket bits (nf bytes)
         uint8_t* stage_lo = (uint8_t*)mb.stage.p + (size_t)pl.nf * 4;
@@ -1379,6 +1386,7 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    ZK_HIP_TRY(hipMemsetAsync((uint32_t*)mb.part_key.p + PRE_Q_OFF, 0, 8, st));   // combine queue counters (see pre_queue_reduce)
     hipLaunchKernelGGL(msm_hist, dim3(pl.S, 1), dim3(1024), lds, st, dig, pl.nf, pl.g1, pl.S, hist);
     const unsigned nblk = (pl.g1.nb + 1023) / 1024;
     hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, pl.g1, pl.S, bsum);
@@ -1415,7 +1423,7 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         jobs.part_pt[k] = mb.part_pt.p;
         jobs.offsets[k] = (const uint32_t*)mb.offsets.p;
         jobs.buckets[k] = mb.buckets.p;
-        jobs.q[k] = (uint32_t*)mb.part_key.p;
+        jobs.q[k] = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
         jobs.seg_run[k] = mb.seg.p;
         jobs.seg_acc[k] = (char*)mb.seg.p + (size_t)p0.gv.W * p0.gv.ns * PT;
         // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
@@ -1424,7 +1432,8 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
         jobs.L[k] = pls[k].chunk_l;
     }
-    return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st);
+    // the queue counters were cleared by the job's sort (psort_hist / the memset of the fallback sort)
+    return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
 }
 
 // host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index).

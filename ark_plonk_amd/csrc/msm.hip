@@ -291,20 +291,76 @@ constexpr uint32_t PS_LOB = 7;        // low bucket bits ordered inside a partit
 constexpr uint32_t PS_T = 1024;
 constexpr uint32_t PS_SLABS = 1024;   // workgroups of the partition passes
 
-__global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t nf, uint32_t P, uint32_t* hist /* [P][PS_SLABS] */,
-                                                   uint32_t* scan_counter, uint32_t* combine_q) {
-    extern __shared__ uint32_t lc[];
+// A slab of the partition sort = a range of SCALARS with all their W digits (dig[w*n + i], i in the range), so
+// that the kernel that produces the digits can count them too.  sp = scalars per slab (even).
+ZK_HD uint32_t psort_slab_len(uint64_t n) {
+    uint64_t sp = (n + PS_SLABS - 1) / PS_SLABS;
+    sp = (sp + 1) & ~1ull;
+    return (uint32_t)(sp < 2 ? 2 : sp);
+}
+
+// digits of the slab's scalars (as msm_digits2: two scalars per lane, 16-bit windows) + the slab's partition counts
+template <class Fr, bool MONT>
+__global__ void __launch_bounds__(256) psort_digits_hist(const uint32_t* scalars, uint64_t n, uint32_t sp, int16_t* dig,
+                                                         uint32_t* hist /* [256][PS_SLABS] */, uint32_t* scan_counter, uint32_t* combine_q) {
+    __shared__ uint32_t lc[256];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scan_counter[0] = 0;
         combine_q[0] = 0;      // counters of the combine queues of this job (msm_combine*)
         combine_q[1] = 0;
     }
+    lc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;      // n even, sp even: the range holds whole pairs
+    for (uint64_t i0 = lo + 2 * threadIdx.x; i0 < hi; i0 += 512) {
+        uint32_t sc[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (i0 + h);
+            uint4 a = q[0], b = q[1];
+            Fr x;
+            x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+            x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+            if (MONT) x = Fr::from_mont(x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sc[h][k] = x.v[k];
+        }
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            uint32_t r0 = ((sc[0][w >> 1] >> (16 * (w & 1))) & 0xffffu) + c0;
+            uint32_t r1 = ((sc[1][w >> 1] >> (16 * (w & 1))) & 0xffffu) + c1;
+            c0 = r0 >= 0x8000u ? 1u : 0u;
+            c1 = r1 >= 0x8000u ? 1u : 0u;
+            r0 &= 0xffffu;
+            r1 &= 0xffffu;
+            *reinterpret_cast<uint32_t*>(dig + (uint64_t)w * n + i0) = r0 | (r1 << 16);
+            if (r0) atomicAdd(&lc[((c0 ? 0x10000u - r0 : r0) - 1u) >> PS_LOB], 1u);
+            if (r1) atomicAdd(&lc[((c1 ? 0x10000u - r1 : r1) - 1u) >> PS_LOB], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * PS_SLABS + blockIdx.x] = lc[threadIdx.x];
+}
+
+// the same counts from an existing digit array (lengths the fused kernel does not take)
+__global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t P,
+                                                   uint32_t* hist /* [P][PS_SLABS] */, uint32_t* scan_counter, uint32_t* combine_q) {
+    extern __shared__ uint32_t lc[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scan_counter[0] = 0;
+        combine_q[0] = 0;
+        combine_q[1] = 0;
+    }
     for (uint32_t j = threadIdx.x; j < P; j += PS_T) lc[j] = 0;
     __syncthreads();
-    uint64_t lo, hi;
-    slab_range(nf, PS_SLABS, blockIdx.x, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += PS_T) {
-        const int32_t d = dig[i];
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;
+    const uint32_t len = (uint32_t)(hi - lo);
+    for (uint32_t q = threadIdx.x; q < W * len; q += PS_T) {
+        const uint32_t w = q / len, ii = q - w * len;
+        const int32_t d = dig[(uint64_t)w * n + lo + ii];
         if (d != 0) atomicAdd(&lc[(uint32_t)((d < 0 ? -d : d) - 1) >> PS_LOB], 1u);
     }
     __syncthreads();
@@ -373,17 +429,19 @@ ZK_D uint32_t scan256_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
 // A tile of PS_STILE digits is ordered by partition in LDS first (packed: position in the tile, sign, low bits,
 // partition), so the 8-byte records leave as runs of consecutive addresses, one run per partition and tile.
 constexpr uint32_t PS_STILE = 16384;   // 16 digits per lane
-__global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t nf, uint32_t P, const uint32_t* cursors,
-                                                      const uint32_t* part_start, uint32_t* stage_ref, uint8_t* stage_lo, uint32_t n_real) {
+__global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t P, const uint32_t* cursors,
+                                                      const uint32_t* part_start, uint32_t* stage_ref, uint8_t* stage_lo) {
     constexpr uint32_t PER = PS_STILE / PS_T, LOM = (1u << PS_LOB) - 1u;
     __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
     __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | low bits << 15 | partition << 22
     const uint32_t t = threadIdx.x;
     if (t < 256) gcur[t] = t < P ? part_start[t] + cursors[(uint64_t)t * PS_SLABS + blockIdx.x] : 0u;
-    uint64_t lo, hi;
-    slab_range(nf, PS_SLABS, blockIdx.x, lo, hi);
-    for (uint64_t base = lo; base < hi; base += PS_STILE) {
-        const uint32_t m = hi - base < PS_STILE ? (uint32_t)(hi - base) : PS_STILE;
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;
+    const uint32_t len = (uint32_t)(hi - lo);
+    const uint32_t total_digits = W * len;           // the slab: W windows x len scalars, visited window-major
+    for (uint32_t base = 0; base < total_digits; base += PS_STILE) {
+        const uint32_t m = total_digits - base < PS_STILE ? total_digits - base : PS_STILE;
         __syncthreads();
         if (t < 256) cnt[t] = 0;
         __syncthreads();
@@ -393,7 +451,8 @@ __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64
             const uint32_t i = k * PS_T + t;
             pk[k] = 0xffffffffu;
             if (i < m) {
-                const int32_t d = dig[base + i];
+                const uint32_t q = base + i, w = q / len, ii = q - w * len;
+                const int32_t d = dig[(uint64_t)w * n + lo + ii];
                 if (d != 0) {
                     const uint32_t neg = d < 0 ? 1u : 0u;
                     const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
@@ -419,14 +478,13 @@ __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64
         const uint32_t total = toff[256];
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t q = k * PS_T + t;   // consecutive lanes -> consecutive records of a partition's run
-            if (q < total) {
-                const uint32_t r = rec[q];
+            const uint32_t qq = k * PS_T + t;   // consecutive lanes -> consecutive records of a partition's run
+            if (qq < total) {
+                const uint32_t r = rec[qq];
                 const uint32_t pp = r >> 22;
-                const uint64_t gi = base + (r & 0x3fffu);
-                const uint32_t wq = (uint32_t)(gi / n_real);
-                const uint32_t ref = (wq << 26) | (uint32_t)(gi - (uint64_t)wq * n_real) | (((r >> 14) & 1u) << 31);
-                const uint32_t dst = gcur[pp] + (q - toff[pp]);
+                const uint32_t q = base + (r & 0x3fffu), w = q / len, ii = q - w * len;
+                const uint32_t ref = (w << 26) | (uint32_t)(lo + ii) | (((r >> 14) & 1u) << 31);
+                const uint32_t dst = gcur[pp] + (qq - toff[pp]);
                 stage_ref[dst] = ref;
                 stage_lo[dst] = (uint8_t)((r >> 15) & LOM);
             }
@@ -1347,35 +1405,49 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
     typedef typename Cv::Fr FrS;
-    if ((n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16) {
-        unsigned b2 = (unsigned)((n / 2 + T - 1) / T);
-        if (mont) hipLaunchKernelGGL((msm_digits2<FrS, true>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
-        else hipLaunchKernelGGL((msm_digits2<FrS, false>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
-    } else {
-        const void* canon = d_scalars;
-        if (mont) {   // odd length: separate into_repr pass, then the one-scalar-per-lane kernel
-            int rc = mb.scalars.ensure(n * 32);
-            if (rc) return rc;
-            if ((rc = fr_convert_stream(c, Cv::ID, d_scalars, n, mb.scalars.p, st))) return rc;
-            canon = mb.scalars.p;
-        }
-        hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)canon, (uint64_t)n, pl.g, dig);
-    }
-    if (pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256) {
-        const uint32_t P = pl.g1.nb >> PS_LOB;
+    const bool psort = pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256;   // two-pass partition sort
+    const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16;                     // two scalars per lane
+    const uint32_t P = pl.g1.nb >> PS_LOB;
+    const uint32_t sp = psort_slab_len(n);
+    uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 partition starts | P totals | scan counter
+    uint32_t* part_total = part_start + P + 1;
+    uint32_t* scan_counter = part_total + P;
+    uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
+    if (psort) {
         int rc = mb.stage.ensure((size_t)pl.nf * 5);
         if (rc) return rc;
-        if ((rc = mb.counts.ensure((size_t)P * PS_SLABS * 4))) return rc;
+        if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
         hist = (uint32_t*)mb.counts.p;
-        uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 values (the buffer holds nb + 2)
-        uint32_t* part_total = part_start + P + 1;
-        uint32_t* scan_counter = part_total + P;
-        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, pl.nf, P, hist, scan_counter,
-                           (uint32_t*)mb.part_key.p + PRE_Q_OFF);
+    }
+    if (pairs && psort && P == 256) {
+        // digits and the per-slab partition counts in one kernel
+        if (mont) hipLaunchKernelGGL((psort_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp,
+                                     dig, hist, scan_counter, combine_q);
+        else hipLaunchKernelGGL((psort_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp,
+                                dig, hist, scan_counter, combine_q);
+    } else {
+        if (pairs) {
+            unsigned b2 = (unsigned)((n / 2 + T - 1) / T);
+            if (mont) hipLaunchKernelGGL((msm_digits2<FrS, true>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+            else hipLaunchKernelGGL((msm_digits2<FrS, false>), dim3(b2), dim3(T), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, pl.g, dig);
+        } else {
+            const void* canon = d_scalars;
+            if (mont) {   // odd length: separate into_repr pass, then the one-scalar-per-lane kernel
+                int rc = mb.scalars.ensure(n * 32);
+                if (rc) return rc;
+                if ((rc = fr_convert_stream(c, Cv::ID, d_scalars, n, mb.scalars.p, st))) return rc;
+                canon = mb.scalars.p;
+            }
+            hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)canon, (uint64_t)n, pl.g, dig);
+        }
+        if (psort)
+            hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, (uint64_t)n, pl.g.W, sp, P, hist, scan_counter, combine_q);
+    }
+    if (psort) {
         hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
         uint32_t* stage_ref = (uint32_t*)mb.stage.p;                       // references | their low bucket bits (nf bytes)
         uint8_t* stage_lo = (uint8_t*)mb.stage.p + (size_t)pl.nf * 4;
-        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, pl.nf, P, hist, part_start, stage_ref, stage_lo, (uint32_t)n);
+        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, (uint64_t)n, pl.g.W, sp, P, hist, part_start, stage_ref, stage_lo);
         hipLaunchKernelGGL(psort_final, dim3(P), dim3(PS_T), 0, st, (const uint32_t*)stage_ref, (const uint8_t*)stage_lo, part_start, P, entries,
                            offsets);
         ZK_HIP_TRY(hipGetLastError());

@@ -7,7 +7,7 @@
 // Pipeline (all on the ctx stream; no host round trip until the window sums are read back):
 //   1. msm_digits(2)  signed c-bit digits of every scalar (window-major int16; into_repr fused for commits)
 //   2. sort           the (point, sign) references by bucket, no global atomics:
-//                       window-table path: psort_hist / psort_scan / psort_scatter / psort_final -- two-pass
+//                       window-table path: psort_digits_hist / psort_scan / psort_scatter / psort_final -- two-pass
 //                       partition sort over the one shared bucket set;
 //                       per-window path:   msm_hist / msm_scan1/2/3 / msm_scatter -- LDS counting sort
 //   3. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
@@ -283,7 +283,7 @@ __global__ void msm_scatter(const int16_t* dig, uint64_t n, MsmGeom g, uint32_t 
 // writes 16-byte runs at random places (measured: 513 MB leaving L2 per launch for 67 MB of output).
 // Here the references first go to P = nb/128 partitions by the high bucket bits -- every (slab, partition)
 // run is ~1 KiB contiguous -- and one workgroup per partition then orders its ~nf/P references by the low
-// 7 bits out of L2.  psort_hist / psort_scan / psort_scatter / psort_final; order
+// 7 bits out of L2.  psort_digits_hist (or psort_hist) / psort_scan / psort_scatter / psort_final; order
 // inside a bucket is arbitrary (the sums are commutative).  Measured at 2^20: 0.23 ms against 0.33 ms for
 // msm_hist + msm_scan1/2/3 + msm_scatter; what is left is the ~64 distinct cache lines every wave-store of
 // the two placement kernels touches.

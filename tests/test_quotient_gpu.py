@@ -158,3 +158,28 @@ def test_permutation_argument_end_to_end(ctx):
     chal2["gamma"] = zk.curves.fr_to_mont(cid, [chv["gamma"] + 1])[0]
     t_bad = quotient.compute(dom, dom4, polys, key, sig, chal2).cpu().numpy().view(np.uint64)
     assert all(t_bad[k].any() for k in range(4 * n - 4, 4 * n))
+
+
+def test_bad_arguments_are_error_codes(ctx):
+    """Null columns, mismatched lengths and oversized domains come back as codes / ValueError, never as a fault."""
+    import ctypes
+    import torch
+    from ark_plonk_amd import _lib, permutation
+    L = _lib.lib()
+    args = quotient.QuotientArgs()                       # every pointer null
+    out = torch.empty((16, 4), dtype=torch.int64, device="cuda")
+    assert L.zk_quotient_evals_dev(ctx.handle, 0, 2, ctypes.byref(args), out.data_ptr()) == _lib.ZK_ERR_BAD_ARG
+    assert L.zk_quotient_evals_dev(ctx.handle, 0, 31, ctypes.byref(args), out.data_ptr()) == _lib.ZK_ERR_DOMAIN_TOO_LARGE
+    assert L.zk_quotient_evals_dev(ctx.handle, 7, 2, ctypes.byref(args), out.data_ptr()) == _lib.ZK_ERR_BAD_ARG
+    assert L.zk_quotient_evals_dev(None, 0, 2, ctypes.byref(args), out.data_ptr()) == _lib.ZK_ERR_BAD_ARG
+    dom = zk.Radix2EvaluationDomain.new(8, 0, ctx)
+    cols = [torch.zeros((8, 4), dtype=torch.int64, device="cuda") for _ in range(8)]
+    one = zk.curves.fr_to_mont(0, [1])[0]
+    with pytest.raises(ValueError):
+        permutation.permutation_evals(dom, cols[:4], cols[4:7] + [cols[7][:4]], one, one)       # a short sigma column
+    with pytest.raises(ValueError):
+        permutation.lookup_permutation_evals(ctx, 0, cols[0], cols[1][:3], cols[2], cols[3], one, one)
+    nullp = (ctypes.c_void_p * 4)()
+    assert L.zk_perm_product_dev(ctx.handle, 0, 3, nullp, nullp, one.ctypes.data, one.ctypes.data, out.data_ptr(), None) == _lib.ZK_ERR_BAD_ARG
+    assert L.zk_lookup_product_dev(ctx.handle, 0, 0, out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), one.ctypes.data,
+                                   one.ctypes.data, out.data_ptr(), None) == _lib.ZK_ERR_BAD_ARG

@@ -39,6 +39,8 @@ while time.time() < t_end:
     for _ in range(k):
         ln = min(n, int(rng.choice([n, n - 1, n - 2, 8192, 8193, 8191, int(rng.integers(1, n + 1))])))
         p = rng.integers(0, 1 << 62, size=(ln, 4), dtype=np.uint64)
+        if cid == 1:
+            p[:, 3] >>= np.uint64(2)      # BN254: r ~ 2^253.6, keep the Montgomery residues canonical (< 2^252)
         mode = rng.random()
         if mode < 0.2:      # heavy skew: most coefficients equal
             p[rng.random(ln) < 0.9] = p[0]

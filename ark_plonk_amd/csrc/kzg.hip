@@ -11,110 +11,146 @@
 // (into_repr) form for the opening MSM.
 #include "ctx.h"
 
+// Arithmetic: the 29-bit-limb Montgomery type of fieldu.cuh (as in the NTT).  Data stay in the arkworks
+// Montgomery domain (R = 2^256): every constant multiplier (chi^k, z, z^CHUNK and the running powers of the
+// scan) is held in the R' = 2^261 form, so data * multiplier / R' keeps the factor R; chunk sums and chunk
+// carries are kept as lazily reduced limb vectors (48 B) between the phases.
+
 namespace {
 
-template <class Fr>
-ZK_D Fr ld_fr(const void* base, uint64_t idx) {
+struct Packed {            // a field element as 8 little-endian words (kernel argument form)
+    uint32_t w[8];
+};
+
+template <class FU>
+ZK_D FU ld_u(const void* base, uint64_t idx) {       // 32-byte element -> limbs (no domain change)
     const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
     uint4 a = q[0], b = q[1];
-    Fr r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return FU::split_words(w);
+}
+template <class FU>
+ZK_D void st_u(void* base, uint64_t idx, const FU& x) {   // value < 2r -> canonical 32-byte element
+    uint32_t w[8];
+    FU::canonical_lt2p(x).pack_words(w);
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// lazily reduced limb vectors: 9 limbs in 12 words
+template <class FU>
+ZK_D FU ld_l(const void* base, uint64_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 3 * idx;
+    uint4 a = q[0], b = q[1], c = q[2];
+    const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    FU r;
+#pragma unroll
+    for (int i = 0; i < FU::NL; ++i) r.v[i] = w[i];
     return r;
 }
-template <class Fr>
-ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
-    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+template <class FU>
+ZK_D void st_l(void* base, uint64_t idx, const FU& x) {
+    uint32_t w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < FU::NL; ++i) w[i] = x.v[i];
+    uint4* q = reinterpret_cast<uint4*>(base) + 3 * idx;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    q[2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
+template <class FU>
+ZK_D FU unpack(const Packed& p) { return FU::split_words(p.w); }
 
 constexpr int MAX_POLYS = 16;
-template <class Fr>
 struct RlcArgs {
     const void* poly[MAX_POLYS];
     uint64_t len[MAX_POLYS];
-    Fr chi_pow[MAX_POLYS];   // chi^k, Montgomery
+    Packed chi_pow[MAX_POLYS];   // chi^k in the R' form
     uint32_t n_polys;
 };
 
 // comb[i] = sum_k chi^k * p_k[i]
-template <class Fr>
-__global__ void kzg_rlc(RlcArgs<Fr> a, uint64_t m, void* comb) {
+template <class FU>
+__global__ void kzg_rlc(RlcArgs a, uint64_t m, void* comb) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    Fr acc = Fr::zero();
+    FU acc = FU::zero();                     // <= 16 terms < 2r each
     for (uint32_t k = 0; k < a.n_polys; ++k) {
-        if (i < a.len[k]) acc = Fr::add(acc, Fr::mul(ld_fr<Fr>(a.poly[k], i), a.chi_pow[k]));
+        if (i < a.len[k]) acc = FU::add(acc, FU::mul(ld_u<FU>(a.poly[k], i), unpack<FU>(a.chi_pow[k])));
     }
-    st_fr<Fr>(comb, i, acc);
+    st_u<FU>(comb, i, FU::mul(acc, FU::one()));   // * 1 (R' form): back under 2r
 }
 
 constexpr uint32_t CHUNK = 64;       // coefficients per lane in phases 1 and 3
 constexpr uint32_t SCAN_T = 1024;    // lanes of the single scan workgroup
 
-// phase 1: H[t] = sum_{j < CHUNK} c[t*CHUNK + j] z^j
-template <class Fr>
-__global__ void kzg_chunk_horner(const void* comb, uint64_t m, Fr z, void* H, uint64_t n_chunks) {
+// phase 1: H[t] = sum_{j < CHUNK} c[t*CHUNK + j] z^j          (lazy, < 3r)
+template <class FU>
+__global__ void kzg_chunk_horner(const void* comb, uint64_t m, Packed zp, void* H, uint64_t n_chunks) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks) return;
+    const FU z = unpack<FU>(zp);
     const uint64_t lo = t * CHUNK;
     const uint64_t hi = lo + CHUNK < m ? lo + CHUNK : m;
-    Fr acc = Fr::zero();
-    for (uint64_t j = hi; j-- > lo;) acc = Fr::add(ld_fr<Fr>(comb, j), Fr::mul(acc, z));
-    st_fr<Fr>(H, t, acc);
+    FU acc = FU::zero();
+    for (uint64_t j = hi; j-- > lo;) acc = FU::add(ld_u<FU>(comb, j), FU::mul(acc, z));
+    st_l<FU>(H, t, acc);
 }
 
 // phase 2 (one workgroup): A[t] = sum_{t' > t} H[t'] (z^CHUNK)^(t'-t-1), the value flowing into chunk t
-template <class Fr>
-__global__ void __launch_bounds__(SCAN_T) kzg_chunk_scan(const void* H, uint64_t n_chunks, Fr zk /* z^CHUNK */, void* A) {
-    extern __shared__ uint4 sh[];          // (h, q) per lane: 2 x Fr
+template <class FU>
+__global__ void __launch_bounds__(SCAN_T) kzg_chunk_scan(const void* H, uint64_t n_chunks, Packed zkp /* z^CHUNK, R' form */, void* A) {
+    extern __shared__ uint4 sh[];          // (h, q) per lane: 2 x 48 B
     const uint32_t u = threadIdx.x;
+    const FU zk = unpack<FU>(zkp);
     const uint64_t per = (n_chunks + SCAN_T - 1) / SCAN_T;
-    const uint64_t lo = (uint64_t)u * per;
+    const uint64_t lo = (uint64_t)u * per < n_chunks ? (uint64_t)u * per : n_chunks;
     const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
-    // local: h = sum_{t in [lo,hi)} H[t] zk^(t-lo),  q = zk^(hi-lo)
-    Fr h = Fr::zero(), q = Fr::one();
+    // local: h = sum_{t in [lo,hi)} H[t] zk^(t-lo) (data, < 5r),  q = zk^(hi-lo) (multiplier, R' form, < 2r)
+    FU h = FU::zero(), q = FU::one();
     for (uint64_t t = hi; t-- > lo;) {
-        h = Fr::add(ld_fr<Fr>(H, t), Fr::mul(h, zk));
-        q = Fr::mul(q, zk);
+        h = FU::add(ld_l<FU>(H, t), FU::mul(h, zk));
+        q = FU::mul(q, zk);
     }
-    // exclusive suffix scan of (h, q) with (h1,q1) o (h2,q2) = (h1 + q1 h2, q1 q2): Hillis-Steele
-    Fr sh_h = h, sh_q = q;
+    // exclusive suffix scan of (h, q) with (h1,q1) o (h2,q2) = (h1 + q1 h2, q1 q2): Hillis-Steele.
+    // h grows by < 2r per step (< 25r after 10 steps); q1 * h2 < 2r * 25r stays inside the product's range.
     for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
-        st_fr<Fr>(sh, 2 * u, sh_h);
-        st_fr<Fr>(sh, 2 * u + 1, sh_q);
+        st_l<FU>(sh, 2 * u, h);
+        st_l<FU>(sh, 2 * u + 1, q);
         __syncthreads();
         if (u + d < SCAN_T) {
-            Fr oh = ld_fr<Fr>(sh, 2 * (u + d)), oq = ld_fr<Fr>(sh, 2 * (u + d) + 1);
-            sh_h = Fr::add(sh_h, Fr::mul(sh_q, oh));
-            sh_q = Fr::mul(sh_q, oq);
+            const FU oh = ld_l<FU>(sh, 2 * (u + d)), oq = ld_l<FU>(sh, 2 * (u + d) + 1);
+            h = FU::add(h, FU::mul(q, oh));
+            q = FU::mul(q, oq);
         }
         __syncthreads();
     }
-    // sh_h = inclusive suffix value starting at this lane's first chunk; the value entering the lane
+    // h = inclusive suffix value starting at this lane's first chunk; the value entering the lane
     // from above is the inclusive value of lane u+1
-    st_fr<Fr>(sh, 2 * u, sh_h);
+    st_l<FU>(sh, 2 * u, h);
     __syncthreads();
-    Fr carry = (u + 1 < SCAN_T) ? ld_fr<Fr>(sh, 2 * (u + 1)) : Fr::zero();
+    FU carry = (u + 1 < SCAN_T) ? ld_l<FU>(sh, 2 * (u + 1)) : FU::zero();
     // replay the lane's chunks from the top to hand every chunk its incoming value
     for (uint64_t t = hi; t-- > lo;) {
-        st_fr<Fr>(A, t, carry);
-        carry = Fr::add(ld_fr<Fr>(H, t), Fr::mul(carry, zk));
+        st_l<FU>(A, t, carry);
+        carry = FU::add(ld_l<FU>(H, t), FU::mul(carry, zk));
     }
 }
 
-// phase 3: replay each chunk with its incoming value; w[i-1] = c[i] + z*w[i], written canonical
-template <class Fr>
-__global__ void kzg_witness(const void* comb, uint64_t m, Fr z, const void* A, void* w_out, uint64_t n_chunks) {
+// phase 3: replay each chunk with its incoming value; w[i-1] = c[i] + z*w[i], written canonical (into_repr)
+template <class FU>
+__global__ void kzg_witness(const void* comb, uint64_t m, Packed zp, const void* A, void* w_out, uint64_t n_chunks) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks) return;
+    const FU z = unpack<FU>(zp);
+    FU unR = FU::zero();      // the plain integer R'/R = 2^5: (x R) * 2^5 / R' = x
+    unR.v[0] = 32u;
     const uint64_t lo = t * CHUNK;
     const uint64_t hi = lo + CHUNK < m ? lo + CHUNK : m;
-    Fr run = ld_fr<Fr>(A, t);
+    FU run = ld_l<FU>(A, t);
     for (uint64_t j = hi; j-- > lo;) {
-        run = Fr::add(ld_fr<Fr>(comb, j), Fr::mul(run, z));   // = w[j-1]
-        if (j >= 1) st_fr<Fr>(w_out, j - 1, Fr::from_mont(run));
+        run = FU::add(ld_u<FU>(comb, j), FU::mul(run, z));   // = w[j-1] (Montgomery, lazy)
+        if (j >= 1) st_u<FU>(w_out, j - 1, FU::mul(run, unR));
     }
 }
 
@@ -122,6 +158,7 @@ template <class C>
 int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
                  const uint64_t* chal_mont, void** d_w, size_t* wlen) {
     typedef typename C::Fr Fr;
+    typedef typename C::FrU FU;
     if (n_polys > (uint32_t)MAX_POLYS) return ZK_ERR_UNSUPPORTED;
     uint64_t m = 0;
     for (uint32_t k = 0; k < n_polys; ++k) m = lens[k] > m ? lens[k] : m;
@@ -131,34 +168,43 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     Fr z, chi;
     memcpy(z.v, z_mont, 32);
     memcpy(chi.v, chal_mont, 32);
-    RlcArgs<Fr> a;
+    // R' mod r as a plain integer: x R -> x R' by one product in the arkworks domain (as ntt.hip's tables)
+    Fr to_rp;
+    FU::one().pack_words(to_rp.v);
+    auto pack = [&](const Fr& v_mont) {
+        Packed p;
+        const Fr rp = Fr::mul(v_mont, to_rp);
+        memcpy(p.w, rp.v, 32);
+        return p;
+    };
+    RlcArgs a;
     memset(&a, 0, sizeof a);
     a.n_polys = n_polys;
     Fr pw = Fr::one();
     for (uint32_t k = 0; k < n_polys; ++k) {
         a.poly[k] = d_polys[k];
         a.len[k] = lens[k];
-        a.chi_pow[k] = pw;
+        a.chi_pow[k] = pack(pw);
         pw = Fr::mul(pw, chi);
     }
     const uint64_t n_chunks = (m + CHUNK - 1) / CHUNK;
     int rc;
     if ((rc = c->io_a.ensure(m * 32))) return rc;                       // comb
-    if ((rc = c->io_b.ensure(n_chunks * 32 * 2))) return rc;            // H | A
+    if ((rc = c->io_b.ensure(n_chunks * 48 * 2))) return rc;            // H | A  (limb vectors)
     if ((rc = c->mb[0].scalars.ensure(m * 32))) return rc;                // witness, canonical
     void* comb = c->io_a.p;
     void* H = c->io_b.p;
-    void* A = (char*)c->io_b.p + n_chunks * 32;
-    Fr zk = Fr::pow_u64(z, CHUNK);
+    void* A = (char*)c->io_b.p + n_chunks * 48;
+    const Packed zp = pack(z), zkp = pack(Fr::pow_u64(z, CHUNK));
     hipStream_t st = c->stream;
     ProfScope ps(c, "kzg_open_prep");
     const int T = 256;
-    hipLaunchKernelGGL(kzg_rlc<Fr>, dim3((unsigned)((m + T - 1) / T)), dim3(T), 0, st, a, m, comb);
-    hipLaunchKernelGGL(kzg_chunk_horner<Fr>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, z, H, n_chunks);
-    size_t shmem = (size_t)SCAN_T * 2 * 32;
-    ZK_HIP_TRY(hipFuncSetAttribute((const void*)kzg_chunk_scan<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kzg_chunk_scan<Fr>, dim3(1), dim3(SCAN_T), shmem, st, H, n_chunks, zk, A);
-    hipLaunchKernelGGL(kzg_witness<Fr>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, z, A, c->mb[0].scalars.p, n_chunks);
+    hipLaunchKernelGGL(kzg_rlc<FU>, dim3((unsigned)((m + T - 1) / T)), dim3(T), 0, st, a, m, comb);
+    hipLaunchKernelGGL(kzg_chunk_horner<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, H, n_chunks);
+    size_t shmem = (size_t)SCAN_T * 2 * 48;
+    ZK_HIP_TRY(hipFuncSetAttribute((const void*)kzg_chunk_scan<FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kzg_chunk_scan<FU>, dim3(1), dim3(SCAN_T), shmem, st, H, n_chunks, zkp, A);
+    hipLaunchKernelGGL(kzg_witness<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, A, c->mb[0].scalars.p, n_chunks);
     ZK_HIP_TRY(hipGetLastError());
     *d_w = c->mb[0].scalars.p;
     return ZK_OK;

@@ -7,17 +7,18 @@ produced from the mathematical definitions (naive/recursive DFT over Fr, affine 
 G1) and pin BOTH the C++ CPU restatement (oracle/ark_cpu.cpp) and the HIP path.  Values are stored
 exactly as they cross the C ABI: Montgomery limbs for Fr/Fq elements, canonical limbs for scalars.
 
-Run from the repo root:  python3 tools/gen_golden.py
+Run from the repo root:  python3 tests/golden/gen_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from oracle import bigint_oracle as bo  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.path.join(ROOT, "tests", "golden")
 
 
 def limbs(vals, n):

@@ -1,7 +1,7 @@
 """Randomised cross-check of the opening witness (RLC + synthetic division on the device, csrc/kzg.hip) against the
 CPU restatement: 1..16 polynomials of random ragged lengths (1 .. 2^17, around the 64-coefficient chunk and the
 1024-lane scan boundaries), both curves.  Compares the witness scalars (canonical) limb for limb.
-usage: python tools/stress_kzg.py [seconds]"""
+usage: python tests/stress/stress_kzg.py [seconds]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ark_plonk_amd as zk  # noqa: E402
 from oracle import cpu  # noqa: E402

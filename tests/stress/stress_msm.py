@@ -1,6 +1,6 @@
 """Randomised cross-check of the commit paths against the CPU restatement: random lengths (odd / even / threshold
 neighbours), random batch shapes, uniform and heavily skewed scalars, table and per-window paths.
-usage: python tools/stress_msm.py [seconds]"""
+usage: python tests/stress/stress_msm.py [seconds]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ark_plonk_amd as zk  # noqa: E402
 from ark_plonk_amd import _lib  # noqa: E402

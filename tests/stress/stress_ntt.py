@@ -1,6 +1,6 @@
 """Randomised cross-check of the transforms against the CPU restatement: random log N (1..20), kind, input length
 (empty, short, a quarter, full), both curves, host and device entry points, in place and out of place.
-usage: python tools/stress_ntt.py [seconds]"""
+usage: python tests/stress/stress_ntt.py [seconds]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ark_plonk_amd as zk  # noqa: E402
 from oracle import cpu  # noqa: E402

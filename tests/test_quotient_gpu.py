@@ -131,7 +131,7 @@ def test_permutation_argument_end_to_end(ctx):
     factors and z), so an exact quotient has degree <= 4n-5: its last four coefficients are zero, while the interpolant
     of a non-divisible numerator / Z_H has no reason to have any zero coefficient."""
     from ark_plonk_amd import permutation
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from gen_golden_gp import valid_permutation
     cid, cv, log_n = 0, bo.CURVES[0], 5
     n, p = 1 << log_n, cv.r

@@ -8,10 +8,11 @@ All compute runs in libark_plonk_amd.so (C ABI: include/ark_plonk_amd.h); there 
 from .context import Context, default_context  # noqa: F401
 from .curves import BLS12_381, BN254, get_curve  # noqa: F401
 from .domain import GeneralEvaluationDomain, Radix2EvaluationDomain  # noqa: F401
-from . import permutation, quotient  # noqa: F401
-from .msm import CommitterKey, G1Affine, VariableBaseMSM, kzg_witness, sum_partials, sum_partials_batch  # noqa: F401
+from . import permutation, quotient, transcript  # noqa: F401
+from .msm import (CommitterKey, G1Affine, VariableBaseMSM, kzg_witness, srs_cache_config, srs_cache_stats, sum_partials,  # noqa: F401
+                  sum_partials_batch)
 
 __all__ = [
     "Context", "default_context", "BLS12_381", "BN254", "get_curve", "GeneralEvaluationDomain",
-    "Radix2EvaluationDomain", "CommitterKey", "G1Affine", "VariableBaseMSM", "kzg_witness", "sum_partials", "sum_partials_batch", "permutation", "quotient",
+    "Radix2EvaluationDomain", "CommitterKey", "G1Affine", "VariableBaseMSM", "kzg_witness", "sum_partials", "sum_partials_batch", "srs_cache_stats", "srs_cache_config", "permutation", "quotient",
 ]

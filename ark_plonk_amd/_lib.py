@@ -41,6 +41,17 @@ class DomainInfo(ctypes.Structure):
     ]
 
 
+ZK_PROOF_N_EVALS = 16
+
+
+class ZkProof(ctypes.Structure):
+    """zk_proof (proof_system/proof.rs:41-103)."""
+    _fields_ = [
+        ("commitments", c_void_p), ("commitment_inf", c_void_p), ("openings", c_void_p), ("opening_inf", c_void_p),
+        ("evals", c_void_p), ("n_custom_evals", c_u32), ("custom_labels", ctypes.POINTER(ctypes.c_char_p)), ("custom_evals", c_void_p),
+    ]
+
+
 # every symbol include/ark_plonk_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "zk_strerror": (ctypes.c_char_p, [c_int]),
@@ -66,7 +77,16 @@ SYMBOLS = {
     "zk_fr_to_mont_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "zk_msm_g1": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_srs_register": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
-    "zk_srs_register_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_srs_register_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "zk_srs_cache_config": (c_int, [c_size_t]),
+    "zk_srs_cache_stats": (c_int, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "zk_io_stats": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_int]),
+    "zk_ctx_set_staging": (c_int, [c_void_p, c_int]),
+    "zk_ctx_set_commit_cache": (c_int, [c_void_p, c_int, c_u32]),
+    "zk_commit_cache_stats": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "zk_kzg_commit_batch": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_kzg_open": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
     "zk_srs_precompute": (c_int, [c_void_p, c_void_p]),
     "zk_srs_free": (None, [c_void_p]),
     "zk_srs_len": (c_size_t, [c_void_p]),
@@ -97,6 +117,28 @@ SYMBOLS = {
     "zk_dev_free": (c_int, [c_void_p, c_void_p]),
     "zk_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "zk_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    # N4: wire formats + transcript (host only)
+    "zk_fr_serialized_size": (c_size_t, [c_int]),
+    "zk_g1_compressed_size": (c_size_t, [c_int]),
+    "zk_fr_serialize": (c_int, [c_int, c_void_p, ctypes.c_char_p]),
+    "zk_fr_deserialize": (c_int, [c_int, ctypes.c_char_p, c_void_p]),
+    "zk_g1_serialize_compressed": (c_int, [c_int, c_void_p, ctypes.c_uint8, ctypes.c_char_p]),
+    "zk_g1_deserialize_compressed": (c_int, [c_int, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_uint8)]),
+    "zk_g1_serialize_uncompressed": (c_int, [c_int, c_void_p, ctypes.c_uint8, ctypes.c_char_p]),
+    "zk_g1_deserialize_uncompressed": (c_int, [c_int, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_uint8)]),
+    "zk_transcript_new": (c_void_p, [ctypes.c_char_p, c_size_t]),
+    "zk_transcript_clone": (c_void_p, [c_void_p]),
+    "zk_transcript_free": (None, [c_void_p]),
+    "zk_transcript_append_message": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, ctypes.c_char_p, c_size_t]),
+    "zk_transcript_append_u64": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, c_u64]),
+    "zk_transcript_challenge_bytes": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, ctypes.c_char_p, c_size_t]),
+    "zk_transcript_append_fr": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_size_t, c_void_p]),
+    "zk_transcript_append_g1": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_size_t, c_void_p, ctypes.c_uint8]),
+    "zk_transcript_challenge_scalar": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_size_t, c_void_p]),
+    "zk_transcript_circuit_domain_sep": (c_int, [c_void_p, c_u64]),
+    "zk_transcript_append_public_inputs": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_size_t, c_void_p, c_void_p, c_size_t]),
+    "zk_proof_serialized_size": (c_size_t, [c_int, c_u32, ctypes.POINTER(c_u32)]),
+    "zk_proof_serialize": (c_int, [c_int, ctypes.POINTER(ZkProof), ctypes.c_char_p, c_size_t, ctypes.POINTER(c_size_t)]),
 }
 
 _lib = None

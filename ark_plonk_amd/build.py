@@ -29,6 +29,8 @@ def jobs():
     """(object name, source, extra defines, header deps)"""
     out = [
         ("api.o", "api.hip", [], HOST_HDRS),
+        ("hostio.o", "hostio.hip", [], HOST_HDRS),
+        ("wire.o", "wire.hip", [], HOST_HDRS),
         ("kzg.o", "kzg.hip", [], HOST_HDRS),
         ("grand_product.o", "grand_product.hip", [], HOST_HDRS),
         ("quotient.o", "quotient.hip", [], HOST_HDRS),

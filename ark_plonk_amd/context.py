@@ -24,6 +24,8 @@ class Context:
         self._h = ctypes.c_void_p()
         check(lib().zk_ctx_create(int(device), ctypes.byref(self._h)), "zk_ctx_create")
         self.device = int(device)
+        self._stream_ptr = None
+        self._stream_thread = None
         if stream is not None:
             self.set_stream(stream)
 
@@ -52,12 +54,20 @@ class Context:
         if stream is None:
             check(lib().zk_ctx_use_own_stream(self.handle), "zk_ctx_use_own_stream")
             self._stream_ptr = None
+            self._stream_thread = None
             return
         ptr = int(getattr(stream, "cuda_stream", stream))
-        if getattr(self, "_stream_ptr", None) == ptr:
+        if self._stream_ptr == ptr:
             return
+        # the stream is ctx state set by a separate call: two threads alternating streams on one Context would race
+        # between set_stream and the launch (include/ark_plonk_amd.h: one ctx per thread and stream)
+        me = threading.get_ident()
+        if self._stream_thread not in (None, me) and self._stream_ptr is not None:
+            raise RuntimeError("Context is bound to another thread's stream: use one Context per thread and stream "
+                               "(contexts are cheap and share CommitterKey handles via CommitterKey.with_ctx)")
         check(lib().zk_ctx_set_stream(self.handle, ctypes.c_void_p(ptr)), "zk_ctx_set_stream")
         self._stream_ptr = ptr
+        self._stream_thread = me
 
     def use_torch_stream(self):
         import torch
@@ -68,6 +78,24 @@ class Context:
 
     def set_msm_window(self, c: int):
         check(lib().zk_ctx_set_msm_window(self.handle, int(c)), "zk_ctx_set_msm_window")
+
+    # -- N3: content-addressed commitment cache (prover.rs:569-607 re-commits 12 polynomials)
+    def set_commit_cache(self, on: bool = True, capacity: int = 0):
+        check(lib().zk_ctx_set_commit_cache(self.handle, 1 if on else 0, int(capacity)), "zk_ctx_set_commit_cache")
+
+    def commit_cache_stats(self) -> dict:
+        v = [ctypes.c_uint64() for _ in range(3)]
+        check(lib().zk_commit_cache_stats(self.handle, *[ctypes.byref(x) for x in v]), "zk_commit_cache_stats")
+        return {"hits": v[0].value, "misses": v[1].value, "entries": v[2].value}
+
+    # -- host-pointer entry points: PCIe volume and staging mode
+    def io_stats(self, reset: bool = False) -> dict:
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().zk_io_stats(self.handle, ctypes.byref(a), ctypes.byref(b), 1 if reset else 0), "zk_io_stats")
+        return {"h2d_bytes": a.value, "d2h_bytes": b.value}
+
+    def set_staging(self, pinned_ring: bool = True):
+        check(lib().zk_ctx_set_staging(self.handle, 1 if pinned_ring else 0), "zk_ctx_set_staging")
 
     # -- profiling
     def profile(self, on: bool = True):

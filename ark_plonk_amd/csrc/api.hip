@@ -111,6 +111,12 @@ static int domain_new(uint64_t num_coeffs, zk_domain_info* out) {
     return ZK_OK;
 }
 
+int ensure_pinned_small(zk_ctx* c) {
+    if (c->pinned_small) return ZK_OK;
+    if (hipHostMalloc(&c->pinned_small, 4096, hipHostMallocDefault) != hipSuccess) return ZK_ERR_OOM;
+    return ZK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -174,6 +180,8 @@ void zk_ctx_destroy(zk_ctx* c) {
         for (int i = 0; i < 16; ++i)
             if (c->ev_job[i]) (void)hipEventDestroy(c->ev_job[i]);
         if (c->pinned) (void)hipHostFree(c->pinned);
+        if (c->pinned_small) (void)hipHostFree(c->pinned_small);
+        zk_io_release(c);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     delete c;
@@ -203,7 +211,7 @@ int zk_ctx_sync(zk_ctx* c) {
 }
 
 int zk_ctx_set_msm_window(zk_ctx* c, int w) {
-    if (!c || w < 0 || w > 20 || w == 1) return ZK_ERR_BAD_ARG;
+    if (!c || w < 0 || w > 16 || w == 1) return ZK_ERR_BAD_ARG;
     Guard g(c);
     c->msm_window = w;
     return ZK_OK;
@@ -261,6 +269,8 @@ int zk_ntt_batch_dev(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t
                      const size_t* in_lens, void* const* d_outs) {
     if (!c || (n_polys && (!d_ins || !in_lens || !d_outs))) return ZK_ERR_BAD_ARG;
     if (log_n > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
+    for (uint32_t i = 0; i < n_polys; ++i)
+        if (!d_outs[i] || (!d_ins[i] && in_lens[i])) return ZK_ERR_BAD_ARG;
     Guard g(c);
     for (uint32_t i = 0; i < n_polys; ++i) {
         int rc = ntt_run_dev(c, curve_id, kind, log_n, d_ins[i], in_lens[i], d_outs[i]);
@@ -286,10 +296,10 @@ int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in
     int rc;
     if ((rc = c->io_a.ensure((in_len ? in_len : 1) * 32))) return rc;
     if ((rc = c->io_b.ensure(n * 32))) return rc;
-    if (in_len) ZK_HIP_TRY(hipMemcpyAsync(c->io_a.p, in, in_len * 32, hipMemcpyHostToDevice, c->stream));
+    if (in_len && (rc = zk_h2d(c, c->io_a.p, in, in_len * 32, c->stream))) return rc;
     rc = ntt_run_dev(c, curve_id, kind, log_n, c->io_a.p, in_len, c->io_b.p);
     if (rc) return rc;
-    ZK_HIP_TRY(hipMemcpyAsync(out, c->io_b.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = zk_d2h(c, out, c->io_b.p, n * 32, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
@@ -322,10 +332,48 @@ int zk_fr_mul_dev(zk_ctx* c, int curve_id, const void* d_a, const void* d_b, siz
 }
 
 // ------------------------------------------------------------------------------------------ MSM
-// shared tail of the two registration entry points: d_sat = arkworks-layout points on the device
+// ---- SRS registry: device-scoped, refcounted, content-addressed (PC::trim runs on every gen_proof,
+// circuit.rs:276, so a second registration of the same powers_of_g must cost a lookup, not a 96 MiB upload + table build)
+static std::mutex g_srs_mu;
+static std::list<zk_srs*> g_srs_cache;            // cached entries, most recently used first
+static std::atomic<uint64_t> g_srs_next_id{1};
+static size_t g_srs_idle_limit = (size_t)32 << 30;   // bytes of UNREFERENCED cached SRS (incl. window tables) kept resident
+static uint64_t g_srs_hits = 0, g_srs_misses = 0;
+
+static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_W ? s->pre_W : 1); }
+
+static void srs_destroy(zk_srs* s) {
+    if (s->d_xy) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (prev != s->device) (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();     // kernels of any ctx may still read the bases
+        (void)hipFree(s->d_xy);
+        if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+    }
+    delete s;
+}
+
+// g_srs_mu held: drop least recently used unreferenced entries beyond the idle limit
+static void srs_evict_locked() {
+    size_t idle = 0;
+    for (zk_srs* s : g_srs_cache)
+        if (s->refs.load() == 0) idle += srs_bytes(s);
+    for (auto it = g_srs_cache.end(); idle > g_srs_idle_limit && it != g_srs_cache.begin();) {
+        --it;
+        zk_srs* s = *it;
+        if (s->refs.load() != 0) continue;
+        idle -= srs_bytes(s);
+        it = g_srs_cache.erase(it);
+        srs_destroy(s);
+    }
+}
+
+// shared tail of the registration entry points: d_sat = arkworks-layout points on the device
 static int srs_build(zk_ctx* c, int curve_id, const void* d_sat, const uint8_t* d_inf, size_t n, zk_srs** out) {
     zk_srs* s = new zk_srs();
-    s->ctx = c;
+    s->device = c->device;
+    s->id = g_srs_next_id.fetch_add(1);
     s->curve = curve_id;
     s->n = n;
     s->point_bytes = msm_point_bytes(curve_id);
@@ -346,53 +394,116 @@ static int srs_build(zk_ctx* c, int curve_id, const void* d_sat, const uint8_t* 
     return ZK_OK;
 }
 
-int zk_srs_register_dev(zk_ctx* c, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out) {
+int zk_srs_register_dev(zk_ctx* c, int curve_id, const void* d_bases_xy, const uint8_t* d_inf_flags, size_t n, zk_srs** out) {
     if (!c || !out || (n && !d_bases_xy)) return ZK_ERR_BAD_ARG;
     if (!fq_limbs64(curve_id)) return ZK_ERR_BAD_ARG;
     Guard g(c);
-    return srs_build(c, curve_id, d_bases_xy, nullptr, n, out);
+    return srs_build(c, curve_id, d_bases_xy, d_inf_flags, n, out);
 }
 
-int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out) {
-    if (!c || !out || (n && !bases_xy)) return ZK_ERR_BAD_ARG;
+// upload + convert; use_cache: look the content digest up first / publish the new handle
+static int srs_register_host(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out, bool use_cache) {
     int L = fq_limbs64(curve_id);
     if (!L) return ZK_ERR_BAD_ARG;
     Guard g(c);
     const size_t bytes = n * 2 * L * 8;
+    uint64_t dig[4] = {0, 0, 0, 0};
+    std::unique_lock<std::mutex> reg(g_srs_mu, std::defer_lock);
+    if (use_cache) {
+        host_digest256(bases_xy, bytes, 0x5125ull ^ ((uint64_t)curve_id << 32) ^ (uint64_t)n, dig);
+        if (inf_flags) {
+            uint64_t d2[4];
+            host_digest256(inf_flags, n, 0xF1A65ull, d2);
+            bool any = false;
+            for (size_t i = 0; i < n && !any; ++i) any = inf_flags[i] != 0;
+            if (any)   // an all-zero flag array is the same SRS as no flag array
+                for (int k = 0; k < 4; ++k) dig[k] ^= d2[k];
+        }
+        reg.lock();   // held across the build: two threads registering the same SRS build it once
+        for (auto it = g_srs_cache.begin(); it != g_srs_cache.end(); ++it) {
+            zk_srs* s = *it;
+            if (s->device == c->device && s->curve == curve_id && s->n == n && !memcmp(s->digest, dig, sizeof dig)) {
+                s->refs.fetch_add(1);
+                g_srs_cache.splice(g_srs_cache.begin(), g_srs_cache, it);
+                ++g_srs_hits;
+                *out = s;
+                return ZK_OK;
+            }
+        }
+        ++g_srs_misses;
+    }
     int rc = c->io_b.ensure(bytes ? bytes : 1);
     if (rc) return rc;
     const uint8_t* d_inf = nullptr;
     if (n) {
-        ZK_HIP_TRY(hipMemcpyAsync(c->io_b.p, bases_xy, bytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = zk_h2d(c, c->io_b.p, bases_xy, bytes, c->stream))) return rc;
         if (inf_flags) {
             rc = c->msm_tmp.ensure(n);
             if (rc) return rc;
-            ZK_HIP_TRY(hipMemcpyAsync(c->msm_tmp.p, inf_flags, n, hipMemcpyHostToDevice, c->stream));
+            if ((rc = zk_h2d(c, c->msm_tmp.p, inf_flags, n, c->stream))) return rc;
             d_inf = (const uint8_t*)c->msm_tmp.p;
         }
     }
-    return srs_build(c, curve_id, c->io_b.p, d_inf, n, out);
+    zk_srs* s = nullptr;
+    rc = srs_build(c, curve_id, c->io_b.p, d_inf, n, &s);
+    if (rc) return rc;
+    if (use_cache) {
+        s->cached = true;
+        memcpy(s->digest, dig, sizeof dig);
+        g_srs_cache.push_front(s);
+        srs_evict_locked();
+    }
+    *out = s;
+    return ZK_OK;
+}
+
+int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out) {
+    if (!c || !out || (n && !bases_xy)) return ZK_ERR_BAD_ARG;
+    return srs_register_host(c, curve_id, bases_xy, inf_flags, n, out, n != 0);
 }
 
 int zk_srs_precompute(zk_ctx* c, zk_srs* s) {
-    if (!c || !s || s->ctx != c) return ZK_ERR_BAD_ARG;
+    if (!c || !s || s->device != c->device) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    std::unique_lock<std::shared_mutex> wl(s->mu);   // no MSM of any ctx is reading or enqueueing on this SRS
     if (s->pre_W || s->n == 0) return ZK_OK;
+    ZK_HIP_TRY(hipDeviceSynchronize());               // ... and none it enqueued earlier is still running
     return msm_precompute_dev(c, s);
 }
 
 void zk_srs_free(zk_srs* s) {
     if (!s) return;
-    if (s->d_xy || s->d_pre) {
-        Guard g(s->ctx);
-        (void)hipStreamSynchronize(s->ctx->stream);
-        if (s->d_xy) (void)hipFree(s->d_xy);
-        if (s->d_pre) (void)hipFree(s->d_pre);
+    std::lock_guard<std::mutex> reg(g_srs_mu);
+    const int left = s->refs.fetch_sub(1) - 1;
+    if (left > 0) return;
+    if (!s->cached) {
+        srs_destroy(s);
+        return;
     }
-    delete s;
+    srs_evict_locked();    // stays resident for the next PC::trim unless the idle budget is exceeded
 }
 
 size_t zk_srs_len(const zk_srs* s) { return s ? s->n : 0; }
+
+int zk_srs_cache_config(size_t max_idle_bytes) {
+    std::lock_guard<std::mutex> reg(g_srs_mu);
+    g_srs_idle_limit = max_idle_bytes;
+    srs_evict_locked();
+    return ZK_OK;
+}
+
+int zk_srs_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* resident_bytes) {
+    std::lock_guard<std::mutex> reg(g_srs_mu);
+    if (hits) *hits = g_srs_hits;
+    if (misses) *misses = g_srs_misses;
+    if (entries) *entries = g_srs_cache.size();
+    if (resident_bytes) {
+        uint64_t b = 0;
+        for (zk_srs* s : g_srs_cache) b += srs_bytes(s);
+        *resident_bytes = b;
+    }
+    return ZK_OK;
+}
 
 static int srs_slice(zk_srs* s, size_t base_offset, size_t n, const void** d_bases) {
     if (!s) return ZK_ERR_BAD_ARG;
@@ -401,14 +512,22 @@ static int srs_slice(zk_srs* s, size_t base_offset, size_t n, const void** d_bas
     return ZK_OK;
 }
 
-int zk_msm_g1_srs_partial_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
-    if (!c || !s || s->ctx != c || !out_xyz || (n && !d_scalars)) return ZK_ERR_BAD_ARG;
+typedef std::shared_lock<std::shared_mutex> SrsRead;
+
+// ctx lock and SRS read lock held
+static int msm_partial_locked(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     const void* d_bases = nullptr;
     int rc = srs_slice(s, base_offset, n, &d_bases);
     if (rc) return rc;
-    Guard g(c);
     if (s->pre_W && n >= ZK_PRE_MIN_N && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
     return msm_run_dev(c, s->curve, d_bases, d_scalars, n, out_xyz);
+}
+
+int zk_msm_g1_srs_partial_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
+    if (!c || !s || s->device != c->device || !out_xyz || (n && !d_scalars)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    return msm_partial_locked(c, s, base_offset, d_scalars, n, out_xyz);
 }
 
 int zk_msm_g1_srs_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
@@ -420,12 +539,12 @@ int zk_msm_g1_srs_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_sc
 }
 
 int zk_msm_g1_srs(zk_ctx* c, zk_srs* s, size_t base_offset, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!c || !s || s->ctx != c || !out_xy || (n && !scalars)) return ZK_ERR_BAD_ARG;
+    if (!c || !s || s->device != c->device || !out_xy || (n && !scalars)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     {
         int rc = c->mb[0].scalars.ensure((n ? n : 1) * 32);
         if (rc) return rc;
-        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->mb[0].scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+        if (n && (rc = zk_h2d(c, c->mb[0].scalars.p, scalars, n * 32, c->stream))) return rc;
     }
     return zk_msm_g1_srs_dev(c, s, base_offset, c->mb[0].scalars.p, n, out_xy, out_inf);
 }
@@ -435,7 +554,7 @@ int zk_msm_g1(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uint8_t* 
     if (!c || !out_xy || (n && (!bases_xy || !scalars))) return ZK_ERR_BAD_ARG;
     Guard g(c);
     zk_srs* s = nullptr;
-    int rc = zk_srs_register(c, curve_id, bases_xy, inf_flags, n, &s);
+    int rc = srs_register_host(c, curve_id, bases_xy, inf_flags, n, &s, false);   // ad-hoc bases: never cached
     if (rc) return rc;
     rc = zk_msm_g1_srs(c, s, 0, scalars, n, out_xy, out_inf);
     zk_srs_free(s);
@@ -468,17 +587,153 @@ int zk_g1_sum_partials_batch(int curve_id, const uint64_t* partials_xyz, size_t 
 }
 
 // ------------------------------------------------------------------------------------ KZG commit
-int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!c || !s || s->ctx != c || !out_xy || (n && !d_coeffs_mont)) return ZK_ERR_BAD_ARG;
+typedef std::function<int(uint32_t)> BeforeJob;
+
+// one commitment, no table / no batch: into_repr (unless canonical) + the per-window or single-job table MSM
+static int commit_one_locked(zk_ctx* c, zk_srs* s, const void* d_in, size_t n, bool canonical, uint64_t* out_xyz) {
     if (n > s->n) return ZK_ERR_BAD_ARG;
-    Guard g(c);
-    {
+    const void* sc = d_in;
+    if (!canonical) {
         int rc = c->mb[0].scalars.ensure((n ? n : 1) * 32);
         if (rc) return rc;
-        rc = fr_convert_dev(c, s->curve, 0, d_coeffs_mont, n, c->mb[0].scalars.p);
-        if (rc) return rc;
+        if ((rc = fr_convert_dev(c, s->curve, 0, d_in, n, c->mb[0].scalars.p))) return rc;
+        sc = c->mb[0].scalars.p;
     }
-    return zk_msm_g1_srs_dev(c, s, 0, c->mb[0].scalars.p, n, out_xy, out_inf);
+    return msm_partial_locked(c, s, 0, sc, n, out_xyz);
+}
+
+// the jobs of one PC call, no cache: fused window-table batch when every job qualifies, else one at a time.
+// before_job(k) (optional) runs right before job k's kernels are queued (the host-pointer batch uploads job k there).
+// Exactly one of out_xyz (Jacobian partials, 3L per job) / out_xy (affine, 2L per job) is non-null.
+static int batch_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds,
+                        uint64_t* out_xyz, uint64_t* out_xy, uint8_t* out_inf, const BeforeJob* before_job) {
+    const int L = fq_limbs64(s->curve);
+    bool fused = s->pre_W != 0 && c->msm_window == 0;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
+        if (lens[k] < ZK_PRE_MIN_N) fused = false;
+    }
+    if (fused) {
+        uint64_t tmp[16 * 18];
+        return msm_batch_pre_dev(c, s, n_jobs, d_inputs, lens, out_xyz ? out_xyz : tmp, kinds, out_xy, out_inf, before_job);
+    }
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        int rc;
+        if (before_job && (rc = (*before_job)(k))) return rc;
+        uint64_t xyz[18];
+        if ((rc = commit_one_locked(c, s, d_inputs[k], lens[k], kinds && kinds[k], out_xyz ? out_xyz + (size_t)k * 3 * L : xyz))) return rc;
+        if (out_xy && (rc = finish_point(s->curve, xyz, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr))) return rc;
+    }
+    return ZK_OK;
+}
+
+// N3: the same with the ctx's content-addressed commitment cache in front (affine outputs only).
+// Inputs must already be on the device (the digest is computed there).
+static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds,
+                               uint64_t* out_xy, uint8_t* out_inf) {
+    const int L = fq_limbs64(s->curve);
+    if (!c->commit_cache_on || n_jobs == 0) return batch_locked(c, s, n_jobs, d_inputs, lens, kinds, nullptr, out_xy, out_inf, nullptr);
+    int rc;
+    if ((rc = c->digest_dev.ensure(16 * 32))) return rc;
+    if ((rc = ensure_pinned_small(c))) return rc;
+    if ((rc = dev_digest256(d_inputs, lens, n_jobs, (uint64_t*)c->digest_dev.p, c->stream))) return rc;
+    ZK_HIP_TRY(hipMemcpyAsync(c->pinned_small, c->digest_dev.p, (size_t)n_jobs * 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t* dig = (const uint64_t*)c->pinned_small;
+    const void* miss_in[16];
+    size_t miss_len[16];
+    uint8_t miss_kind[16];
+    uint32_t miss_job[16], n_miss = 0;
+    int alias[16];     // job k repeats miss alias[k] of this very call
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        const uint32_t kind = kinds && kinds[k] ? 1u : 0u;
+        alias[k] = -1;
+        bool hit = false;
+        for (auto it = c->commit_cache.begin(); it != c->commit_cache.end(); ++it) {
+            if (it->srs_id == s->id && it->n == lens[k] && it->kind == kind && !memcmp(it->dig, dig + 4 * k, 32)) {
+                memcpy(out_xy + (size_t)k * 2 * L, it->xy, sizeof(uint64_t) * 2 * L);
+                if (out_inf) out_inf[k] = it->inf;
+                c->commit_cache.splice(c->commit_cache.begin(), c->commit_cache, it);
+                hit = true;
+                break;
+            }
+        }
+        if (hit) {
+            ++c->cache_hits;
+            continue;
+        }
+        for (uint32_t m = 0; m < n_miss && alias[k] < 0; ++m) {
+            const uint32_t j = miss_job[m];
+            if (lens[j] == lens[k] && miss_kind[m] == kind && !memcmp(dig + 4 * j, dig + 4 * k, 32)) alias[k] = (int)m;
+        }
+        if (alias[k] >= 0) {
+            ++c->cache_hits;
+            continue;
+        }
+        ++c->cache_misses;
+        miss_in[n_miss] = d_inputs[k];
+        miss_len[n_miss] = lens[k];
+        miss_kind[n_miss] = (uint8_t)kind;
+        miss_job[n_miss] = k;
+        ++n_miss;
+    }
+    uint64_t m_xy[16 * 12];
+    uint8_t m_inf[16];
+    if (n_miss) {
+        if ((rc = batch_locked(c, s, n_miss, miss_in, miss_len, miss_kind, nullptr, m_xy, m_inf, nullptr))) return rc;
+        for (uint32_t m = 0; m < n_miss; ++m) {
+            const uint32_t k = miss_job[m];
+            memcpy(out_xy + (size_t)k * 2 * L, m_xy + (size_t)m * 2 * L, sizeof(uint64_t) * 2 * L);
+            if (out_inf) out_inf[k] = m_inf[m];
+            zk_ctx::CommitEntry e;
+            memset(&e, 0, sizeof e);
+            e.srs_id = s->id;
+            e.n = lens[k];
+            e.kind = miss_kind[m];
+            memcpy(e.dig, dig + 4 * k, 32);
+            memcpy(e.xy, m_xy + (size_t)m * 2 * L, sizeof(uint64_t) * 2 * L);
+            e.inf = m_inf[m];
+            c->commit_cache.push_front(e);
+        }
+        while (c->commit_cache.size() > c->commit_cache_cap) c->commit_cache.pop_back();
+    }
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        if (alias[k] >= 0) {
+            memcpy(out_xy + (size_t)k * 2 * L, m_xy + (size_t)alias[k] * 2 * L, sizeof(uint64_t) * 2 * L);
+            if (out_inf) out_inf[k] = m_inf[alias[k]];
+        }
+    return ZK_OK;
+}
+
+int zk_ctx_set_commit_cache(zk_ctx* c, int enable, uint32_t capacity) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    c->commit_cache_on = enable != 0;
+    if (capacity) c->commit_cache_cap = capacity;
+    if (!enable) c->commit_cache.clear();
+    while (c->commit_cache.size() > c->commit_cache_cap) c->commit_cache.pop_back();
+    return ZK_OK;
+}
+
+int zk_commit_cache_stats(zk_ctx* c, uint64_t* hits, uint64_t* misses, uint64_t* entries) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (hits) *hits = c->cache_hits;
+    if (misses) *misses = c->cache_misses;
+    if (entries) *entries = c->commit_cache.size();
+    return ZK_OK;
+}
+
+int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->device != c->device || !out_xy || (n && !d_coeffs_mont)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    if (n > s->n) return ZK_ERR_BAD_ARG;
+    if (c->commit_cache_on && n) return batch_cached_locked(c, s, 1, &d_coeffs_mont, &n, nullptr, out_xy, out_inf);
+    uint64_t xyz[18];
+    int rc = commit_one_locked(c, s, d_coeffs_mont, n, false, xyz);
+    if (rc) return rc;
+    return finish_point(s->curve, xyz, out_xy, out_inf);
 }
 
 int zk_kzg_commit_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
@@ -488,27 +743,11 @@ int zk_kzg_commit_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, cons
 
 int zk_kzg_round_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
                                    const uint8_t* kinds, uint64_t* out_xyz) {
-    if (!c || !s || s->ctx != c || (n_jobs && (!d_inputs || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
+    if (!c || !s || s->device != c->device || (n_jobs && (!d_inputs || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
     if (n_jobs > 16) return ZK_ERR_BAD_ARG;
-    const int L = fq_limbs64(s->curve);
-    bool fused = s->pre_W != 0 && c->msm_window == 0;
-    for (uint32_t k = 0; k < n_jobs; ++k) {
-        if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
-        if (lens[k] < ZK_PRE_MIN_N) fused = false;
-    }
     Guard g(c);
-    if (fused) return msm_batch_pre_dev(c, s, n_jobs, d_inputs, lens, out_xyz, kinds);
-    for (uint32_t k = 0; k < n_jobs; ++k) {
-        const void* sc = d_inputs[k];
-        int rc;
-        if (!(kinds && kinds[k])) {
-            if ((rc = c->mb[0].scalars.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
-            if ((rc = fr_convert_dev(c, s->curve, 0, d_inputs[k], lens[k], c->mb[0].scalars.p))) return rc;
-            sc = c->mb[0].scalars.p;
-        }
-        if ((rc = zk_msm_g1_srs_partial_dev(c, s, 0, sc, lens[k], out_xyz + (size_t)k * 3 * L))) return rc;
-    }
-    return ZK_OK;
+    SrsRead rl(s->mu);
+    return batch_locked(c, s, n_jobs, d_inputs, lens, kinds, out_xyz, nullptr, nullptr, nullptr);
 }
 
 int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
@@ -518,52 +757,90 @@ int zk_kzg_commit_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* 
 
 int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs_mont, const size_t* lens,
                            const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!c || !s || s->ctx != c || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
+    if (!c || !s || s->device != c->device || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
     if (n_polys > 16) return ZK_ERR_BAD_ARG;
-    const int L = fq_limbs64(s->curve);
-    bool pipelined = s->pre_W != 0 && c->msm_window == 0;
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        if (lens[k] > s->n || (lens[k] && !d_coeffs_mont[k])) return ZK_ERR_BAD_ARG;
-        if (lens[k] < ZK_PRE_MIN_N) pipelined = false;
-    }
-    if (!pipelined) {   // no table or tiny polynomials: one at a time
-        for (uint32_t k = 0; k < n_polys; ++k) {
-            int rc = (kinds && kinds[k])
-                         ? zk_msm_g1_srs_dev(c, s, 0, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr)
-                         : zk_kzg_commit_dev(c, s, d_coeffs_mont[k], lens[k], out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
-            if (rc) return rc;
-        }
-        return ZK_OK;
-    }
     Guard g(c);
-    uint64_t xyz[16 * 18];
-    // window combine and affine normalisation of a job run back to back on one pool thread
-    return msm_batch_pre_dev(c, s, n_polys, d_coeffs_mont, lens, xyz, kinds, out_xy, out_inf);
+    SrsRead rl(s->mu);
+    return batch_cached_locked(c, s, n_polys, d_coeffs_mont, lens, kinds, out_xy, out_inf);
+}
+
+static int ensure_copy_stream(zk_ctx* c) {
+    if (!c->copy_stream) ZK_HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 16; ++i)
+        if (!c->ev_up[i]) ZK_HIP_TRY(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+    return ZK_OK;
+}
+
+// PC::commit(ck, polys) with the caller's host slices (prover.rs:213 passes 4 polynomials, :579 and :606 seven):
+// polynomial k+1 is uploaded (pinned staging ring, copy stream) while polynomial k's MSM runs.
+int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* coeffs_mont, const size_t* lens, uint64_t* out_xy,
+                        uint8_t* out_inf) {
+    if (!c || !s || s->device != c->device || (n_polys && (!coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
+    if (n_polys > 16) return ZK_ERR_BAD_ARG;
+    for (uint32_t k = 0; k < n_polys; ++k)
+        if (lens[k] && !coeffs_mont[k]) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    int rc = ensure_copy_stream(c);
+    if (rc) return rc;
+    const void* d_in[16];
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if (lens[k] > s->n) return ZK_ERR_BAD_ARG;
+        if ((rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
+        d_in[k] = c->mb[k].upload.p;
+    }
+    BeforeJob up = [&](uint32_t k) -> int {
+        int r = zk_h2d(c, c->mb[k].upload.p, coeffs_mont[k], lens[k] * 32, c->copy_stream);
+        if (r) return r;
+        ZK_HIP_TRY(hipEventRecord(c->ev_up[k], c->copy_stream));
+        ZK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
+        return ZK_OK;
+    };
+    if (c->commit_cache_on) {   // the digests need every input on the device first
+        for (uint32_t k = 0; k < n_polys; ++k)
+            if ((rc = up(k))) return rc;
+        return batch_cached_locked(c, s, n_polys, d_in, lens, nullptr, out_xy, out_inf);
+    }
+    return batch_locked(c, s, n_polys, d_in, lens, nullptr, nullptr, out_xy, out_inf, &up);
 }
 
 int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!c || !s || s->ctx != c || !out_xy || (n && !coeffs_mont)) return ZK_ERR_BAD_ARG;
-    Guard g(c);
-    {
-        int rc = c->io_a.ensure((n ? n : 1) * 32);
-        if (rc) return rc;
-        if (n) ZK_HIP_TRY(hipMemcpyAsync(c->io_a.p, coeffs_mont, n * 32, hipMemcpyHostToDevice, c->stream));
-    }
-    return zk_kzg_commit_dev(c, s, c->io_a.p, n, out_xy, out_inf);
+    return zk_kzg_commit_batch(c, s, 1, &coeffs_mont, &n, out_xy, out_inf);
 }
 
 int zk_kzg_open_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
                     const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!c || !s || s->ctx != c || !out_xy || !z_mont || !challenge_mont || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
+    if (!c || !s || s->device != c->device || !out_xy || !z_mont || !challenge_mont || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
     void* d_w = nullptr;
     size_t wlen = 0;
     Guard g(c);
+    SrsRead rl(s->mu);
     {
         int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
         if (rc) return rc;
     }
     if (wlen > s->n) return ZK_ERR_BAD_ARG;
-    return zk_msm_g1_srs_dev(c, s, 0, d_w, wlen, out_xy, out_inf);
+    uint64_t xyz[18];
+    int rc = msm_partial_locked(c, s, 0, d_w, wlen, xyz);
+    if (rc) return rc;
+    return finish_point(s->curve, xyz, out_xy, out_inf);
+}
+
+// PC::open with the caller's host slices: the polynomials are uploaded (staged), everything else as zk_kzg_open_dev
+int zk_kzg_open(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* polys_mont, const size_t* lens, const uint64_t* z_mont,
+                const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || !s || s->device != c->device || !out_xy || !z_mont || !challenge_mont || (n_polys && (!polys_mont || !lens))) return ZK_ERR_BAD_ARG;
+    if (n_polys > 16) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    const void* d_in[16];
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if (lens[k] && !polys_mont[k]) return ZK_ERR_BAD_ARG;
+        int rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32);
+        if (rc) return rc;
+        if ((rc = zk_h2d(c, c->mb[k].upload.p, polys_mont[k], lens[k] * 32, c->stream))) return rc;
+        d_in[k] = c->mb[k].upload.p;
+    }
+    return zk_kzg_open_dev(c, s, n_polys, d_in, lens, z_mont, challenge_mont, out_xy, out_inf);
 }
 
 int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
@@ -579,6 +856,22 @@ int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* co
         if (!d_out) return ZK_ERR_BAD_ARG;
         ZK_HIP_TRY(hipMemcpyAsync(d_out, d_w, wlen * 32, hipMemcpyDeviceToDevice, c->stream));
     }
+    return ZK_OK;
+}
+
+int zk_io_stats(zk_ctx* c, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (h2d_bytes) *h2d_bytes = c->h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = c->d2h_bytes;
+    if (reset) c->h2d_bytes = c->d2h_bytes = 0;
+    return ZK_OK;
+}
+
+int zk_ctx_set_staging(zk_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 1) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    c->staging_mode = mode;
     return ZK_OK;
 }
 

@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <list>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <condition_variable>
@@ -159,9 +162,9 @@ struct DevBuf {
 };
 
 struct MsmBufs {
-    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars, stage;
+    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars, stage, upload;
     void release() {
-        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars, &stage};
+        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars, &stage, &upload};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -214,11 +217,50 @@ struct zk_ctx {
     hipEvent_t ev_job[16] = {};
     void* pinned = nullptr;      // virtual-window sums of up to 16 batched MSMs land here
     size_t pinned_cap = 0;
+    void* pinned_small = nullptr;   // 4 KiB: digests of the commitment cache
     DevBuf msm_tmp;       // infinity flags staging (SRS registration)
+
+    // host-pointer entry points (the drop-in boundary): pinned staging ring + a copy stream so that the upload of
+    // polynomial k+1 runs under the MSM of polynomial k (hostio.hip)
+    hipStream_t copy_stream = nullptr;
+    static constexpr int STAGE_SLOTS = 4;
+    static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+    void* stage_pin[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_busy[STAGE_SLOTS] = {false, false, false, false};
+    int stage_next = 0;
+    hipEvent_t ev_up[16] = {};     // "input of job k is on the device" (copy stream -> main stream)
+    uint64_t h2d_bytes = 0, d2h_bytes = 0;   // PCIe volume of the host-pointer entry points (zk_io_stats)
+    int staging_mode = 1;                     // 1 = pinned staging ring, 0 = plain hipMemcpyAsync from the caller's (pageable) buffer
+
+    // N3: opt-in content-addressed commitment cache -- key = (srs id, input kind, length, 256-bit
+    // digest of the coefficient vector computed on the device); value = the affine commitment
+    struct CommitEntry {
+        uint64_t srs_id;
+        uint64_t n;
+        uint32_t kind;
+        uint64_t dig[4];
+        uint64_t xy[12];
+        uint8_t inf;
+    };
+    bool commit_cache_on = false;
+    size_t commit_cache_cap = 64;
+    std::list<CommitEntry> commit_cache;      // most recently used first
+    uint64_t cache_hits = 0, cache_misses = 0;
+    DevBuf digest_dev;                        // 16 jobs x 4 u64
 };
 
+// An SRS belongs to a DEVICE, not to a ctx: every zk_ctx of that device may use it (several proof streams share one
+// copy of the bases and of the window table).  Readers (the MSM entry points) hold `mu` shared from reading the
+// pointers to the end of their kernel enqueue; zk_srs_precompute takes it exclusively, drains the device and swaps
+// the bases for the table.  refs counts user handles; a cached SRS (zk_srs_register) outlives refs == 0 until evicted.
 struct zk_srs {
-    zk_ctx* ctx = nullptr;
+    int device = 0;
+    uint64_t id = 0;
+    std::shared_mutex mu;
+    std::atomic<int> refs{1};
+    bool cached = false;
+    uint64_t digest[4] = {0, 0, 0, 0};
     int curve = 0;
     size_t n = 0;
     void* d_xy = nullptr;   // n points in the device-internal form (2 x Fu, 29-bit limbs, padded to 16 B);
@@ -258,8 +300,10 @@ int msm_precompute_dev(zk_ctx* c, zk_srs* s);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 // a batch of commitments over one SRS, queued back to back; the host blocks once per result
 // out_xy / out_inf (optional): also normalise every result to affine (n_polys x 2L limbs, n_polys flags)
+// before_job(k) (optional) is called right before job k's kernels are queued on the ctx stream
 int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
-                      const uint8_t* kinds = nullptr, uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
+                      const uint8_t* kinds = nullptr, uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr,
+                      const std::function<int(uint32_t)>* before_job = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
@@ -275,3 +319,14 @@ int quad_selftest_dev(zk_ctx* c, int curve, uint32_t n_quads, uint32_t* out2);
 int quotient_evals_dev(zk_ctx* c, int curve, uint32_t log_n, const zk_quotient_args* q, void* d_out);
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                          const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);
+
+// hostio.hip: staged host<->device copies and digests
+// Copies run on `st`; h2d returns once the host buffer has been read (the device copy may still be in flight on st),
+// d2h returns once the host buffer is filled.
+int zk_h2d(zk_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
+int zk_d2h(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
+void zk_io_release(zk_ctx* c);
+// 256-bit digest of a host buffer (4 lanes; block-parallel on the ctx-less pool)
+void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]);
+// 256-bit multiset digests of n_jobs device vectors of 32-byte elements -> d_out[job][4] (async on st)
+int dev_digest256(const void* const* d_ptrs, const size_t* lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st);

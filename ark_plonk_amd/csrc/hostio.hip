@@ -1,0 +1,232 @@
+// Host <-> device transfers of the host-pointer entry points (zk_ntt, zk_kzg_commit(_batch), zk_kzg_open,
+// zk_msm_g1_srs: the calls a Rust shim binds) and the content digests of the SRS / commitment caches.
+//
+// The reference hands over ordinary heap slices (`domain.ifft(&w_l_scalar)` prover.rs:196-203, `PC::commit(ck, polys)`
+// prover.rs:213), i.e. pageable memory.  A hipMemcpyAsync from pageable memory is staged by the runtime on the calling
+// thread; here the staging is explicit: a ring of pinned 8 MiB slots per ctx, the caller's bytes copied into a slot by
+// the ctx's host pool (several cores share one slot, a single core's memcpy is slower than the PCIe link) and sent by DMA
+// while the next slot is being filled.  Pinned or hipHostRegister-ed caller buffers are detected and sent directly.
+#include "ctx.h"
+
+namespace {
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary heap pointer: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int stage_setup(zk_ctx* c) {
+    for (int i = 0; i < zk_ctx::STAGE_SLOTS; ++i) {
+        if (!c->stage_pin[i]) {
+            if (hipHostMalloc(&c->stage_pin[i], zk_ctx::STAGE_BYTES, hipHostMallocDefault) != hipSuccess) return ZK_ERR_OOM;
+            ZK_HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+            c->stage_busy[i] = false;
+        }
+    }
+    return ZK_OK;
+}
+
+// copy with the ctx's pool: pieces of 1 MiB
+void pooled_memcpy(zk_ctx* c, void* dst, const void* src, size_t bytes) {
+    constexpr size_t PIECE = (size_t)1 << 20;
+    const uint32_t pieces = (uint32_t)((bytes + PIECE - 1) / PIECE);
+    if (pieces <= 1 || !c->pool) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    c->pool->run(pieces, [&](uint32_t k) {
+        const size_t off = (size_t)k * PIECE;
+        const size_t len = bytes - off < PIECE ? bytes - off : PIECE;
+        memcpy((char*)dst + off, (const char*)src + off, len);
+    });
+}
+
+int take_slot(zk_ctx* c, int* slot) {
+    const int s = c->stage_next;
+    c->stage_next = (s + 1) % zk_ctx::STAGE_SLOTS;
+    if (c->stage_busy[s]) {
+        ZK_HIP_TRY(hipEventSynchronize(c->stage_ev[s]));
+        c->stage_busy[s] = false;
+    }
+    *slot = s;
+    return ZK_OK;
+}
+
+// ---- digests --------------------------------------------------------------------------------------------
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull,
+                   P5 = 0x27D4EB2F165667C5ull;
+
+ZK_HD uint64_t fmix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// one block: four xxhash-style lanes over 32-byte stripes, cross-mixed at the end so that every output word depends
+// on every input byte
+void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, uint64_t out[4]) {
+    uint64_t a[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) a[k] = rotl64(a[k] + w[k] * P2, 31) * P1;
+    }
+    if (i < bytes) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        memcpy(w, p + i, bytes - i);
+        for (int k = 0; k < 4; ++k) a[k] = rotl64(a[k] + w[k] * P2, 31) * P1;
+    }
+    const uint64_t len = (uint64_t)bytes;
+    for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < 4; ++k) a[k] = fmix64(a[k] ^ rotl64(a[(k + 1) & 3], 17) ^ (a[(k + 2) & 3] * P3) ^ (len + P5 * (uint64_t)(k + 1)));
+    for (int k = 0; k < 4; ++k) out[k] = a[k];
+}
+
+// per element (index i, four 64-bit words): four independently seeded chained mixes; the vector digest is their sum
+// over i (a multiset hash: position enters through i, so the launch geometry and reduction order are free)
+struct DigJobs {
+    const void* p[16];
+    uint64_t n[16];
+};
+__global__ void __launch_bounds__(256) digest_kernel(DigJobs jobs, uint64_t* out) {
+    const uint32_t job = blockIdx.y;
+    const uint64_t* v = (const uint64_t*)jobs.p[job];
+    const uint64_t n = jobs.n[job];
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 lo = reinterpret_cast<const ulonglong2*>(v)[2 * i], hi = reinterpret_cast<const ulonglong2*>(v)[2 * i + 1];
+        const uint64_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint64_t h = fmix64(i * 0x9E3779B97F4A7C15ull + 0xD6E8FEB86659FD93ull * (uint64_t)(k + 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h = fmix64(h ^ (w[(j + k) & 3] + 0x9E3779B185EBCA87ull * (uint64_t)(j + 1)));
+            acc[k] += h;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t x = acc[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[4 * job + k], (unsigned long long)x);
+    }
+}
+
+}  // namespace
+
+void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]) {
+    constexpr size_t BLOCK = (size_t)1 << 20;
+    const uint32_t nblk = (uint32_t)((bytes + BLOCK - 1) / BLOCK);
+    if (nblk <= 1) {
+        block_digest((const uint8_t*)p, bytes, seed, out);
+        return;
+    }
+    std::vector<uint64_t> parts((size_t)nblk * 4);
+    host_parallel_for(nblk, [&](uint32_t k) {
+        const size_t off = (size_t)k * BLOCK;
+        const size_t len = bytes - off < BLOCK ? bytes - off : BLOCK;
+        block_digest((const uint8_t*)p + off, len, seed ^ (P4 * (uint64_t)(k + 1)), &parts[(size_t)k * 4]);
+    });
+    block_digest((const uint8_t*)parts.data(), parts.size() * 8, seed ^ (uint64_t)bytes, out);
+}
+
+int dev_digest256(const void* const* d_ptrs, const size_t* d_lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st) {
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > 16) return ZK_ERR_BAD_ARG;
+    DigJobs jobs;
+    for (uint32_t k = 0; k < 16; ++k) {
+        jobs.p[k] = k < n_jobs ? d_ptrs[k] : nullptr;
+        jobs.n[k] = k < n_jobs ? d_lens[k] : 0;
+    }
+    ZK_HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_jobs * 32, st));
+    hipLaunchKernelGGL(digest_kernel, dim3(512, n_jobs), dim3(256), 0, st, jobs, d_out);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_h2d(zk_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return ZK_OK;
+    c->h2d_bytes += bytes;
+    if (c->staging_mode == 0 || is_pinned(h_src)) {
+        ZK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        return ZK_OK;
+    }
+    int rc = stage_setup(c);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += zk_ctx::STAGE_BYTES) {
+        const size_t len = bytes - off < zk_ctx::STAGE_BYTES ? bytes - off : zk_ctx::STAGE_BYTES;
+        int s;
+        if ((rc = take_slot(c, &s))) return rc;
+        pooled_memcpy(c, c->stage_pin[s], (const char*)h_src + off, len);
+        ZK_HIP_TRY(hipMemcpyAsync((char*)d_dst + off, c->stage_pin[s], len, hipMemcpyHostToDevice, st));
+        ZK_HIP_TRY(hipEventRecord(c->stage_ev[s], st));
+        c->stage_busy[s] = true;
+    }
+    return ZK_OK;
+}
+
+int zk_d2h(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return ZK_OK;
+    c->d2h_bytes += bytes;
+    if (c->staging_mode == 0 || is_pinned(h_dst)) {
+        ZK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        ZK_HIP_TRY(hipStreamSynchronize(st));
+        return ZK_OK;
+    }
+    int rc = stage_setup(c);
+    if (rc) return rc;
+    // keep up to STAGE_SLOTS DMA chunks in flight; unload the oldest into the caller's buffer while the rest arrive
+    struct Pending {
+        int slot;
+        size_t off, len;
+    };
+    Pending ring[zk_ctx::STAGE_SLOTS];
+    int head = 0, count = 0;
+    auto drain_one = [&]() -> int {
+        Pending& p = ring[head];
+        ZK_HIP_TRY(hipEventSynchronize(c->stage_ev[p.slot]));
+        c->stage_busy[p.slot] = false;
+        pooled_memcpy(c, (char*)h_dst + p.off, c->stage_pin[p.slot], p.len);
+        head = (head + 1) % zk_ctx::STAGE_SLOTS;
+        --count;
+        return ZK_OK;
+    };
+    for (size_t off = 0; off < bytes; off += zk_ctx::STAGE_BYTES) {
+        const size_t len = bytes - off < zk_ctx::STAGE_BYTES ? bytes - off : zk_ctx::STAGE_BYTES;
+        if (count == zk_ctx::STAGE_SLOTS && (rc = drain_one())) return rc;
+        int s;
+        if ((rc = take_slot(c, &s))) return rc;
+        ZK_HIP_TRY(hipMemcpyAsync(c->stage_pin[s], (const char*)d_src + off, len, hipMemcpyDeviceToHost, st));
+        ZK_HIP_TRY(hipEventRecord(c->stage_ev[s], st));
+        c->stage_busy[s] = true;
+        ring[(head + count) % zk_ctx::STAGE_SLOTS] = Pending{s, off, len};
+        ++count;
+    }
+    while (count)
+        if ((rc = drain_one())) return rc;
+    return ZK_OK;
+}
+
+void zk_io_release(zk_ctx* c) {
+    for (int i = 0; i < zk_ctx::STAGE_SLOTS; ++i) {
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+        if (c->stage_pin[i]) (void)hipHostFree(c->stage_pin[i]);
+        c->stage_ev[i] = nullptr;
+        c->stage_pin[i] = nullptr;
+    }
+    for (int i = 0; i < 16; ++i)
+        if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+    c->digest_dev.release();
+}

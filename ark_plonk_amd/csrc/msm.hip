@@ -1017,16 +1017,23 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
 }
 
-// arkworks-layout affine (x||y Montgomery words; x = y = 0 or flagged = infinity) -> internal points
-template <class F>
+// arkworks-layout affine (x||y Montgomery words) -> internal points.  Accepted encodings of the point at infinity:
+// the flag, x = y = 0, and GroupAffine::zero() = (0, 1) (Montgomery one) -- what this library itself emits for an
+// infinite result and what an arkworks caller holds; (0, 1) lies on neither supported curve (b = 4 / b = 3).
+template <class Cv>
 __global__ void bases_to_internal(const uint32_t* xy_sat, const uint8_t* inf, uint64_t n, void* out) {
+    typedef typename Cv::FqU F;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* w = xy_sat + i * 2 * F::SAT;
-    uint32_t any = 0;
-    for (int k = 0; k < 2 * F::SAT; ++k) any |= w[k];
+    uint32_t any_x = 0, y_not_zero = 0, y_not_one = 0;
+    for (int k = 0; k < F::SAT; ++k) {
+        any_x |= w[k];
+        y_not_zero |= w[F::SAT + k];
+        y_not_one |= w[F::SAT + k] ^ Cv::FqP::R(k);
+    }
     uint4* q = reinterpret_cast<uint4*>(out) + i * (2 * Store<F>::U4);
-    if (any == 0 || (inf && inf[i])) {
+    if ((any_x == 0 && (y_not_zero == 0 || y_not_one == 0)) || (inf && inf[i])) {
         st_fu<F>(q, F::zero());
         st_fu<F>(q + Store<F>::U4, F::zero());
         return;
@@ -1607,7 +1614,8 @@ int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 template <class Cv>
 int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
                   const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
-                  uint64_t* out_xy /* optional: n_polys x 2L affine */, uint8_t* out_inf /* optional flags */) {
+                  uint64_t* out_xy /* optional: n_polys x 2L affine */, uint8_t* out_inf /* optional flags */,
+                  const std::function<int(uint32_t)>* before_job /* optional: runs before job k is queued */) {
     typedef typename Cv::Fq Fq;
     constexpr int L64 = Fq::N / 2;
     if (n_polys == 0) return ZK_OK;
@@ -1624,6 +1632,7 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[k];
         const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
+        if (before_job && (rc = (*before_job)(k))) return rc;
         if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, d_coeffs[k], lens[k], st, mont))) return rc;
         if ((rc = pre_queue_accumulate<Cv>(c, pl[k], mb, s, 0, st))) return rc;
     }
@@ -1743,7 +1752,7 @@ int ZK_SYM(msm_convert_bases_dev)(zk_ctx* c, const void* d_xy_sat, const uint8_t
     if (n == 0) return ZK_OK;
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
-    hipLaunchKernelGGL(bases_to_internal<CurveSel::FqU>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_xy_sat, d_inf, (uint64_t)n,
+    hipLaunchKernelGGL(bases_to_internal<CurveSel>, dim3(blocks), dim3(T), 0, c->stream, (const uint32_t*)d_xy_sat, d_inf, (uint64_t)n,
                        d_out_internal);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
@@ -1755,8 +1764,8 @@ int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
 }
 int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
-                              const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf) {
-    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf);
+                              const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job) {
+    return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf, before_job);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

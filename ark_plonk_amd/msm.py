@@ -55,16 +55,24 @@ class CommitterKey:
     """Device-resident `powers_of_g` (what `PC::trim` hands the prover; circuit.rs:236,276)."""
 
     def __init__(self, powers_of_g, curve="bls12_381", ctx: Context | None = None, infinity=None):
+        """Host arrays go through zk_srs_register, which is content-addressed: registering the same bases again (the
+        reference trims on every gen_proof, circuit.rs:276) returns the resident handle, window table included.
+        Device tensors (zk_srs_register_dev) are never cached.  The handle belongs to the device: pass `ctx=` of any
+        Context on the same GPU to the call methods to use it from another proof stream."""
         self.curve = get_curve(curve)
         L = self.curve.fq_limbs
         self._h = ctypes.c_void_p()
         if _is_torch(powers_of_g):
             self.ctx = ctx or default_context(powers_of_g.device.index)
             n = check_dev_tensor(powers_of_g, 2 * L, self.ctx.device)
+            d_inf = None
             if infinity is not None:
-                raise ValueError("infinity flags are only accepted with host arrays")
+                import torch
+                if not _is_torch(infinity) or infinity.dtype != torch.uint8 or infinity.numel() != n or not infinity.is_cuda:
+                    raise ValueError("device bases take device uint8 infinity flags of the same length")
+                d_inf = ptr_of(infinity.contiguous())
             self.ctx.use_torch_stream()
-            check(lib().zk_srs_register_dev(self.ctx.handle, self.curve.curve_id, ptr_of(powers_of_g), n, ctypes.byref(self._h)),
+            check(lib().zk_srs_register_dev(self.ctx.handle, self.curve.curve_id, ptr_of(powers_of_g), d_inf, n, ctypes.byref(self._h)),
                   "zk_srs_register_dev")
         else:
             self.ctx = ctx or default_context(0)
@@ -90,7 +98,8 @@ class CommitterKey:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().zk_srs_free(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib().zk_srs_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -139,11 +148,32 @@ class CommitterKey:
             check(lib().zk_kzg_commit(self.ctx.handle, self._h, ptr_of(a), a.shape[0], ptr_of(out), ptr_of(inf)), "zk_kzg_commit")
         return _point(out, inf, self.curve)
 
+    def with_ctx(self, ctx: Context) -> "CommitterKey":
+        """The same device-resident SRS (and window table) driven from another Context of the same GPU."""
+        if ctx.device != self.ctx.device:
+            raise ValueError("an SRS handle belongs to one device")
+        other = object.__new__(CommitterKey)
+        other.curve, other.ctx, other.n, other._h, other._borrowed = self.curve, ctx, self.n, self._h, True
+        return other
+
     def commit_batch(self, polys, canonical=None) -> list:
-        """The MSMs of one prover round (<= 16 device-resident vectors) as one batch.  canonical[k] marks
-        inputs that already are canonical scalars (opening witnesses) rather than Montgomery coefficients."""
+        """The MSMs of one prover round (<= 16 vectors) as one batch.  Device tensors: zk_kzg_round_batch_dev;
+        canonical[k] marks inputs that already are canonical scalars (opening witnesses) rather than Montgomery
+        coefficients.  Host arrays: zk_kzg_commit_batch (what GpuKZG10::commit forwards `polys` to)."""
         L = self.curve.fq_limbs
         k = len(polys)
+        if k and not _is_torch(polys[0]):
+            if canonical is not None and any(canonical):
+                raise ValueError("host batches hold Montgomery coefficients only")
+            arrs = [as_host_u64(p, 4) for p in polys]
+            ptrs = (ctypes.c_void_p * k)()
+            lens = (ctypes.c_size_t * k)()
+            for i, a in enumerate(arrs):
+                ptrs[i], lens[i] = a.ctypes.data, a.shape[0]
+            out = np.zeros((k, 2 * L), dtype=np.uint64)
+            inf = np.zeros(k, dtype=np.uint8)
+            check(lib().zk_kzg_commit_batch(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(out), ptr_of(inf)), "zk_kzg_commit_batch")
+            return [_point(out[i], inf[i:i + 1], self.curve) for i in range(k)]
         kinds = None
         if canonical is not None:
             kinds = np.ascontiguousarray([1 if f else 0 for f in canonical], dtype=np.uint8)
@@ -185,11 +215,17 @@ class CommitterKey:
         k = len(polys)
         ptrs = (ctypes.c_void_p * k)()
         lens = (ctypes.c_size_t * k)()
+        z = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
+        ch = np.ascontiguousarray(challenge_mont, dtype=np.uint64).reshape(4)
+        if k and not _is_torch(polys[0]):
+            arrs = [as_host_u64(p, 4) for p in polys]
+            for i, a in enumerate(arrs):
+                ptrs[i], lens[i] = a.ctypes.data, a.shape[0]
+            check(lib().zk_kzg_open(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(z), ptr_of(ch), ptr_of(out), ptr_of(inf)), "zk_kzg_open")
+            return _point(out, inf, self.curve)
         for i, p in enumerate(polys):
             lens[i] = check_dev_tensor(p, 4, self.ctx.device)
             ptrs[i] = p.data_ptr()
-        z = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
-        ch = np.ascontiguousarray(challenge_mont, dtype=np.uint64).reshape(4)
         self.ctx.use_torch_stream()
         check(lib().zk_kzg_open_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(z), ptr_of(ch), ptr_of(out), ptr_of(inf)),
               "zk_kzg_open_dev")
@@ -217,6 +253,17 @@ def kzg_witness(polys, point_mont, challenge_mont, curve="bls12_381", ctx: Conte
     check(lib().zk_kzg_witness_dev(ctx.handle, cv.curve_id, k, ptrs, lens, ptr_of(z), ptr_of(ch), ptr_of(out), ctypes.byref(n_out)),
           "zk_kzg_witness_dev")
     return out[: n_out.value]
+
+
+def srs_cache_stats() -> dict:
+    """Counters of the content-addressed SRS cache behind zk_srs_register."""
+    v = [ctypes.c_uint64() for _ in range(4)]
+    check(lib().zk_srs_cache_stats(*[ctypes.byref(x) for x in v]), "zk_srs_cache_stats")
+    return {"hits": v[0].value, "misses": v[1].value, "entries": v[2].value, "resident_bytes": v[3].value}
+
+
+def srs_cache_config(max_idle_bytes: int):
+    check(lib().zk_srs_cache_config(int(max_idle_bytes)), "zk_srs_cache_config")
 
 
 class VariableBaseMSM:

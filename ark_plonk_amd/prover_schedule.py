@@ -27,8 +27,8 @@ from .msm import CommitterKey, sum_partials_batch
 
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
-                 dist=None, seed: int = 0x5EED0000, dedup: bool = False,
-                 grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False):
+                 dist=None, seed: int = 0x5EED0000, dedup=False,
+                 grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform"):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -40,7 +40,12 @@ class ProofSchedule:
         # commitments cached by polynomial label, so the 12 polynomials the reference
         # commits a second time in round 5 (prover.rs:569-607) cost no MSM: 29 -> 17 per proof (20 on the first,
         # which also commits the prover key's sigma polynomials), same outputs
-        self.dedup = dedup
+        # dedup: False | True ("label": the Python-side label cache of round 1, kept for comparison) | "abi" (the library's
+        # content-addressed commitment cache, zk_ctx_set_commit_cache: what an unchanged Prover::prove gets)
+        self.dedup = dedup is True or dedup == "label"
+        self.dedup_abi = dedup == "abi"
+        if self.dedup_abi:
+            ctx.set_commit_cache(True)
         # prover.rs:579-618 issues PC::commit(aw) / PC::open / PC::commit(saw) / PC::open as four calls.  The default
         # replays them as four batches -- what a drop-in PC implementation sees.  All 16 MSMs depend only on values
         # known before the first call (both opening challenges are drawn with no transcript append in between), so
@@ -67,6 +72,22 @@ class ProofSchedule:
 
         # 17 distinct polynomials of the proof: w_l w_r w_o w_4 | f h1 h2 | z z2 | t1..t4 | lin table | 2 witnesses
         self.evals = [rnd(n) for _ in range(4)]          # wire evaluations (prover.rs:188-192)
+        if data == "benchcircuit":
+            # the wire columns of benches/plonk.rs' BenchCircuit -- 3 random blinding rows
+            # (composer.rs:580-596), then add_dummy_constraints pairs (composer.rs:493-548: rows (6, 7, -20, 1) and
+            # (-20, 6, 7, 0)) up to 2^(log_n-1) + 2 gates, zero-padded to n (preprocess.rs:61-88)
+            from .curves import fr_to_mont
+            pat = fr_to_mont(self.cv, [6, 7, self.cv.r - 20, 1, self.cv.r - 20, 6, 7, 0])
+            rows = torch.from_numpy(pat.view(np.int64)).to(dev).view(2, 4, 4)     # [row of the pair][wire][limb]
+            gates = min(n - 4, n // 2 + 2)
+            for k in range(4):
+                col = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+                col[:3] = self.evals[k][:3]
+                body = rows[:, k, :].repeat((gates + 1) // 2, 1)[:gates]
+                col[3:3 + gates] = body
+                self.evals[k] = col
+        elif data != "uniform":
+            raise ValueError("data: 'uniform' or 'benchcircuit'")
         self.aux_evals = [rnd(n) for _ in range(9)]      # table, f, h1, h2, z, z2, pi, l1, l1*alpha^2 evaluation vectors
         self.sigma = [rnd(n) for _ in range(4)]          # sigma polynomials (coefficients, from the prover key)
         self.coef = [torch.empty((n, 4), dtype=torch.int64, device=dev) for _ in range(13)]
@@ -101,6 +122,11 @@ class ProofSchedule:
             return [self._cache[lb] for lb in labels]
         self.msms_run += len(polys)
         if self.world == 1:
+            if self.dedup_abi:
+                before = self.ctx.commit_cache_stats()["hits"]
+                res = self.ck.commit_batch(polys, canonical=canonical)
+                self.msms_run -= self.ctx.commit_cache_stats()["hits"] - before
+                return res
             return self.ck.commit_batch(polys, canonical=canonical)
         # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the round
         torch = self.torch
@@ -197,3 +223,73 @@ class ProofSchedule:
 
     def msm_count(self) -> int:
         return 29
+
+
+class DropInSchedule:
+    """The same per-proof schedule through the HOST-POINTER entry points a Rust shim binds: every
+    transform is one `zk_ntt` on ordinary (pageable) numpy buffers -- the patched ark-poly sees one `fft_in_place` at a
+    time -- every `PC::commit(ck, polys)` is one `zk_kzg_commit_batch` over the caller's slices and every `PC::open` one
+    `zk_kzg_open`; the SRS is registered once (zk_srs_register is content-addressed, so the reference's `PC::trim` on every
+    gen_proof, circuit.rs:276, is a lookup).  Same seeded inputs and same outputs as `ProofSchedule`; what differs is that
+    every buffer crosses PCIe on every call, as it does for an unchanged `Prover::prove`."""
+
+    def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", seed: int = 0x5EED0000):
+        import torch
+        self.cv = get_curve(curve)
+        self.log_n, self.n, self.ctx, self.ck = log_n, 1 << log_n, ctx, ck
+        self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
+        self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
+        dev = torch.device("cuda", ctx.device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        n = self.n
+
+        def rnd(rows):   # the same draws, in the same order, as ProofSchedule
+            return torch.randint(0, 1 << 62, (rows, 4), dtype=torch.int64, device=dev, generator=g).cpu().numpy().view(np.uint64)
+
+        self.evals = [rnd(n) for _ in range(4)]
+        self.aux_evals = [rnd(n) for _ in range(9)]
+        self.sigma = [rnd(n) for _ in range(4)]
+        self.quot = rnd(4 * n)
+        self.ev4n = np.empty((4 * n, 4), dtype=np.uint64)
+        self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
+        self.chi_mont = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
+        self.msms_run = 0
+
+    def run_once(self):
+        d, d4, n = self.dom_n, self.dom_4n, self.n
+        ck = self.ck
+        out = []
+        c = [None] * 13
+        for i in range(4):
+            c[i] = d.ifft(self.evals[i])
+        out += ck.commit_batch(c[:4])                               # prover.rs:213
+        c[4] = d.ifft(self.aux_evals[0])
+        c[5] = d.ifft(self.aux_evals[1])
+        out += ck.commit_batch([c[5]])                              # :289
+        c[6] = d.ifft(self.aux_evals[2])
+        c[7] = d.ifft(self.aux_evals[3])
+        out += ck.commit_batch([c[6]])                              # :312
+        out += ck.commit_batch([c[7]])                              # :315
+        for i in range(4):
+            d.fft(self.sigma[i])                                    # permutation/mod.rs:671-674
+        c[8] = d.ifft(self.aux_evals[4])
+        out += ck.commit_batch([c[8]])                              # :361
+        c[9] = d.ifft(self.aux_evals[5])
+        out += ck.commit_batch([c[9]])                              # :387
+        c[10] = d.ifft(self.aux_evals[6])
+        c[11] = d.ifft(self.aux_evals[7])
+        for poly in (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10]):
+            d4._run(2, poly, out=self.ev4n)                         # quotient_poly.rs:72-120
+        c[12] = d.ifft(self.aux_evals[8])
+        d4._run(2, c[12], out=self.ev4n)
+        t = d4.coset_ifft(self.quot)                                # quotient_poly.rs:175-177
+        out += ck.commit_batch([t[i * n:(i + 1) * n] for i in range(4)])    # :459
+        aw = [c[11], self.sigma[0], self.sigma[1], self.sigma[2], c[5], c[7], c[4]]
+        saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]
+        out += ck.commit_batch(aw)                                  # :579
+        out.append(ck.open(aw + [c[0], c[1], c[2], c[3]], self.z_mont, self.chi_mont))   # :582
+        out += ck.commit_batch(saw)                                 # :606
+        out.append(ck.open(saw, self.z_mont, self.chi_mont))        # :609
+        self.msms_run = 29
+        assert len(out) == 29
+        return out

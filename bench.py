@@ -4,26 +4,36 @@
 A "step" = one proof's hot path: the reference's exact per-proof schedule of 31 transforms and 29
 KZG commitments (ark_plonk_amd/prover_schedule.py <- prover.rs:163-638) at n = 2^20 constraints,
 BLS12-381 + KZG10, on synthetic polynomials with every input (SRS, evaluation vectors) already
-resident in HBM.  N > 1: one process per GPU (torchrun).  `value` is the throughput of N replicas --
-whole proofs are independent, so every rank runs the schedule K times with no data-path collective
-(SURVEY.md 8e "whole proofs: replicas only", scaling "weak").  The same run then times a second leg,
-reported under `msm_sharded` and never part of `value`: one proof stream with every MSM sharded by
-points over the ranks and combined by an RCCL all-gather of Jacobian partials per prover round (NTTs
-replicated) -- the single-proof latency mode.  `--mode shard` makes that leg the headline instead
-(scaling "strong").
+resident in HBM.
 
-N = 1 adds a `concurrent_streams` leg (also never part of `value`): the same GPU with 4 proofs in flight
-(one thread + zk_ctx + HIP stream each), i.e. the throughput a proving service would see.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, before anything touches the GPU) and relays rank 0's
+line; under an external torchrun it is a rank.  `value` for N > 1 is the throughput of N replicas -- whole
+proofs are independent, so every rank runs the schedule K times with no data-path collective (SURVEY.md 8e
+"whole proofs: replicas only", scaling "weak").  The same run then times extra legs, never part of `value`:
+`msm_sharded` (this size) and `msm_sharded_n22` (BASELINE config 3, n = 2^22): one proof stream with every MSM
+sharded by points over the ranks and combined by an RCCL all-gather of Jacobian partials per prover round
+(NTTs replicated).  `--mode shard` makes the sharded form the headline instead (scaling "strong").
+
+N = 1 adds, also never part of `value`:
+  concurrent_streams  the same GPU with 4 proofs in flight (one thread + zk_ctx + HIP stream each, ONE shared SRS);
+  drop_in             the same schedule through the host-pointer calls a Rust shim binds (zk_ntt, zk_kzg_commit_batch,
+                      zk_kzg_open on pageable buffers, SRS registered once): the unchanged-caller number, with the
+                      PCIe bytes it moves;
+  dedup               the schedule with the library's content-addressed commitment cache (SURVEY.md 8f N3);
+  no_precompute       the per-window MSM path (no window table), for the table's cost/benefit.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate) with the
 algorithmic bytes of SURVEY.md 8d (128 B per point) over its HIP-event-timed launches;
-`cpu_baseline` times the oracle's CPU restatement of the ark 0.3 algorithms on a bounded sample.
+`cpu_baseline` times the oracle's CPU restatement of the ark 0.3 algorithms at the benchmark sizes.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,6 +54,7 @@ LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
 MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
 # issue cycles of one mixed addition at the kernel's 2 waves/SIMD (220 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
 MADD_CYCLES_2WAVES = 3542 * 4.77 + 126 * 4.70 + 468 * 4.45 + 627 * 2.64
+CURVE_TITLE = {"bls12_381": "BLS12-381", "bn254": "BN254"}
 
 
 def ark_adds(n: int, bits: int = 255) -> int:
@@ -73,42 +84,88 @@ def build_srs(ctx, cv, n, lo, hi, torch):
     return out
 
 
-def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255):
-    """Bounded sample of the same workload on the host cores with the oracle's CPU restatement."""
+def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45.0):
+    """The oracle's CPU restatement (oracle/ark_cpu.cpp, OpenMP) timed AT the benchmark sizes on this box's host cores: one
+    ifft(n), one coset_fft(4n) and one MSM(n), multiplied by the schedule's 17 / 14 / 29.  The MSM is timed in the
+    ark/rayon shape (threads over windows: at most W = 17 busy) -- that is the `value` -- and in an all-cores shape
+    (the points cut into per-thread MSMs, summed), SURVEY.md 8d.  Sizes shrink (and are scaled back by operation counts) only
+    if a first small probe says the full-size sample would exceed `budget_s`."""
     from oracle import cpu
     cpu.build()
     cores = cpu.num_threads()
     rng = np.random.default_rng(1)
-    s_ntt = min(log_n, 18)
-    s_msm = min(log_n, 16)
+    cpu.ntt(cid, 1, 10, rng.integers(0, 1 << 62, size=(1024, 4), dtype=np.uint64))  # warm OpenMP
+    # probe at 2^14 to bound the sample
+    probe = 14
+    srs_s = cpu.srs_powers(cid, 0x7A5C0DE, 1 << 10)
+    sc_p = rng.integers(0, 1 << 62, size=(1 << probe, 4), dtype=np.uint64)
+    t0 = time.perf_counter()
+    cpu.msm_g1(cid, np.tile(srs_s, ((1 << probe) >> 10, 1)), sc_p, threads=cores)
+    t_probe = time.perf_counter() - t0
+    s_msm = log_n
+    while s_msm > 14 and t_probe * ark_adds(1 << s_msm, bits) / ark_adds(1 << probe, bits) > budget_s / 3:
+        s_msm -= 1
+    s_ntt = log_n
     x = rng.integers(0, 1 << 62, size=(1 << s_ntt, 4), dtype=np.uint64)
-    cpu.ntt(cid, 1, 10, x[:1024])  # warm OpenMP
     t0 = time.perf_counter()
     cpu.ntt(cid, 1, s_ntt, x)
     t_ntt_n = time.perf_counter() - t0
     t0 = time.perf_counter()
     cpu.ntt(cid, 2, s_ntt + 2, x)
     t_ntt_4n = time.perf_counter() - t0
-    srs = cpu.srs_powers(cid, 0x7A5C0DE, 1 << 10)
-    bases = np.tile(srs, ((1 << s_msm) >> 10, 1))
+    bases = np.tile(srs_s, ((1 << s_msm) >> 10, 1))
     sc = rng.integers(0, 1 << 62, size=(1 << s_msm, 4), dtype=np.uint64)
     t0 = time.perf_counter()
-    cpu.msm_g1(cid, bases, sc, threads=cores)
+    ref_xy, ref_inf = cpu.msm_g1(cid, bases, sc, threads=cores)
     t_msm = time.perf_counter() - t0
-    # scale to the benchmark size by the reference-equivalent operation counts
-    bf = lambda k: (1 << k) // 2 * k  # noqa: E731
-    t_proof = (17 * t_ntt_n * bf(log_n) / bf(s_ntt) + 14 * t_ntt_4n * bf(log_n + 2) / bf(s_ntt + 2)
-               + 29 * t_msm * ark_adds(1 << log_n, bits) / ark_adds(1 << s_msm, bits))
-    return {
+    # all-cores shape: split the points over the threads, each part a full (single-threaded) Pippenger, sum the parts
+    t_all = None
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        parts = min(cores, max(1, (1 << s_msm) >> 12))
+        step = (1 << s_msm) // parts
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=parts) as ex:
+            list(ex.map(lambda k: cpu.msm_g1(cid, bases[k * step:(k + 1) * step], sc[k * step:(k + 1) * step], threads=1), range(parts)))
+        t_all = time.perf_counter() - t0
+    except Exception:
+        t_all = None
+    scale = ark_adds(1 << log_n, bits) / ark_adds(1 << s_msm, bits)
+    t_proof = 17 * t_ntt_n + 14 * t_ntt_4n + 29 * t_msm * scale
+    out = {
         "value": 1.0 / t_proof, "unit": "proofs/s", "cores": cores, "kind": "port",
-        "sample": f"oracle/ark_cpu.cpp (OpenMP): ifft 2^{s_ntt} {t_ntt_n:.3f}s, coset_fft 2^{s_ntt + 2} {t_ntt_4n:.3f}s, "
-                  f"MSM 2^{s_msm} {t_msm:.3f}s (threads over windows as ark/rayon); scaled to n=2^{log_n} by butterfly / "
-                  f"G1-add counts x the 17+14 NTT, 29 MSM per-proof schedule",
+        "sample": f"oracle/ark_cpu.cpp (OpenMP, {cores} threads) at the benchmark sizes: ifft 2^{s_ntt} {t_ntt_n:.3f}s, coset_fft 2^{s_ntt + 2} "
+                  f"{t_ntt_4n:.3f}s, MSM 2^{s_msm} {t_msm:.3f}s (threads over windows as ark/rayon"
+                  + ("" if s_msm == log_n else f"; scaled x{scale:.2f} to 2^{log_n} by G1-add count") + "); x 17 / 14 / 29 per proof",
         "msm_adds_per_s": ark_adds(1 << s_msm, bits) / t_msm,
+        "ntt_ms": {"ifft_n": t_ntt_n * 1e3, "coset_fft_4n": t_ntt_4n * 1e3}, "msm_ms": t_msm * 1e3 * scale,
     }
+    if t_all:
+        t_proof_all = 17 * t_ntt_n + 14 * t_ntt_4n + 29 * t_all * scale
+        out["all_cores"] = {"value": 1.0 / t_proof_all, "msm_ms": t_all * 1e3 * scale, "msm_adds_per_s": ark_adds(1 << s_msm, bits) / t_all,
+                            "shape": f"MSM cut into {parts} point ranges, one single-threaded Pippenger each"}
+    return out
 
 
-def main():
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_ranks: int) -> int:
+    """Start `n_ranks` ranks of this script (one per GPU) and relay their output.  Runs before any import that could
+    touch the GPU; the parent never initialises HIP."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -116,19 +173,25 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"],
                     help="bn254 = BASELINE.json's second-curve config (same kernels, 4-limb base field); the headline is bls12_381")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "benchcircuit"],
+                    help="wire columns: uniform random, or BenchCircuit's periodic {6,7,-20,1} rows + 3 blinding rows (SURVEY.md 8d config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
-                    help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by an "
-                         "untimed-for-value sharded leg; 'shard' = every MSM point-sharded over the ranks (strong scaling)")
+                    help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by "
+                         "untimed-for-value sharded legs; 'shard' = every MSM point-sharded over the ranks (strong scaling)")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent proof streams per GPU (threads with their own zk_ctx + HIP stream); the K steps are shared out")
     ap.add_argument("--streams-leg", type=int, default=4,
                     help="N = 1: after the timed region, also report the throughput with this many concurrent proof streams (0/1 = skip)")
-    ap.add_argument("--no-sharded-leg", action="store_true", help="replica mode: skip the extra sharded-MSM leg")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="replica mode: skip the extra sharded-MSM legs")
+    ap.add_argument("--sharded-n22-leg", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: also time BASELINE config 3 (n = 2^22, MSMs point-sharded); auto = on for the default workload")
+    ap.add_argument("--extra-legs", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: drop_in, dedup and no_precompute legs; auto = on when log-n >= 16")
     ap.add_argument("--dedup", action="store_true",
-                    help="NOT the headline workload: commitments cached by polynomial label (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
+                    help="NOT the headline workload: the library's commitment cache on (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
     ap.add_argument("--grand-products", action="store_true",
                     help="also build the z / z2 evaluation vectors on the device (SURVEY.md 8f N2) inside each step")
     ap.add_argument("--fuse-round5", action="store_true",
@@ -137,7 +200,13 @@ def main():
                     help="also compute the 4n quotient evaluations on the device (SURVEY.md 8f N1) inside each step")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -154,20 +223,17 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
     import ark_plonk_amd as zk
-    from ark_plonk_amd.prover_schedule import ProofSchedule
+    from ark_plonk_amd.prover_schedule import DropInSchedule, ProofSchedule
 
     dev = torch.cuda.current_device()
     ctx = zk.Context(dev)
     ctx.use_torch_stream()
     cv = zk.get_curve(args.curve)
     sbits = cv.r.bit_length()
-    log_n = args.log_n
-    n = 1 << log_n
     steps = args.steps
     mode = args.mode
     if mode == "auto":
@@ -181,33 +247,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_ok(ok: bool) -> bool:
+        """every rank agrees on whether a leg may start / succeeded, so no rank is left alone in a collective"""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     def digest(points):
         import hashlib
         return hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in points)).hexdigest()
 
-    def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps):
+    def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps, log_n: int = args.log_n, precompute: bool = not args.no_precompute,
+                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
-        --streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
-        streams (one thread + zk_ctx + HIP stream each) on this rank's GPU."""
+        n_streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
+        streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
         import threading
+        n = 1 << log_n
         lo, hi = (rank * n // world, (rank + 1) * n // world) if sharded else (0, n)
         S = 1 if sharded else max(1, min(n_streams, steps))
+        srs = build_srs(ctx, cv, n, lo, hi, torch)
+        ck0 = zk.CommitterKey(srs, cv, ctx)
+        del srs
+        if precompute:
+            ck0.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
         lanes = []
         for i in range(S):
             cx = ctx if i == 0 else zk.Context(dev)
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+            ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
-                srs = build_srs(cx, cv, n, lo, hi, torch)
-                ck = zk.CommitterKey(srs, cv, cx)
-                del srs
-                if not args.no_precompute:
-                    ck.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
+                kw = dict(dedup=dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5, data=args.data)
                 if sharded:
-                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5)
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
-                    sched = ProofSchedule(log_n, cx, ck, cv, dedup=args.dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5)
+                    sched = ProofSchedule(log_n, cx, ck, cv, **kw)
                 pts = None
-                for _ in range(args.warmup):
+                for _ in range(warmup):
                     pts = sched.run_once()
             lanes.append({"ctx": cx, "stream": st, "ck": ck, "sched": sched, "pts": pts, "k": steps // S + (1 if i < steps % S else 0)})
         barrier()
@@ -246,7 +324,7 @@ def main():
                 raise errs[0]
         ctx.profile(False)
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient")}
@@ -258,13 +336,54 @@ def main():
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
-               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"]}
-        for ln in lanes:
-            ln["ck"].close()
+               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": lanes[0]["sched"].msms_run,
+               "windows": ck0.table_windows()}
+        if dedup == "abi":
+            for ln in lanes:
+                ln["ctx"].set_commit_cache(False)
+        for ln in lanes[1:]:
+            ln["ctx"].close()
+        ck0.close()
         lanes.clear()
         return res
 
+    def drop_in_region(k: int, log_n: int = args.log_n):
+        """K proofs through the host-pointer entry points, pageable numpy buffers, SRS registered once."""
+        n = 1 << log_n
+        srs = build_srs(ctx, cv, n, 0, n, torch).cpu().numpy().view(np.uint64)
+        t0 = time.perf_counter()
+        ck = zk.CommitterKey(srs, cv, ctx)                  # zk_srs_register: upload + digest
+        t_reg = time.perf_counter() - t0
+        if not args.no_precompute:
+            ck.precompute()
+        t0 = time.perf_counter()
+        ck2 = zk.CommitterKey(srs, cv, ctx)                 # PC::trim on the next gen_proof: a cache hit
+        t_hit = time.perf_counter() - t0
+        sched = DropInSchedule(log_n, ctx, ck2, cv)
+        pts = sched.run_once()
+        ctx.io_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            pts = sched.run_once()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        io = ctx.io_stats()
+        out = {"proofs_per_s": k / dt, "ms_per_proof": dt / k * 1e3, "steps": k,
+               "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
+               "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,
+               "srs_register_ms_first": t_reg * 1e3, "srs_register_ms_cached": t_hit * 1e3, "srs_cache": zk.srs_cache_stats(),
+               "calls": "31 zk_ntt + 9 zk_kzg_commit_batch (4|1|1|1|1|1|4|7|7 polynomials) + 2 zk_kzg_open per proof; pageable host buffers, "
+                        "pinned staging ring",
+               "digest": digest(pts) if args.check else None}
+        ck2.close()
+        ck.close()
+        zk.srs_cache_config(0)          # drop the resident copy before the next leg
+        zk.srs_cache_config(32 << 30)
+        return out
+
     main_sharded = mode == "shard"
+    log_n = args.log_n
+    n = 1 << log_n
     r = timed_region(main_sharded, args.streams)
     dt = r["dt"]
     proofs = steps * (1 if (main_sharded or world == 1) else world)   # replicas: every rank proves K times
@@ -276,21 +395,27 @@ def main():
     alg_bytes = (32.0 + 16.0 * cv.fq_limbs) * r["points_per_launch"]   # 32 B scalar + packed affine base (96 B BLS12-381), once
     avg_s = (acc_ms / max(acc_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if acc_n else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
-    if os.path.exists(pmc_path) and not main_sharded and log_n == 20 and cv.curve_id == 0:
+    if os.path.exists(pmc_path) and not main_sharded and log_n == 20 and cv.curve_id == 0 and not args.no_precompute:
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pm = json.load(open(pmc_path))
+            traffic = pm.get("hbm_bytes_per_launch")
+            traffic_source = {"file": "profiles/pmc_msm_accumulate.json", "collected": pm.get("collected"), "commit": pm.get("commit"),
+                              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command on an earlier box; a "
+                                      "constant of the kernel build named in `commit`, not a counter of the run that printed this line"}
         except Exception:
             traffic = None
     msm_total_s = (acc_ms + sort_ms + red_ms) * 1e-3
     valu = None
-    if acc_n and not args.no_precompute and cv.curve_id == 0:
-        madds = 16.0 * r["points_per_launch"]               # one mixed addition per (16-bit window, point)
+    W = r["windows"]
+    if acc_n and W and cv.curve_id == 0:
+        madds = float(W) * r["points_per_launch"]             # one mixed addition per (window, point) on the table path
         mac_s = madds * MADD_MADS / avg_s
         peak_mac_s = LANES * CLOCK_HZ / MAD_CYCLES_FULL
         bound2 = LANES * CLOCK_HZ / MADD_CYCLES_2WAVES
-        valu = {"mixed_adds_per_s": madds / avg_s, "u32_mac_per_s": mac_s, "peak_u32_mac_per_s": peak_mac_s, "frac_of_mad_peak": mac_s / peak_mac_s,
+        valu = {"mixed_adds_per_scalar": W, "mixed_adds_per_s": madds / avg_s, "u32_mac_per_s": mac_s, "peak_u32_mac_per_s": peak_mac_s,
+                "frac_of_mad_peak": mac_s / peak_mac_s,
                 "issue_bound_mixed_adds_per_s_at_2_waves_per_simd": bound2, "frac_of_issue_bound": madds / avg_s / bound2}
     kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
     S = r["streams"]
@@ -301,21 +426,24 @@ def main():
     else:
         par = f"{world} replicas (one whole proof stream per GPU, no data-path collective)"
     line = {
-        "metric": "proofs/sec at 2^20 constraints (BLS12-381, KZG10); MSM G1-adds/s",
+        "metric": f"proofs/sec at 2^{log_n} constraints ({CURVE_TITLE[cv.name]}, KZG10); MSM G1-adds/s",
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if main_sharded else "weak",
         "vs_baseline": None, "dtype": "u32 limbs (256/384-bit Montgomery integers)", "data": "synthetic",
         "config": {"workload": f"per-proof hot path of Prover::prove at n=2^{log_n}: 13 ifft(n)+4 fft(n)+13 coset_fft(4n)+"
-                               f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident",
-                   "log_n": log_n, "curve": cv.name, "parallelism": par},
+                               f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident"
+                               + (", wire columns as BenchCircuit builds them (periodic {6,7,-20,1} rows + 3 blinding rows)" if args.data != "uniform" else ""),
+                   "log_n": log_n, "curve": cv.name, "parallelism": par, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_note": "each of the W digits of a scalar gathers its own 128-B row of the window table instead of re-deriving "
+                                     "2^(c w) P: HBM bytes traded for doublings, by design",
                      "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes,
                      "valu": valu},
         # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
         "msm_g1_adds_per_s": ((29 * kp * ark_adds(n, sbits)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
-                              if (msm_total_s and S == 1) else None),
+                              if (msm_total_s and S == 1 and not args.dedup) else None),
         "msm_ms_per_proof": msm_total_s / kp * 1e3,
         "ntt_GBps": (r["ntt_bytes"] * kp) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
         "ntt_ms_per_proof": ntt_ms / kp,
@@ -330,38 +458,77 @@ def main():
         line["config"]["workload"] += " + pointwise quotient on device"
         line["quotient_ms_per_proof"] = r["prof"]["quotient"][0] / kp
     if args.dedup:
-        line["config"]["workload"] += " -- WITH commitment de-duplication: 17 MSMs computed, 12 served from the per-proof cache"
-        line["msm_g1_adds_per_s"] = None
+        line["config"]["workload"] += f" -- WITH the commitment cache (zk_ctx_set_commit_cache): {r['msms_run']} MSMs computed per proof, the rest served from the cache"
     if S > 1:
         line["config"]["parallelism"] += f", {S} concurrent proof streams per GPU (kernel times below overlap other streams' work)"
     if args.check:
         line["commitments_sha256"] = r["digest"]
-    if world == 1 and S == 1 and args.streams_leg > 1:
-        # second leg, not part of `value`: the GPU's throughput with several proofs in flight (a proving service):
-        # small kernels of one proof fill the registers/issue slots the 2-waves/SIMD accumulate of another leaves idle
+
+    def leg(name, fn):
+        """an extra leg never takes the headline down; every rank agrees on its outcome first"""
         try:
+            res = fn()
+            ok = True
+        except Exception as e:
+            res, ok = {"error": repr(e)}, False
+        if not all_ok(ok) and ok:
+            res = {"error": "another rank failed this leg"}
+        line[name] = res
+
+    extra = args.extra_legs == "on" or (args.extra_legs == "auto" and log_n >= 16)
+    if world == 1 and S == 1 and args.streams_leg > 1:
+        # the GPU's throughput with several proofs in flight (a proving service): small kernels of one proof fill the
+        # registers/issue slots the 2-waves/SIMD accumulate of another leaves idle
+        def streams_leg():
             k2 = max(steps, 2 * args.streams_leg)
             r2 = timed_region(False, args.streams_leg, k2)
-            line["concurrent_streams"] = {"streams": r2["streams"], "steps": k2, "proofs_per_s": k2 / r2["dt"],
-                                          "ms_per_proof_aggregate": r2["dt"] / k2 * 1e3,
-                                          "commitments_match": (r2["digest"] == r["digest"]) if args.check else None}
-        except Exception as e:
-            line["concurrent_streams"] = {"error": repr(e)}
+            return {"streams": r2["streams"], "steps": k2, "proofs_per_s": k2 / r2["dt"], "ms_per_proof_aggregate": r2["dt"] / k2 * 1e3,
+                    "shared_srs": True, "commitments_match": (r2["digest"] == r["digest"]) if args.check else None}
+        leg("concurrent_streams", streams_leg)
+    if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
+        def drop_in_leg():
+            d = drop_in_region(max(2, min(steps, 3)))
+            d["commitments_match_resident"] = (d.pop("digest") == r["digest"]) if args.check else None
+            d["vs_resident"] = d["proofs_per_s"] / value
+            return d
+        leg("drop_in", drop_in_leg)
+        if not args.dedup:
+            def dedup_leg():
+                k2 = max(2, min(steps, 5))
+                r3 = timed_region(False, 1, k2, dedup="abi")
+                return {"proofs_per_s": k2 / r3["dt"], "ms_per_proof": r3["dt"] / k2 * 1e3, "msms_computed_per_proof": r3["msms_run"],
+                        "how": "zk_ctx_set_commit_cache(1): 256-bit device digest of every coefficient vector; prover.rs:569-607 re-commits 12 polynomials",
+                        "commitments_match": (r3["digest"] == r["digest"]) if args.check else None}
+            leg("dedup", dedup_leg)
+        if not args.no_precompute:
+            def nopre_leg():
+                k2 = max(2, min(steps, 3))
+                r4 = timed_region(False, 1, k2, precompute=False, warmup=1)
+                a_ms, a_n = r4["prof"]["msm_accumulate"]
+                return {"proofs_per_s": k2 / r4["dt"], "ms_per_proof": r4["dt"] / k2 * 1e3, "accumulate_avg_launch_ms": a_ms / max(a_n, 1),
+                        "path": "per-window buckets, host Horner; bases read once per window, no 128-B row gathers of a table",
+                        "commitments_match": (r4["digest"] == r["digest"]) if args.check else None}
+            leg("no_precompute", nopre_leg)
     if world > 1 and mode == "replica" and not args.no_sharded_leg:
-        # second leg, not part of `value`: the same proofs with every MSM point-sharded over the ranks
-        # (one RCCL all-gather of Jacobian partials per prover round) -- single-proof latency
-        try:
-            rs = timed_region(True)
-            sa_ms, sa_n = rs["prof"]["msm_accumulate"]
-            line["msm_sharded"] = {
-                "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
-                "speedup_vs_one_gpu_replica": (dt / steps) / (rs["dt"] / steps),
-                "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (11 per proof)",
-                "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
-                "commitments_match_replicas": (rs["digest"] == r["digest"]) if args.check else None,
-            }
-        except Exception as e:  # the headline above stands on its own
-            line["msm_sharded"] = {"error": repr(e)}
+        # the same proofs with every MSM point-sharded over the ranks (one RCCL all-gather of Jacobian partials per
+        # prover round) -- single-proof latency
+        def shard_leg(lg):
+            def run():
+                rs = timed_region(True, log_n=lg)
+                sa_ms, sa_n = rs["prof"]["msm_accumulate"]
+                d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
+                     "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (11 per proof)",
+                     "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
+                     "commitments_sha256": rs["digest"]}
+                if lg == log_n:
+                    d["speedup_vs_one_gpu_replica"] = (dt / steps) / (rs["dt"] / steps)
+                    d["commitments_match_replicas"] = (rs["digest"] == r["digest"]) if args.check else None
+                return d
+            return run
+        leg("msm_sharded", shard_leg(log_n))
+        n22 = args.sharded_n22_leg == "on" or (args.sharded_n22_leg == "auto" and log_n == 20 and cv.curve_id == 0)
+        if n22 and log_n != 22:
+            leg("msm_sharded_n22", shard_leg(22))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

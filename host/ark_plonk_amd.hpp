@@ -146,9 +146,14 @@ struct VariableBaseMSM {
 // device-resident powers_of_g (PC::trim output) + KZG10::commit
 class CommitterKey {
   public:
-    CommitterKey(Context& ctx, const std::vector<uint64_t>& powers_of_g, int curve = ZK_CURVE_BLS12_381) : ctx_(&ctx), curve_(curve) {
-        check(zk_srs_register(ctx.handle(), curve, powers_of_g.data(), nullptr, powers_of_g.size() / (2 * fq_limbs(curve)), &h_),
-              "zk_srs_register");
+    // PC::trim: content-addressed -- a second key over the same bases (circuit.rs:276 trims on every gen_proof) shares the
+    // resident device copy and window table.  infinity: optional per-point flags; (0, 1) and (0, 0) are infinity too.
+    CommitterKey(Context& ctx, const std::vector<uint64_t>& powers_of_g, int curve = ZK_CURVE_BLS12_381,
+                 const std::vector<uint8_t>* infinity = nullptr)
+        : ctx_(&ctx), curve_(curve) {
+        const size_t n = powers_of_g.size() / (2 * fq_limbs(curve));
+        if (infinity && infinity->size() != n) throw Error(ZK_ERR_BAD_ARG, "infinity flags length");
+        check(zk_srs_register(ctx.handle(), curve, powers_of_g.data(), infinity ? infinity->data() : nullptr, n, &h_), "zk_srs_register");
     }
     ~CommitterKey() { zk_srs_free(h_); }
     CommitterKey(const CommitterKey&) = delete;
@@ -169,6 +174,26 @@ class CommitterKey {
         std::vector<uint64_t> xy((size_t)k * 2 * L);
         std::vector<uint8_t> inf(k ? k : 1);
         check(zk_kzg_round_batch_dev(ctx_->handle(), h_, k, ptrs.data(), lens.data(), nullptr, xy.data(), inf.data()), "zk_kzg_round_batch_dev");
+        std::vector<G1Affine> out(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
+            out[i].infinity = inf[i] != 0;
+        }
+        return out;
+    }
+    // PC::commit(ck, polys, None) with host coefficient vectors (prover.rs:213,579,606): uploads overlap the MSMs
+    std::vector<G1Affine> commit(const std::vector<const std::vector<uint64_t>*>& polys) const {
+        const int L = fq_limbs(curve_);
+        const uint32_t k = (uint32_t)polys.size();
+        std::vector<const uint64_t*> ptrs(k);
+        std::vector<size_t> lens(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            ptrs[i] = polys[i]->data();
+            lens[i] = polys[i]->size() / 4;
+        }
+        std::vector<uint64_t> xy((size_t)k * 2 * L);
+        std::vector<uint8_t> inf(k ? k : 1);
+        check(zk_kzg_commit_batch(ctx_->handle(), h_, k, ptrs.data(), lens.data(), xy.data(), inf.data()), "zk_kzg_commit_batch");
         std::vector<G1Affine> out(k);
         for (uint32_t i = 0; i < k; ++i) {
             out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
@@ -209,6 +234,7 @@ inline DeviceVec permutation_evals(const Radix2EvaluationDomain& d, const Device
 // compute_lookup_permutation_poly up to its ifft (permutation/mod.rs:754-797)
 inline DeviceVec lookup_permutation_evals(Context& ctx, int curve, const DeviceVec& f, const DeviceVec& t, const DeviceVec& h1,
                                           const DeviceVec& h2, const uint64_t* delta_mont, const uint64_t* epsilon_mont) {
+    if (t.size() != f.size() || h1.size() != f.size() || h2.size() != f.size()) throw Error(ZK_ERR_BAD_ARG, "column length");   // mod.rs:764-767 asserts
     DeviceVec out(ctx, f.size());
     check(zk_lookup_product_dev(ctx.handle(), curve, f.size(), f.data(), t.data(), h1.data(), h2.data(), delta_mont, epsilon_mont, out.data(),
                                 nullptr),

@@ -10,15 +10,23 @@
  *   Fr element  : 4 x uint64 little-endian limbs, Montgomery form (value * 2^256 mod r), < r.
  *   Fr scalar   : 4 x uint64 little-endian limbs, canonical integer (PrimeField::into_repr), < r.
  *   Fq element  : L x uint64 limbs (L = 6 BLS12-381, 4 BN254), Montgomery form (R = 2^(64L)).
- *   G1 affine   : x || y (2L limbs, packed); infinity carried in a separate uint8 flag array
- *                 (arkworks' GroupAffine is not repr(C): the shim copies x, y, infinity).
- *   Output point: affine x || y Montgomery; infinity is (0, 1) + flag 1, as GroupAffine::zero().
+ *   G1 affine   : x || y (2L limbs, packed) (arkworks' GroupAffine is not repr(C): the shim copies x, y, infinity).
+ *                 The point at infinity is accepted in three encodings: inf_flags[i] != 0 (x, y ignored),
+ *                 x = y = 0, and GroupAffine::zero() = (0, 1) with 1 in Montgomery form.  (0, 1) is on neither
+ *                 supported curve, so no finite point is lost.
+ *   Output point: affine x || y Montgomery; infinity is (0, 1) + flag 1, as GroupAffine::zero() -- an output may be
+ *                 fed back as a base with or without its flag.
  *
  * Ownership: the caller owns every buffer; nothing is retained after return except the device
  * copy held by a zk_srs handle.  Errors: 0 = success, negative = failure (never aborts, never
- * throws).  Threading: calls on one ctx are serialised internally; one HIP stream per ctx.
- * One ctx drives one GPU (one process per GPU; multi-GPU MSM = one ctx per rank + an
- * all-gather of zk_msm_g1_*_partial outputs).
+ * throws).  Threading: calls on one ctx are serialised internally; one HIP stream per ctx, and the stream is ctx
+ * state (zk_ctx_set_stream), so threads that want different streams use one ctx each -- ctxs are cheap and share
+ * SRS handles.  One ctx drives one GPU: zk_ctx_create(int device) instead of SURVEY.md 8b's
+ * (const int* devices, int n_dev) -- one process per GPU; multi-GPU MSM = one ctx per rank + an all-gather of
+ * zk_msm_g1_*_partial outputs, see INTEGRATION.md.
+ * Host-pointer entry points (zk_ntt, zk_kzg_commit(_batch), zk_kzg_open, zk_msm_g1(_srs), zk_srs_register) accept
+ * ordinary pageable memory; transfers go through a pinned staging ring (pinned / hipHostRegister-ed buffers are
+ * sent directly); zk_io_stats reports the bytes moved.
  */
 #ifndef ARK_PLONK_AMD_H
 #define ARK_PLONK_AMD_H
@@ -66,8 +74,12 @@ int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
 int zk_ctx_use_own_stream(zk_ctx* ctx);
 /* Block until all queued work of this ctx is complete. */
 int zk_ctx_sync(zk_ctx* ctx);
-/* Override the MSM window size c (0 = automatic). Test/tuning hook. */
+/* Override the MSM window size c of the per-window path (0 = automatic, else 2..16). Test/tuning hook. */
 int zk_ctx_set_msm_window(zk_ctx* ctx, int c);
+/* Host<->device bytes moved by the host-pointer entry points of this ctx since creation / the last reset. */
+int zk_io_stats(zk_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset);
+/* 1 (default): pageable host buffers go through the ctx's pinned staging ring; 0: plain hipMemcpyAsync. Tuning hook. */
+int zk_ctx_set_staging(zk_ctx* ctx, int mode);
 
 /* Per-kernel HIP-event timing (bench.py roofline leg). When enabled every launch of the hot
  * kernels is bracketed by hipEventRecord on the ctx stream. */
@@ -117,15 +129,26 @@ int zk_fr_to_mont_dev(zk_ctx* ctx, int curve_id, const void* d_in, size_t n, voi
 int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags,
               const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
 
-/* Device-resident SRS (CommitterKey::powers_of_g after PC::trim, circuit.rs:236,276). */
+/* Device-resident SRS (CommitterKey::powers_of_g after PC::trim, circuit.rs:236,276).
+ * A zk_srs belongs to the DEVICE of the registering ctx: every ctx of that device may use it (several proof streams
+ * share one copy of the bases and of the window table).  It may outlive the ctx that registered it.
+ * zk_srs_register is content-addressed: the reference trims on every gen_proof (circuit.rs:276), so registering
+ * the same (curve, n, bases, flags) again returns the resident handle -- window table included -- after one pass of a
+ * 256-bit digest over the host bytes, with no upload.  Handles are reference counted: call zk_srs_free once per
+ * successful register.  An unreferenced cached SRS stays resident until zk_srs_cache_config's idle budget (default
+ * 32 GiB) is exceeded, least recently used first.  zk_srs_register_dev (bases already on the device; d_inf_flags may
+ * be NULL) is never cached. */
 int zk_srs_register(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out);
-int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, size_t n, zk_srs** out);
-/* Optional: build the table of window multiples 2^(16 w) * P_i (w = 1..15) for this SRS, 16x its
- * size in HBM (2 GiB per 2^20 BLS12-381 points; the card has 288 GB).  MSMs over the SRS then use a
- * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged. */
+int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const uint8_t* d_inf_flags, size_t n, zk_srs** out);
+/* Optional: build the table of window multiples 2^(c w) * P_i (w = 1..W-1) for this SRS, W x its
+ * size in HBM (2 GiB per 2^20 BLS12-381 points at c = 16; the card has 288 GB).  MSMs over the SRS then use a
+ * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged.  Idempotent. */
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 void zk_srs_free(zk_srs* srs);
 size_t zk_srs_len(const zk_srs* srs);
+/* SRS cache: bytes of unreferenced entries kept resident (0 = free on last zk_srs_free) / counters. */
+int zk_srs_cache_config(size_t max_idle_bytes);
+int zk_srs_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* resident_bytes);
 
 /* MSM over srs[base_offset .. base_offset+n) with host / device canonical scalars. */
 int zk_msm_g1_srs(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const uint64_t* scalars, size_t n,
@@ -147,6 +170,21 @@ int zk_g1_sum_partials_batch(int curve_id, const uint64_t* partials_xyz, size_t 
  * srs[0..n) (leading zero coefficients contribute nothing, as kzg10::commit's stripping). */
 int zk_kzg_commit_dev(zk_ctx* ctx, zk_srs* srs, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
 int zk_kzg_commit(zk_ctx* ctx, zk_srs* srs, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* PC::commit(ck, polys, None) with the caller's host slices -- the call GpuKZG10::commit forwards its whole
+ * `polys` iterator to (prover.rs:213 passes 4 polynomials, :579 and :606 seven; n_polys <= 16).  Polynomial k+1 is
+ * uploaded while polynomial k's MSM runs; results equal n_polys calls of zk_kzg_commit. */
+int zk_kzg_commit_batch(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const uint64_t* const* coeffs_mont, const size_t* lens,
+                        uint64_t* out_xy, uint8_t* out_inf);
+
+/* N3: opt-in, per-ctx, content-addressed commitment cache.  The reference commits twelve polynomials
+ * a second time in its last round (prover.rs:569-607: aw_polys / saw_polys repeat sigma_1..3, f, h_2, table, z, w_l,
+ * w_r, w_4, h_1, z_2).  With the cache on, every zk_kzg_commit* / zk_kzg_*_batch* call that returns affine points
+ * first computes a 256-bit digest of each coefficient vector on the device and serves (srs, input kind, length,
+ * digest) hits from the cache: an unchanged Prover::prove runs 17 MSMs per proof instead of 29 (20 on the first: the
+ * prover key's sigma commitments then stay cached across proofs), outputs identical.  capacity = entries kept
+ * (0 = leave unchanged; default 64, least recently used dropped). */
+int zk_ctx_set_commit_cache(zk_ctx* ctx, int enable, uint32_t capacity);
+int zk_commit_cache_stats(zk_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* entries);
 
 /* The commitments of one prover round (e.g. the 4 wire commits of prover.rs:213, the 7 + 7 of
  * prover.rs:569-607): n_polys (<= 16) device-resident coefficient vectors over one precomputed SRS.
@@ -177,6 +215,10 @@ int zk_kzg_round_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, co
  * polys: n_polys device pointers to Montgomery coefficient vectors of lens[k] elements. */
 int zk_kzg_open_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                     const uint64_t* z_mont, const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf);
+
+/* Same with the caller's host slices (n_polys <= 16), as PC::open receives them. */
+int zk_kzg_open(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const uint64_t* const* polys_mont, const size_t* lens,
+                const uint64_t* z_mont, const uint64_t* challenge_mont, uint64_t* out_xy, uint8_t* out_inf);
 
 /* Only the CPU-side part of PC::open: writes the witness polynomial's max(len)-1 coefficients as
  * canonical scalars into d_out (device, max(len) x 4 limbs) and their count into *out_len; the caller
@@ -224,6 +266,65 @@ typedef struct zk_quotient_args {
 } zk_quotient_args;
 /* n = 2^log_n is the circuit domain size; vectors hold 4n elements.  d_out (4n elements) must not alias an input. */
 int zk_quotient_evals_dev(zk_ctx* ctx, int curve_id, uint32_t log_n, const zk_quotient_args* args, void* d_out);
+
+/* ---- N4: canonical wire formats and the transcript (host only, no GPU needed) ------------------ */
+/* ark-serialize 0.3 CanonicalSerialize, as the reference applies it in transcript.rs:27-33 (`append`) and through the
+ * derives on proof.rs:41-103 / linearisation_poly.rs:34-161 / widget/mod.rs:252-278:
+ *   Fr        : zk_fr_serialized_size bytes (32), little-endian canonical (non-Montgomery) integer.
+ *   G1Affine  : compressed = x as little-endian canonical integer in zk_g1_compressed_size bytes (48 BLS12-381,
+ *               32 BN254) with SWFlags in the top bits of the LAST byte: 0x80 = y is the larger of (y, p - y),
+ *               0x40 = infinity (x = 0).  Uncompressed = x then y (2 x that size), the infinity flag on y.
+ * Deserialisation validates like ark: integer < modulus, point on the curve and in the prime-order subgroup, flag
+ * combinations; any violation is ZK_ERR_BAD_ARG.  Field elements cross this API in Montgomery form as everywhere. */
+size_t zk_fr_serialized_size(int curve_id);
+size_t zk_g1_compressed_size(int curve_id);
+int zk_fr_serialize(int curve_id, const uint64_t* fr_mont, uint8_t* out);
+int zk_fr_deserialize(int curve_id, const uint8_t* in, uint64_t* fr_mont);
+int zk_g1_serialize_compressed(int curve_id, const uint64_t* xy_mont, uint8_t inf, uint8_t* out);
+int zk_g1_deserialize_compressed(int curve_id, const uint8_t* in, uint64_t* xy_mont, uint8_t* inf);
+int zk_g1_serialize_uncompressed(int curve_id, const uint64_t* xy_mont, uint8_t inf, uint8_t* out);
+int zk_g1_deserialize_uncompressed(int curve_id, const uint8_t* in, uint64_t* xy_mont, uint8_t* inf);
+
+/* merlin 3.0 `Transcript` (STROBE-128 / Keccak-f[1600]) -- prover.rs:179 clones one and drives it through the proof. */
+typedef struct zk_transcript zk_transcript;
+zk_transcript* zk_transcript_new(const uint8_t* label, size_t label_len);            /* Transcript::new(label)   */
+zk_transcript* zk_transcript_clone(const zk_transcript* t);                          /* prover.rs:179            */
+void zk_transcript_free(zk_transcript* t);
+int zk_transcript_append_message(zk_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
+int zk_transcript_append_u64(zk_transcript* t, const uint8_t* label, size_t label_len, uint64_t v);
+int zk_transcript_challenge_bytes(zk_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+/* plonk-core's TranscriptProtocol (transcript.rs:16-49): append(label, item) for the two item types the prover appends
+ * (a commitment = compressed G1, prover.rs:217-220,294,320-321,366,472-475; a scalar, prover.rs:226,327-337,399-426,481,
+ * 516-553), challenge_scalar (31 challenge bytes as a little-endian integer, transcript.rs:35-46) and
+ * circuit_domain_sep (transcript.rs:45-48).  The order of labels over one proof is tabulated in INTEGRATION.md section 7
+ * and replayed by ark_plonk_amd/transcript.py::ProverTranscript. */
+int zk_transcript_append_fr(zk_transcript* t, int curve_id, const uint8_t* label, size_t label_len, const uint64_t* fr_mont);
+int zk_transcript_append_g1(zk_transcript* t, int curve_id, const uint8_t* label, size_t label_len, const uint64_t* xy_mont, uint8_t inf);
+int zk_transcript_challenge_scalar(zk_transcript* t, int curve_id, const uint8_t* label, size_t label_len, uint64_t* fr_mont);
+int zk_transcript_circuit_domain_sep(zk_transcript* t, uint64_t n);
+/* prover.rs:182 `transcript.append(b"pi", self.cs.get_pi())`: PublicInputs = BTreeMap<usize, F> (pi.rs:28-36), i.e. u64 count,
+ * then (u64 position, Fr) with strictly ascending positions (anything else is ZK_ERR_BAD_ARG). */
+int zk_transcript_append_public_inputs(zk_transcript* t, int curve_id, const uint8_t* label, size_t label_len, const uint64_t* positions,
+                                       const uint64_t* values_mont, size_t n);
+
+/* `Proof<F, PC>` for PC = (Sonic)KZG10 (proof.rs:41-103): the serialised form is the fields in declaration order --
+ * 13 commitments a b c d z f h_1 h_2 z_2 t_1 t_2 t_3 t_4 (compressed G1 each), aw_opening and saw_opening
+ * (kzg10::Proof { w, random_v: None } = compressed G1 + one 0 byte), then ProofEvaluations (linearisation_poly.rs:34-161):
+ * a b c d | left_sigma right_sigma out_sigma permutation | q_lookup z2_next h1 h1_next h2 f table table_next as Fr,
+ * then custom_evals: u64 count, and per entry u64 label length + label bytes + Fr. */
+#define ZK_PROOF_N_EVALS 16
+typedef struct zk_proof {
+    const uint64_t* commitments;     /* 13 x 2L limbs, Montgomery affine, the order above */
+    const uint8_t* commitment_inf;   /* 13 flags */
+    const uint64_t* openings;        /* 2 x 2L limbs: aw_opening.w, saw_opening.w */
+    const uint8_t* opening_inf;      /* 2 flags */
+    const uint64_t* evals;           /* ZK_PROOF_N_EVALS x 4 limbs, Montgomery, the order above */
+    uint32_t n_custom_evals;
+    const char* const* custom_labels; /* NUL-terminated */
+    const uint64_t* custom_evals;    /* n_custom_evals x 4 limbs */
+} zk_proof;
+size_t zk_proof_serialized_size(int curve_id, uint32_t n_custom_evals, const uint32_t* label_lens);
+int zk_proof_serialize(int curve_id, const zk_proof* proof, uint8_t* out, size_t cap, size_t* written);
 
 /* ---- device self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the bucket-reduction kernels (csrc/ecq.cuh) against the

@@ -88,6 +88,8 @@ SYMBOLS = {
     "zk_kzg_open": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "zk_srs_precompute": (c_int, [c_void_p, c_void_p]),
+    "zk_srs_precompute_ex": (c_int, [c_void_p, c_void_p, c_u32]),
+    "zk_srs_table_info": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "zk_srs_free": (None, [c_void_p]),
     "zk_srs_len": (c_size_t, [c_void_p]),
     "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),

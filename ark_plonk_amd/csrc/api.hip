@@ -340,6 +340,7 @@ static std::atomic<uint64_t> g_srs_next_id{1};
 static size_t g_srs_idle_limit = (size_t)32 << 30;   // bytes of UNREFERENCED cached SRS (incl. window tables) kept resident
 static uint64_t g_srs_hits = 0, g_srs_misses = 0;
 
+typedef std::shared_lock<std::shared_mutex> SrsReadLock;
 static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_W ? s->pre_W : 1); }
 
 static void srs_destroy(zk_srs* s) {
@@ -462,13 +463,25 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
     return srs_register_host(c, curve_id, bases_xy, inf_flags, n, out, n != 0);
 }
 
-int zk_srs_precompute(zk_ctx* c, zk_srs* s) {
+int zk_srs_precompute_ex(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     if (!c || !s || s->device != c->device) return ZK_ERR_BAD_ARG;
+    if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     std::unique_lock<std::shared_mutex> wl(s->mu);   // no MSM of any ctx is reading or enqueueing on this SRS
-    if (s->pre_W || s->n == 0) return ZK_OK;
+    if (s->n == 0) return ZK_OK;
+    if (s->pre_W) return (window_bits == 0 || window_bits == s->pre_c) ? ZK_OK : ZK_ERR_UNSUPPORTED;   // one table per SRS
     ZK_HIP_TRY(hipDeviceSynchronize());               // ... and none it enqueued earlier is still running
-    return msm_precompute_dev(c, s);
+    return msm_precompute_dev(c, s, window_bits);
+}
+
+int zk_srs_precompute(zk_ctx* c, zk_srs* s) { return zk_srs_precompute_ex(c, s, 0); }
+
+int zk_srs_table_info(zk_srs* s, uint32_t* window_bits, uint32_t* windows) {
+    if (!s) return ZK_ERR_BAD_ARG;
+    SrsReadLock rl(s->mu);
+    if (window_bits) *window_bits = s->pre_c;
+    if (windows) *windows = s->pre_W;
+    return ZK_OK;
 }
 
 void zk_srs_free(zk_srs* s) {

@@ -162,9 +162,9 @@ struct DevBuf {
 };
 
 struct MsmBufs {
-    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, win, tmp, scalars, stage, upload;
+    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, seg3, win, tmp, scalars, stage, upload;
     void release() {
-        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &win, &tmp, &scalars, &stage, &upload};
+        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg3, &win, &tmp, &scalars, &stage, &upload};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -296,7 +296,7 @@ int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, voi
 int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);
 int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy);
 // window-multiples table of an SRS (see zk_srs::d_pre) and the MSM that uses it
-int msm_precompute_dev(zk_ctx* c, zk_srs* s);
+int msm_precompute_dev(zk_ctx* c, zk_srs* s, uint32_t window_bits /* 0 = default (16); 16 .. 21 */);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 // a batch of commitments over one SRS, queued back to back; the host blocks once per result
 // out_xy / out_inf (optional): also normalise every result to affine (n_polys x 2L limbs, n_polys flags)

@@ -579,6 +579,223 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, c
     }
 }
 
+
+// ---- the same partition sort for window tables with c > 16 (2^(c-1) shared buckets, c <= 21) ---------------------------
+// Still P = 256 partitions by the high 8 bucket bits; the low part grows to lob = c - 9 bits (128 ... 4096 buckets per
+// partition), so the digits are int32, the staged low bits uint16 and the LDS tables of the second pass are sized at
+// launch.  One scalar per lane in the digit kernel (a 4-byte store per window either way).
+template <class Fr, bool MONT>
+__global__ void __launch_bounds__(256) psortw_digits_hist(const uint32_t* scalars, uint64_t n, uint32_t sp, MsmGeom g, uint32_t lob, int32_t* dig,
+                                                          uint32_t* hist /* [256][PS_SLABS] */, uint32_t* scan_counter, uint32_t* combine_q) {
+    __shared__ uint32_t lc[256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scan_counter[0] = 0;
+        combine_q[0] = 0;
+        combine_q[1] = 0;
+    }
+    lc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;
+    const uint32_t half = 1u << (g.c - 1), cmask = (1u << g.c) - 1u;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * i;
+        uint4 a = q[0], b = q[1];
+        Fr x;
+        x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+        x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+        if (MONT) x = Fr::from_mont(x);
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < g.W; ++w) {
+            const uint32_t pos = w * g.c, limb = pos >> 5, off = pos & 31;
+            uint64_t lo64 = 0, hi64 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {      // register-resident limbs: select, do not index
+                if ((uint32_t)k == limb) lo64 = x.v[k];
+                if ((uint32_t)k == limb + 1) hi64 = x.v[k];
+            }
+            const uint32_t raw = ((uint32_t)(((hi64 << 32) | lo64) >> off) & cmask) + carry;
+            carry = raw >= half ? 1u : 0u;
+            const int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
+            dig[(uint64_t)w * n + i] = d;
+            if (d != 0) atomicAdd(&lc[(uint32_t)((d < 0 ? -d : d) - 1) >> lob], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * PS_SLABS + blockIdx.x] = lc[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t lob, const uint32_t* cursors,
+                                                       const uint32_t* part_start, uint32_t* stage_ref, uint16_t* stage_lo) {
+    constexpr uint32_t PER = PS_STILE / PS_T;
+    const uint32_t LOM = (1u << lob) - 1u;
+    __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
+    __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | partition << 15
+    __shared__ uint16_t rlo[PS_STILE];       // low bucket bits of the record at the same position
+    const uint32_t t = threadIdx.x;
+    if (t < 256) gcur[t] = part_start[t] + cursors[(uint64_t)t * PS_SLABS + blockIdx.x];
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;
+    const uint32_t len = (uint32_t)(hi - lo);
+    const uint32_t total_digits = W * len;
+    for (uint32_t base = 0; base < total_digits; base += PS_STILE) {
+        const uint32_t m = total_digits - base < PS_STILE ? total_digits - base : PS_STILE;
+        __syncthreads();
+        if (t < 256) cnt[t] = 0;
+        __syncthreads();
+        uint32_t pk[PER];
+        uint16_t pl[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            pk[k] = 0xffffffffu;
+            pl[k] = 0;
+            if (i < m) {
+                const uint32_t q = base + i, w = q / len, ii = q - w * len;
+                const int32_t d = dig[(uint64_t)w * n + lo + ii];
+                if (d != 0) {
+                    const uint32_t neg = d < 0 ? 1u : 0u;
+                    const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
+                    pk[k] = i | (neg << 14) | ((b >> lob) << 15);
+                    pl[k] = (uint16_t)(b & LOM);
+                    atomicAdd(&cnt[b >> lob], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t c = t < 256 ? cnt[t] : 0u;
+            const uint32_t ex = scan256_excl(c, t, stmp);
+            if (t < 256) toff[t] = ex;
+            if (t == 255) toff[256] = ex + c;
+        }
+        __syncthreads();
+        if (t < 256) cnt[t] = toff[t];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k)
+            if (pk[k] != 0xffffffffu) {
+                const uint32_t at = atomicAdd(&cnt[pk[k] >> 15], 1u);
+                rec[at] = pk[k];
+                rlo[at] = pl[k];
+            }
+        __syncthreads();
+        const uint32_t total = toff[256];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t qq = k * PS_T + t;
+            if (qq < total) {
+                const uint32_t r = rec[qq];
+                const uint32_t pp = r >> 15;
+                const uint32_t q = base + (r & 0x3fffu), w = q / len, ii = q - w * len;
+                const uint32_t ref = (w << 26) | (uint32_t)(lo + ii) | (((r >> 14) & 1u) << 31);
+                const uint32_t dst = gcur[pp] + (qq - toff[pp]);
+                stage_ref[dst] = ref;
+                stage_lo[dst] = rlo[qq];
+            }
+        }
+        __syncthreads();
+        if (t < 256) gcur[t] += toff[t + 1] - toff[t];
+    }
+}
+
+// exclusive scan of one value per lane over a 1024-lane workgroup; tmp: 16 LDS words
+ZK_D uint32_t scan1024_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((t & 63) >= d) inc += o;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) tmp[t >> 6] = inc;
+    __syncthreads();
+    uint32_t add = 0;
+    for (uint32_t w = 0; w < (t >> 6); ++w) add += tmp[w];
+    return inc + add - v;
+}
+
+// one workgroup per partition, NB = 2^lob buckets; dynamic LDS: cnt[NB] | cur[NB] | toff[NB + 1] | tmp[16] | sorted[PS_TILE] | skey[PS_TILE] (u16)
+__global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, const uint16_t* stage_lo, const uint32_t* part_start, uint32_t P,
+                                                     uint32_t lob, uint32_t* entries, uint32_t* offsets) {
+    extern __shared__ uint32_t lds[];
+    constexpr uint32_t PER = PS_TILE / PS_T;
+    const uint32_t NB = 1u << lob;
+    const uint32_t K = NB > PS_T ? NB / PS_T : 1u;       // counters per lane in the scans
+    uint32_t* cnt = lds;
+    uint32_t* cur = cnt + NB;
+    uint32_t* toff = cur + NB;
+    uint32_t* tmp = toff + NB + 1;
+    uint32_t* sorted = tmp + 16;
+    uint16_t* skey = reinterpret_cast<uint16_t*>(sorted + PS_TILE);
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t s = part_start[p], e = part_start[p + 1];
+    for (uint32_t j = t; j < NB; j += PS_T) cnt[j] = 0;
+    __syncthreads();
+    for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage_lo[i]], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0 .. NB): lane t owns counters [t*K, (t+1)*K)
+    auto scan_counts = [&](uint32_t* dst, uint32_t add, bool with_total) {
+        uint32_t mine = 0;
+        if (t * K < NB)
+            for (uint32_t k = 0; k < K; ++k) mine += cnt[t * K + k];
+        uint32_t ex = scan1024_excl(mine, t, tmp);
+        if (t * K < NB) {
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t c = cnt[t * K + k];
+                dst[t * K + k] = add + ex;
+                ex += c;
+            }
+            if (with_total && (t + 1) * K == NB) dst[NB] = add + ex;
+        }
+        __syncthreads();
+    };
+    scan_counts(cur, s, false);
+    for (uint32_t j = t; j < NB; j += PS_T) offsets[p * NB + j] = cur[j];
+    if (p == P - 1 && t == 0) offsets[P * NB] = e;
+    for (uint32_t base = s; base < e; base += PS_TILE) {
+        const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;
+        __syncthreads();
+        for (uint32_t j = t; j < NB; j += PS_T) cnt[j] = 0;
+        __syncthreads();
+        uint32_t vr[PER];
+        uint16_t vk[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                vr[k] = stage_ref[base + i];
+                vk[k] = stage_lo[base + i];
+                atomicAdd(&cnt[vk[k]], 1u);
+            }
+        }
+        __syncthreads();
+        scan_counts(toff, 0u, true);
+        for (uint32_t j = t; j < NB; j += PS_T) cnt[j] = toff[j];      // running position inside the tile
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                const uint32_t q = atomicAdd(&cnt[vk[k]], 1u);
+                sorted[q] = vr[k];
+                skey[q] = vk[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                const uint32_t j = skey[i];
+                entries[cur[j] + (i - toff[j])] = sorted[i];
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = t; j < NB; j += PS_T) cur[j] += toff[j + 1] - toff[j];
+    }
+}
+
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
 // PRE: references carry a window number and `bases` is the window-multiples table [W][n_srs]
 // (row w holds 2^(c w) P_i); tab_stride = n_srs, tab_off = base_offset.
@@ -646,16 +863,17 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
 // The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by
 // ONE launch of each kernel, so the latency of the dependent-addition chains is paid once per round.
 constexpr int MAX_JOBS = 16;
+constexpr int MAX_RJOBS = 32;     // the last level of the wide reduction reduces two arrays (S_v, T_v) per job
 struct RJobs {
-    const void* part_pt[MAX_JOBS];
-    const uint32_t* offsets[MAX_JOBS];
-    void* buckets[MAX_JOBS];
-    uint32_t* q[MAX_JOBS];
-    void* seg_run[MAX_JOBS];
-    void* seg_acc[MAX_JOBS];
-    uint32_t* win_s[MAX_JOBS];
-    uint32_t* win_t[MAX_JOBS];
-    uint32_t L[MAX_JOBS];
+    const void* part_pt[MAX_RJOBS];
+    const uint32_t* offsets[MAX_RJOBS];     // nullptr: every bucket is present (levels above the first)
+    void* buckets[MAX_RJOBS];
+    uint32_t* q[MAX_RJOBS];
+    void* seg_run[MAX_RJOBS];
+    void* seg_acc[MAX_RJOBS];
+    uint32_t* win_s[MAX_RJOBS];
+    uint32_t* win_t[MAX_RJOBS];
+    uint32_t L[MAX_RJOBS];
 };
 
 constexpr uint32_t COMBINE_SMALL = 32;     // buckets spanning <= this many chunks: summed by one lane
@@ -799,7 +1017,7 @@ __global__ void __launch_bounds__(128) msm_seg_reduce(RJobs jobs, MsmGeom g) {
     XYZZu<F> run = XYZZu<F>::infinity(), acc = XYZZu<F>::infinity();
     for (int i = (int)G - 1; i >= 0; --i) {
         const uint32_t bi = w * g.B + s * G + (uint32_t)i;
-        if (offsets[bi + 1] != offsets[bi]) run = XYZZu<F>::add(run, ld_xyzz<F>(buckets, bi));
+        if (!offsets || offsets[bi + 1] != offsets[bi]) run = XYZZu<F>::add(run, ld_xyzz<F>(buckets, bi));
         acc = XYZZu<F>::add(acc, run);
     }
     st_xyzz<F>(seg_run, id, run);
@@ -949,7 +1167,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     for (int i = (int)G - 1; i >= 0; --i) {
         const uint32_t bi = w * g.B + sg * G + (uint32_t)i;
         F v = F::zero();
-        if (live && offsets[bi + 1] != offsets[bi]) v = ld_coord<F>(buckets, bi, role);
+        if (live && (!offsets || offsets[bi + 1] != offsets[bi])) v = ld_coord<F>(buckets, bi, role);
         run = qadd<F>(run, v, role);
         acc = qadd<F>(acc, run, role);
     }
@@ -961,7 +1179,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 
 // msm_win_finish for logq == 0 (one segment per chain): 4 * ns lanes per workgroup, ns <= 256
 template <class F>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_win_finish_q(RJobs jobs, MsmGeom g) {
+// raw != 0: the two sums stay on the device in the internal point form (the "buckets" of the next reduction level);
+// raw == 0: arkworks layout for the host, as msm_win_finish.
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_win_finish_q(RJobs jobs, MsmGeom g, uint32_t raw) {
     extern __shared__ uint4 sh[];
     const void* seg_run = jobs.seg_run[blockIdx.y];
     const void* seg_acc = jobs.seg_acc[blockIdx.y];
@@ -986,11 +1206,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     const bool r_inf = quad_is_inf(R, role);
     if (tot_out && u == 0) {
-        uint32_t* o = tot_out + (size_t)w * 4 * F::SAT + role * F::SAT;
-        if (r_inf) {
-            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        if (raw) {
+            st_coord<F>(tot_out, w, role, r_inf ? F::zero() : R);
         } else {
-            R.to_sat(o);
+            uint32_t* o = tot_out + (size_t)w * 4 * F::SAT + role * F::SAT;
+            if (r_inf) {
+                for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+            } else {
+                R.to_sat(o);
+            }
         }
     }
     // Z = Y + G * Q_u   (u >= 1)
@@ -1008,11 +1232,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     const bool z_inf = quad_is_inf(Z, role);
     if (u == 0) {
-        uint32_t* o = win_out + (size_t)w * 4 * F::SAT + role * F::SAT;
-        if (z_inf) {
-            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        if (raw) {
+            st_coord<F>(win_out, w, role, z_inf ? F::zero() : Z);
         } else {
-            Z.to_sat(o);
+            uint32_t* o = win_out + (size_t)w * 4 * F::SAT + role * F::SAT;
+            if (z_inf) {
+                for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+            } else {
+                Z.to_sat(o);
+            }
         }
     }
 }
@@ -1110,7 +1338,7 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
         size_t shmem = (size_t)chains * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(gr.W, n_jobs), dim3(4 * chains), shmem, st, jobs, gr);
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(gr.W, n_jobs), dim3(4 * chains), shmem, st, jobs, gr, 0u);
     } else {
         unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
@@ -1118,6 +1346,85 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(msm_win_finish<F>, dim3(gr.W, n_jobs), dim3(256), shmem, st, jobs, gr);
+    }
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// Reduction for window tables with c > 16 (nb = 2^(c-1) >= 2^16 shared buckets), all on the device:
+//   level 1  msm_seg_reduce      one LANE per segment of 4 buckets: with >= 16 Ki segments per job the launch is throughput-bound,
+//                                where the single-lane group law costs 13.5 product-times per addition against the quad form's 18
+//   level 2  msm_win_finish_q    VW = nb / 512 virtual windows of 128 chains -> S_v = sum_l (l+1) B_{v,l},  T_v = sum_l B_{v,l}, kept on the
+//                                device in the internal point form
+//   level 3  msm_seg_reduce_q + msm_win_finish_q over the two arrays S and T of every job (2 n_jobs "jobs", every element present):
+//                                sum_v S_v,  K = sum_v (v+1) T_v,  sum_v T_v  -> pinned host memory, arkworks layout
+//   host     total = sum_v S_v + 512 * (K - sum_v T_v)      (bucket j = 512 v + l has weight j + 1)
+template <class F>
+int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, void* const* d_vw, void* const* d_seg3,
+                      char* h_out, size_t h_stride, hipStream_t st) {
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    ProfScope ps(c, "msm_reduce", st);
+    const uint32_t VW = gr.W;
+    {   // chunk-edge partials -> buckets (queues cleared by the job's sort)
+        const int T = 128;
+        if (n_jobs <= 2) {
+            unsigned blocks = (unsigned)(((uint64_t)nb * 4 + 255) / 256);
+            hipLaunchKernelGGL(msm_combine_q<F>, dim3(blocks, n_jobs), dim3(256), 0, st, jobs, nb);
+        } else {
+            unsigned blocks = (unsigned)(((uint64_t)nb + T - 1) / T);
+            hipLaunchKernelGGL((msm_combine<F, 1>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
+        }
+        hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
+        hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);
+    }
+    {   // level 1
+        const int T = 128;
+        unsigned sblocks = (unsigned)(((uint64_t)gr.W * gr.ns + T - 1) / T);
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
+    }
+    RJobs j2 = jobs;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        j2.win_s[k] = (uint32_t*)d_vw[k];
+        j2.win_t[k] = (uint32_t*)((char*)d_vw[k] + (size_t)VW * PT);
+    }
+    {   // level 2: 128 chains per virtual window
+        uint32_t chains = 1;
+        while (chains < gr.ns) chains <<= 1;
+        size_t shmem = (size_t)chains * PT;
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(VW, n_jobs), dim3(4 * chains), shmem, st, j2, gr, 1u);
+    }
+    MsmGeom g3 = gr;
+    g3.W = 1;
+    g3.B = VW;
+    g3.nb = VW;
+    g3.logG = VW <= 1024 ? 2 : 3;
+    g3.ns = VW >> g3.logG;
+    g3.logq = 0;
+    if (g3.ns == 0 || g3.ns > 256) return ZK_ERR_UNSUPPORTED;
+    RJobs j3;
+    memset(&j3, 0, sizeof j3);
+    const size_t PHB = h_stride / 4;      // bytes of one host point
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        for (uint32_t a = 0; a < 2; ++a) {
+            const uint32_t j = 2 * k + a;
+            j3.buckets[j] = (char*)d_vw[k] + (size_t)a * VW * PT;
+            j3.offsets[j] = nullptr;
+            j3.seg_run[j] = (char*)d_seg3[k] + (size_t)a * 2 * g3.ns * PT;
+            j3.seg_acc[j] = (char*)d_seg3[k] + ((size_t)a * 2 + 1) * g3.ns * PT;
+            j3.win_s[j] = (uint32_t*)(h_out + (size_t)k * h_stride + (size_t)a * 2 * PHB);
+            j3.win_t[j] = (uint32_t*)(h_out + (size_t)k * h_stride + ((size_t)a * 2 + 1) * PHB);
+        }
+    {
+        unsigned sblocks = (unsigned)(((uint64_t)g3.ns * 4 + 255) / 256);
+        hipLaunchKernelGGL(msm_seg_reduce_q<F>, dim3(sblocks, 2 * n_jobs), dim3(256), 0, st, j3, g3);
+        uint32_t chains = 1;
+        while (chains < g3.ns) chains <<= 1;
+        size_t shmem = (size_t)chains * PT;
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(1, 2 * n_jobs), dim3(4 * chains), shmem, st, j3, g3, 0u);
     }
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
@@ -1143,7 +1450,7 @@ uint32_t modulus_minus_one_bits(uint32_t shift) {
 }
 
 template <class FrP>
-MsmGeom make_geom(uint64_t n, int c_override) {
+MsmGeom make_geom(uint64_t n, int c_override, uint32_t max_c = 16) {
     const int bits = FrP::BITS;
     MsmGeom g;
     uint32_t c;
@@ -1156,7 +1463,7 @@ MsmGeom make_geom(uint64_t n, int c_override) {
         if (c > 16) c = 16;
     }
     if (c < 2) c = 2;
-    if (c > 16) c = 16;   // digits are stored as int16 and a window's histogram lives in LDS
+    if (c > max_c) c = max_c;   // per-window path: digits are stored as int16 and a window's histogram lives in LDS (16)
     g.c = c;
     g.W = (uint32_t)bits / c + 1;
     // the last window must never produce a carry: its largest raw value (top bits of r-1, plus the
@@ -1310,16 +1617,19 @@ __global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, u
     }
 }
 
-constexpr uint32_t PRE_C = 16;        // window of the precomputed table (largest the LDS sort handles)
+constexpr uint32_t PRE_C = 16;        // default window of the precomputed table
+constexpr uint32_t PRE_C_MAX = 21;    // 2^20 shared buckets: 4096 per partition in the second sort pass (144 KiB of LDS)
 constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
 constexpr uint32_t PRE_Q_OFF = 1024;  // words of part_key in front of the combine queues (partition starts, totals, counter)
 constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket reduction: 128 chains x 4 lanes per workgroup
                                       // (256 registers per lane; with 32 windows the 1024-lane workgroup spilled at 128)
 
 template <class Cv>
-int msm_precompute_run(zk_ctx* c, zk_srs* s) {
+int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     typedef typename Cv::FqU F;
-    MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)PRE_C);
+    if (window_bits == 0) window_bits = PRE_C;
+    if (window_bits < PRE_C || window_bits > PRE_C_MAX) return ZK_ERR_BAD_ARG;
+    MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)window_bits, PRE_C_MAX);
     const size_t pb = s->point_bytes;
     void* tab = nullptr;
     if (hipMalloc(&tab, (size_t)g.W * s->n * pb) != hipSuccess) return ZK_ERR_OOM;
@@ -1354,6 +1664,7 @@ struct PrePlan {
     uint64_t nf;
     uint32_t chunk_l, n_lanes, S;
     size_t win_bytes;
+    bool wide;          // c > 16: int32 digits, 2^(c-9) buckets per sort partition, three-level device reduction
 };
 
 template <class Cv>
@@ -1363,16 +1674,17 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     typedef XYZZ<Fq> PH;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
-    pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c);
+    pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
+    pl.wide = pl.g.c > 16;
     pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
     if (pl.nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
     pl.g1 = pl.g;                                       // the sort sees ONE window of nf digits
     pl.g1.W = 1;
     pl.g1.nb = pl.g.B;
-    pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows
-    pl.gv.W = PRE_VW;
-    pl.gv.B = pl.g.B / PRE_VW;
+    pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows (wide: windows of 512 buckets)
+    pl.gv.W = pl.wide ? pl.g.B / 512 : PRE_VW;
+    pl.gv.B = pl.g.B / pl.gv.W;
     pl.gv.nb = pl.g.B;
     pl.gv.logG = 2;
     pl.gv.ns = pl.gv.B >> pl.gv.logG;
@@ -1384,20 +1696,29 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     // L = 128 / 64 / 32 / 16 -> 111.8 / 110.3 / 110.8 / 162 ms per proof; 16 overloads the combine)
     pl.chunk_l = PRE_CHUNK_L;
     while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 262144) pl.chunk_l >>= 1;
+    if (const char* e = getenv("ZK_CHUNK_L")) {          // tuning hook (profiles/r02_notes.md)
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 8 && v <= 1024) pl.chunk_l = v;
+    }
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
     pl.S = 1;
     while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;   // 256 / 512 slabs measured slower (scans grow)
-    pl.win_bytes = (size_t)2 * pl.gv.W * sizeof(PH);
+    pl.win_bytes = pl.wide ? (size_t)4 * sizeof(PH) : (size_t)2 * pl.gv.W * sizeof(PH);
     int rc;
-    if ((rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
+    if (!pl.wide && (rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
     if ((rc = mb.offsets.ensure((size_t)(pl.g.B + 1) * 4))) return rc;
-    if ((rc = mb.tmp.ensure((size_t)pl.nf * 2))) return rc;
+    if ((rc = mb.tmp.ensure((size_t)pl.nf * (pl.wide ? 4 : 2)))) return rc;
     if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
     if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
     if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
     if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
-    if ((rc = mb.win.ensure(pl.win_bytes))) return rc;
+    if (pl.wide) {
+        if ((rc = mb.win.ensure((size_t)2 * pl.gv.W * PT))) return rc;     // S_v | T_v of the virtual windows, internal form
+        if ((rc = mb.seg3.ensure((size_t)4 * 256 * PT))) return rc;         // level 3: (run, acc) of <= 256 segments for each of S, T
+    } else if ((rc = mb.win.ensure(pl.win_bytes))) {
+        return rc;
+    }
     return ZK_OK;
 }
 
@@ -1412,6 +1733,35 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
     typedef typename Cv::Fr FrS;
+    if (pl.wide) {
+        const uint32_t lob = pl.g.c - 9, P = 256;
+        const uint32_t sp = psort_slab_len(n);
+        uint32_t* part_start = (uint32_t*)mb.part_key.p;
+        uint32_t* part_total = part_start + P + 1;
+        uint32_t* scan_counter = part_total + P;
+        uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
+        int rc = mb.stage.ensure((size_t)pl.nf * 6);
+        if (rc) return rc;
+        if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
+        hist = (uint32_t*)mb.counts.p;
+        int32_t* dig32 = (int32_t*)mb.tmp.p;
+        if (mont) hipLaunchKernelGGL((psortw_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
+                                     lob, dig32, hist, scan_counter, combine_q);
+        else hipLaunchKernelGGL((psortw_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
+                                lob, dig32, hist, scan_counter, combine_q);
+        hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
+        uint32_t* stage_ref = (uint32_t*)mb.stage.p;
+        uint16_t* stage_lo = (uint16_t*)((char*)mb.stage.p + (size_t)pl.nf * 4);
+        hipLaunchKernelGGL(psortw_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, (const int32_t*)dig32, (uint64_t)n, pl.g.W, sp, lob, hist, part_start,
+                           stage_ref, stage_lo);
+        const uint32_t NB = 1u << lob;
+        const size_t lds = ((size_t)3 * NB + 1 + 16 + PS_TILE) * 4 + (size_t)PS_TILE * 2;
+        ZK_HIP_TRY(hipFuncSetAttribute((const void*)psortw_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(psortw_final, dim3(P), dim3(PS_T), lds, st, (const uint32_t*)stage_ref, (const uint16_t*)stage_lo, part_start, P, lob, entries,
+                           offsets);
+        ZK_HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
     const bool psort = pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256;   // two-pass partition sort
     const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16;                     // two scalars per lane
     const uint32_t P = pl.g1.nb >> PS_LOB;
@@ -1512,7 +1862,37 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         jobs.L[k] = pls[k].chunk_l;
     }
     // the queue counters were cleared by the job's sort (psort_hist / the memset of the fallback sort)
+    if (p0.wide) {
+        void* d_vw[MAX_JOBS];
+        void* d_seg3[MAX_JOBS];
+        for (uint32_t k = 0; k < n_jobs; ++k) {
+            d_vw[k] = mbs[k].win.p;
+            d_seg3[k] = mbs[k].seg3.p;
+        }
+        return queue_reduce_wide<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, d_vw, d_seg3, (char*)h_win, p0.win_bytes, st);
+    }
     return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
+}
+
+// wide reduction: h = [sum_v S_v (as win: unused), sum_v S_v (tot) | K = sum_v (v+1) T_v, sum_v T_v]; buckets per virtual window = 2^log_bv
+template <class Cv>
+void pre_host_wide(const void* h, uint32_t log_bv, uint64_t* out_xyz) {
+    typedef typename Cv::Fq Fq;
+    typedef XYZZ<Fq> PH;
+    constexpr int L64 = Fq::N / 2;
+    const PH* w = (const PH*)h;
+    PH d = PH::add(w[2], PH::neg(w[3]));
+    for (uint32_t k = 0; k < log_bv; ++k) d = PH::dbl(d);
+    PH total = PH::add(w[1], d);
+    Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
+    if (!total.is_inf()) {
+        X = Fq::mul(total.x, total.zz);
+        Y = Fq::mul(total.y, total.zzz);
+        Z = total.zz;
+    }
+    memcpy(out_xyz, X.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + L64, Y.v, sizeof(uint64_t) * L64);
+    memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
 }
 
 // host: S = sum_v S_v + B_v * sum_v v * T_v   (bucket j of virtual window v has weight v*B_v + local index).
@@ -1598,7 +1978,8 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, base_offset, c->stream))) return rc;
     if ((rc = pre_queue_reduce<Cv>(c, &pl, &mb, 1, c->pinned, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
-    pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
+    if (pl.wide) pre_host_wide<Cv>(c->pinned, ilog2_floor(pl.gv.B), out_xyz);
+    else pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
     return ZK_OK;
 }
 
@@ -1640,7 +2021,13 @@ int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_c
     ZK_HIP_TRY(hipStreamSynchronize(st));
     const char* h_win = (const char*)c->pinned;
     int rcs[MAX_JOBS] = {0};
-    if (n_polys <= 2) {
+    if (pl[0].wide) {
+        c->pool->run(n_polys, [&](uint32_t k) {
+            uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
+            pre_host_wide<Cv>(h_win + (size_t)k * wb, ilog2_floor(pl[k].gv.B), xyz);
+            if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
+        });
+    } else if (n_polys <= 2) {
         // few jobs: the window ranges of a job go to different pool threads as well
         HostPartial<Fq> part[2 * HOST_CHUNKS];
         c->pool->run(n_polys * HOST_CHUNKS, [&](uint32_t i) {
@@ -1758,7 +2145,7 @@ int ZK_SYM(msm_convert_bases_dev)(zk_ctx* c, const void* d_xy_sat, const uint8_t
     return ZK_OK;
 }
 
-int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s) { return msm_precompute_run<CurveSel>(c, s); }
+int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s, uint32_t window_bits) { return msm_precompute_run<CurveSel>(c, s, window_bits); }
 
 int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);

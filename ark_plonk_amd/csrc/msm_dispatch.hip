@@ -8,7 +8,7 @@
     int g1_sum_partials_host##sfx(const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);         \
     int msm_convert_bases_dev##sfx(zk_ctx* c, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out);      \
     size_t msm_point_bytes##sfx();                                                                                     \
-    int msm_precompute_dev##sfx(zk_ctx* c, zk_srs* s);                                                                 \
+    int msm_precompute_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t window_bits);                                                                 \
     int msm_run_pre_dev##sfx(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);  \
     int msm_batch_pre_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz, \
                                const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job);
@@ -45,9 +45,9 @@ size_t msm_point_bytes(int curve) {
     if (curve == ZK_CURVE_BN254) return msm_point_bytes_c1();
     return 0;
 }
-int msm_precompute_dev(zk_ctx* c, zk_srs* s) {
-    if (s->curve == ZK_CURVE_BLS12_381) return msm_precompute_dev_c0(c, s);
-    if (s->curve == ZK_CURVE_BN254) return msm_precompute_dev_c1(c, s);
+int msm_precompute_dev(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_precompute_dev_c0(c, s, window_bits);
+    if (s->curve == ZK_CURVE_BN254) return msm_precompute_dev_c1(c, s, window_bits);
     return ZK_ERR_BAD_ARG;
 }
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {

@@ -90,11 +90,23 @@ class CommitterKey:
     def __len__(self):
         return self.n
 
-    def precompute(self):
-        """Build the window-multiples table (16x the SRS in HBM); later MSMs share one bucket set."""
+    def precompute(self, window_bits: int = 0):
+        """Build the window-multiples table (16x the SRS in HBM at the default window c = 16); later MSMs share one
+        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets)."""
         self.ctx.use_torch_stream() if _has_torch_cuda() else None
-        check(lib().zk_srs_precompute(self.ctx.handle, self._h), "zk_srs_precompute")
+        check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
         return self
+
+    def table_windows(self) -> int:
+        """rows of the window table = mixed additions per scalar on the shared-bucket path (0: no table)."""
+        c, w = ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib().zk_srs_table_info(self._h, ctypes.byref(c), ctypes.byref(w)), "zk_srs_table_info")
+        return w.value
+
+    def table_window_bits(self) -> int:
+        c, w = ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib().zk_srs_table_info(self._h, ctypes.byref(c), ctypes.byref(w)), "zk_srs_table_info")
+        return c.value
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -59,6 +59,8 @@ class ProofSchedule:
         self.quotient = quotient
         self._cache = {}
         self.msms_run = 0
+        self._cur_id = 0
+        self._next_id = 0
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
         self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
         dev = torch.device("cuda", ctx.device)
@@ -146,8 +148,23 @@ class ProofSchedule:
         allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, len(polys), L3)
         return sum_partials_batch(allp, self.cv.curve_id)
 
-    def run_once(self):
-        """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order."""
+    def _set_proof(self, proof_id):
+        """Every proof has its own witness: proof k's evaluation vectors are the seeded ones with k added to their first
+        limb, so no two proofs commit the same polynomials (a content-addressed commitment cache must only find what the
+        reference really repeats: the 12 re-commits of round 5 and the prover key's sigma polynomials)."""
+        if proof_id is None:
+            proof_id = self._next_id
+            self._next_id += 1
+        d = proof_id - self._cur_id
+        if d:
+            for t in self.evals + self.aux_evals + [self.quot]:
+                t[0, 0] += d
+        self._cur_id = proof_id
+
+    def run_once(self, proof_id=None):
+        """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order.
+        proof_id: which synthetic witness (None = the next one; pass the same id to reproduce a proof)."""
+        self._set_proof(proof_id)
         d, d4, n = self.dom_n, self.dom_4n, self.n
         out = []
         # commitments of prover-key polynomials (sigma_1..3) outlive a proof; everything else is per proof
@@ -254,8 +271,18 @@ class DropInSchedule:
         self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
         self.chi_mont = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
         self.msms_run = 0
+        self._cur_id = 0
+        self._next_id = 0
 
-    def run_once(self):
+    def run_once(self, proof_id=None):
+        if proof_id is None:
+            proof_id = self._next_id
+            self._next_id += 1
+        delta = proof_id - self._cur_id
+        if delta:                                                   # the same per-proof witnesses as ProofSchedule._set_proof
+            for t in self.evals + self.aux_evals + [self.quot]:
+                t[0, 0] = np.uint64((int(t[0, 0]) + delta) % (1 << 64))
+        self._cur_id = proof_id
         d, d4, n = self.dom_n, self.dom_4n, self.n
         ck = self.ck
         out = []

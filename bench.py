@@ -177,6 +177,7 @@ def parse_args():
                     help="wire columns: uniform random, or BenchCircuit's periodic {6,7,-20,1} rows + 3 blinding rows (SURVEY.md 8d config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
+    ap.add_argument("--table-window", type=int, default=0, help="window c of the SRS table (0 = library default; 16..21), see zk_srs_precompute_ex")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
                     help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by "
@@ -272,7 +273,7 @@ def main():
         ck0 = zk.CommitterKey(srs, cv, ctx)
         del srs
         if precompute:
-            ck0.precompute()   # window-multiples table resident in HBM (one-time, like PC::trim)
+            ck0.precompute(args.table_window)   # window-multiples table resident in HBM (one-time, like PC::trim)
         lanes = []
         for i in range(S):
             cx = ctx if i == 0 else zk.Context(dev)
@@ -332,7 +333,7 @@ def main():
         if args.check:
             for ln in lanes:
                 with torch.cuda.stream(ln["stream"]):
-                    digs.append(digest(ln["pts"] if ln["pts"] is not None else ln["sched"].run_once()))
+                    digs.append(digest(ln["sched"].run_once(proof_id=0)))
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
@@ -355,19 +356,20 @@ def main():
         ck = zk.CommitterKey(srs, cv, ctx)                  # zk_srs_register: upload + digest
         t_reg = time.perf_counter() - t0
         if not args.no_precompute:
-            ck.precompute()
+            ck.precompute(args.table_window)
         t0 = time.perf_counter()
         ck2 = zk.CommitterKey(srs, cv, ctx)                 # PC::trim on the next gen_proof: a cache hit
         t_hit = time.perf_counter() - t0
         sched = DropInSchedule(log_n, ctx, ck2, cv)
-        pts = sched.run_once()
+        sched.run_once()
         ctx.io_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(k):
-            pts = sched.run_once()
+            sched.run_once()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         io = ctx.io_stats()
+        pts = sched.run_once(proof_id=0) if args.check else None
         out = {"proofs_per_s": k / dt, "ms_per_proof": dt / k * 1e3, "steps": k,
                "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
                "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,

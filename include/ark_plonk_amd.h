@@ -144,6 +144,12 @@ int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const
  * size in HBM (2 GiB per 2^20 BLS12-381 points at c = 16; the card has 288 GB).  MSMs over the SRS then use a
  * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged.  Idempotent. */
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
+/* Same with the table's window c chosen: 16 (default; 16 rows, 2^15 shared buckets) .. 21.  A larger window means fewer
+ * rows (13 at c = 20: 13 mixed additions per scalar instead of 16, table 13 x the SRS) but 2^(c-1) buckets to reduce.
+ * 0 = default.  ZK_ERR_UNSUPPORTED if the SRS already holds a table with another window. */
+int zk_srs_precompute_ex(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits);
+/* window_bits / windows (= rows = mixed additions per scalar) of the SRS's table; both 0 without a table. */
+int zk_srs_table_info(zk_srs* srs, uint32_t* window_bits, uint32_t* windows);
 void zk_srs_free(zk_srs* srs);
 size_t zk_srs_len(const zk_srs* srs);
 /* SRS cache: bytes of unreferenced entries kept resident (0 = free on last zk_srs_free) / counters. */

@@ -13,13 +13,14 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "13", "--steps", "2", "--warmup", "1", "--streams-leg", "2",
-                        "--check"], capture_output=True, text=True, timeout=900)
+                        "--check", "--extra-legs", "on"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert d["metric"] == base["metric"] and d["unit"] == "proofs/s"
+    # BASELINE's metric string, with the size this run was asked for (the default run prints BASELINE's verbatim)
+    assert d["metric"] == base["metric"].replace("2^20", "2^13") and d["unit"] == "proofs/s"
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and isinstance(d["dtype"], str) and "workload" in d["config"] and "model" not in d["config"]
@@ -29,4 +30,21 @@ def test_bench_json_contract():
     assert rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "proofs/s" and cb["sample"]
-    assert d["concurrent_streams"]["commitments_match"] is True
+    assert d["concurrent_streams"]["commitments_match"] is True and d["concurrent_streams"]["shared_srs"] is True
+    # the unchanged-caller path (host pointers, pageable buffers) and the other legs give the same 29 commitments
+    di = d["drop_in"]
+    assert di["commitments_match_resident"] is True and di["proofs_per_s"] > 0 and di["h2d_bytes_per_proof"] > 0 and di["d2h_bytes_per_proof"] > 0
+    assert di["srs_cache"]["hits"] >= 1
+    assert d["dedup"]["commitments_match"] is True and d["dedup"]["msms_computed_per_proof"] == 17
+    assert d["no_precompute"]["commitments_match"] is True
+    assert rf["valu"]["mixed_adds_per_scalar"] == 16 and "traffic_source" in rf
+
+
+def test_bench_default_metric_is_baselines():
+    """`metric` of the default configuration is BASELINE.json's string verbatim (checked without running the GPU part)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert f"proofs/sec at 2^20 constraints ({m.CURVE_TITLE['bls12_381']}, KZG10); MSM G1-adds/s" == base["metric"]

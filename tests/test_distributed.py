@@ -126,10 +126,10 @@ def test_bench_two_ranks_matches_one_rank():
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     def two_ranks(extra):
-        port = _free_port()
-        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                              "127.0.0.1", "--master-port", str(port)] + common + ["--gpus", "2", "--backend", "gloo"] + extra,
-                             capture_output=True, text=True, env=env, timeout=900)
+        # no external torchrun: `bench.py --gpus 2` starts its two ranks itself (both on this box's one card, gloo)
+        env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        two = subprocess.run([sys.executable] + common + ["--gpus", "2", "--backend", "gloo"] + extra,
+                             capture_output=True, text=True, env=env2, timeout=900)
         assert two.returncode == 0, two.stderr[-3000:]
         return json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
 
@@ -138,6 +138,7 @@ def test_bench_two_ranks_matches_one_rank():
     assert d2["n_gpus"] == 2 and d2["scaling"] == "weak"
     assert d1["commitments_sha256"] == d2["commitments_sha256"]
     assert d2["msm_sharded"].get("commitments_match_replicas") is True, d2["msm_sharded"]
+    assert "2^15" in d2["metric"] and "msm_sharded_n22" not in d2        # the 2^22 leg rides along only with the default workload
     # --mode shard: the sharded path as the headline (strong scaling)
     d3 = two_ranks(["--mode", "shard"])
     assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"

@@ -36,7 +36,7 @@ def test_schedule_table_path_matches_plain_path_and_dedup(ctx, log_n):
     s_dd = ProofSchedule(log_n, ctx, ck, cv, dedup=True)
     dd = s_dd.run_once()
     assert s_dd.msms_run == 20          # first proof: the prover key's sigma commitments are computed once ...
-    dd2 = s_dd.run_once()
+    dd2 = s_dd.run_once(proof_id=0)
     assert s_dd.msms_run == 17          # ... and stay cached: lin, table, W_z, W_zw + the 13 of rounds 1-4
     fused = ProofSchedule(log_n, ctx, ck, cv, fuse_round5=True).run_once()
     for a, b, c, e, f in zip(plain, tab, dd, dd2, fused):

@@ -329,6 +329,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient")}
+        msms_run = lanes[0]["sched"].msms_run        # of the last timed proof (the digest run below repeats proof 0)
         digs = []
         if args.check:
             for ln in lanes:
@@ -337,7 +338,7 @@ def main():
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
-               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": lanes[0]["sched"].msms_run,
+               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": msms_run,
                "windows": ck0.table_windows()}
         if dedup == "abi":
             for ln in lanes:

@@ -271,12 +271,11 @@ int zk_ntt_batch_dev(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t
     if (log_n > 63) return ZK_ERR_DOMAIN_TOO_LARGE;
     for (uint32_t i = 0; i < n_polys; ++i)
         if (!d_outs[i] || (!d_ins[i] && in_lens[i])) return ZK_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n_polys; ++i)
+        for (uint32_t j = 0; j < i; ++j)
+            if (d_outs[i] == d_outs[j]) return ZK_ERR_BAD_ARG;     // two results in one buffer
     Guard g(c);
-    for (uint32_t i = 0; i < n_polys; ++i) {
-        int rc = ntt_run_dev(c, curve_id, kind, log_n, d_ins[i], in_lens[i], d_outs[i]);
-        if (rc) return rc;
-    }
-    return ZK_OK;
+    return ntt_run_batch_dev(c, curve_id, kind, log_n, n_polys, d_ins, in_lens, d_outs);
 }
 
 int zk_ntt_prepare(zk_ctx* c, int curve_id, uint32_t log_n) {

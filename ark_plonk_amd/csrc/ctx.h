@@ -286,6 +286,8 @@ void zk_prof_collect(zk_ctx* c);
 
 // implemented in ntt.hip / msm.hip
 int ntt_run_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out);
+int ntt_run_batch_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, uint32_t n_polys, const void* const* d_ins, const size_t* in_lens,
+                      void* const* d_outs);
 int ntt_prepare(zk_ctx* c, int curve, uint32_t log_n);
 void ntt_ctx_free(zk_ctx* c);
 int fr_convert_dev(zk_ctx* c, int curve, int to_mont, const void* d_in, size_t n, void* d_out);

@@ -257,13 +257,23 @@ int dispatch_pass(zk_ctx* c, int s, bool final_pass, const NttPassArgs& a) {
     return ZK_OK;
 }
 
+// n_polys (1 .. 16) independent transforms of one kind and size; n_polys > 1 runs every pass as ONE launch (blockIdx.y)
 template <class C>
-int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
+int ntt_run(zk_ctx* c, int kind, uint32_t log_n, uint32_t n_polys, const void* const* d_ins, const size_t* in_lens, void* const* d_outs) {
     typedef typename C::Fr Fr;
     if (log_n > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
     if (log_n > 27) return ZK_ERR_UNSUPPORTED;
+    if (n_polys == 0 || n_polys > 16) return ZK_ERR_BAD_ARG;
     const uint64_t N = 1ull << log_n;
-    if (in_len > N) return ZK_ERR_BAD_ARG;
+    size_t in_len = 0;               // the longest input of the batch
+    bool all_quarter = true;
+    for (uint32_t i = 0; i < n_polys; ++i) {
+        if (in_lens[i] > N) return ZK_ERR_BAD_ARG;
+        if (in_lens[i] > in_len) in_len = in_lens[i];
+        if ((uint64_t)in_lens[i] * 4 > N) all_quarter = false;
+    }
+    const void* d_in = d_ins[0];
+    void* d_out = d_outs[0];
     const bool inverse = (kind == ZK_NTT_IFFT || kind == ZK_NTT_COSET_IFFT);
     int rc;
     Fr n_inv = Fr::inverse(Fr::from_u64(N));
@@ -274,8 +284,9 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
         Fr pre_g = kind == ZK_NTT_COSET_FFT ? g : Fr::one();
         Fr post_g = kind == ZK_NTT_COSET_IFFT ? Fr::inverse(g) : Fr::one();
         ProfScope ps(c, "ntt_pass");
-        hipLaunchKernelGGL(ntt_tiny<Fr>, dim3(1), dim3(64), 0, c->stream, d_in, d_out, (uint64_t)in_len, log_n, w, pre_g, post_g,
-                           inverse ? n_inv : Fr::one());
+        for (uint32_t i = 0; i < n_polys; ++i)
+            hipLaunchKernelGGL(ntt_tiny<Fr>, dim3(1), dim3(64), 0, c->stream, d_ins[i], d_outs[i], (uint64_t)in_lens[i], log_n, w, pre_g, post_g,
+                               inverse ? n_inv : Fr::one());
         ZK_HIP_TRY(hipGetLastError());
         return ZK_OK;
     }
@@ -295,7 +306,7 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
     if (pl->n_pass > 3) return ZK_ERR_UNSUPPORTED;
     void* work = nullptr;
     if (pl->n_pass > 1) {
-        rc = c->ntt_work.ensure(N * sizeof(Fr));
+        rc = c->ntt_work.ensure((size_t)n_polys * N * sizeof(Fr));     // one intermediate vector per polynomial of the batch
         if (rc) return rc;
         work = c->ntt_work.p;
     }
@@ -311,7 +322,16 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
         a.log_n = log_n;
         a.in = (p == 0) ? d_in : work;
         a.out = last ? d_out : work;
-        a.in_len = (p == 0) ? in_len : N;
+        a.in_len = (p == 0) ? in_lens[0] : N;
+        if (n_polys > 1) {
+            a.n_batch = n_polys;
+            for (uint32_t i = 0; i < n_polys; ++i) {
+                void* wk = (char*)work + (size_t)i * N * sizeof(Fr);
+                a.ins[i] = (p == 0) ? d_ins[i] : wk;
+                a.outs[i] = last ? d_outs[i] : wk;
+                a.in_lens[i] = (p == 0) ? in_lens[i] : N;
+            }
+        }
         a.tw_inner = pl->tw_inner[p];
         a.pre_mul = (p == 0) ? pre : nullptr;
         const uint32_t LC = 9u - (uint32_t)s;
@@ -323,7 +343,7 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
             a.log_mprev = log_mprev;
             a.tw_pass = pl->tw_pass[p];
             a.n_tiles = (uint32_t)(N >> ((uint32_t)s + logc));
-            a.quarter = (p == 0 && s >= 3 && (uint64_t)in_len * 4 <= N) ? 1u : 0u;
+            a.quarter = (p == 0 && s >= 3 && all_quarter) ? 1u : 0u;
             log_mprev = log_m;
         } else {
             uint32_t s1 = (pl->n_pass > 1) ? (uint32_t)pl->s[0] : 0;
@@ -344,10 +364,23 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, const void* d_in, size_t in_len
 }  // namespace
 
 int ntt_run_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, const void* d_in, size_t in_len, void* d_out) {
+    return ntt_run_batch_dev(c, curve, kind, log_n, 1, &d_in, &in_len, &d_out);
+}
+
+// A batch in place (d_ins[i] == d_outs[i]) is fine: every pass but the last writes the ctx's work vectors.  Two DIFFERENT
+// polynomials of a batch must not alias each other.
+int ntt_run_batch_dev(zk_ctx* c, int curve, int kind, uint32_t log_n, uint32_t n_polys, const void* const* d_ins, const size_t* in_lens,
+                      void* const* d_outs) {
     if (kind < 0 || kind > 3) return ZK_ERR_BAD_ARG;
-    if (curve == ZK_CURVE_BLS12_381) return ntt_run<CurveBls>(c, kind, log_n, d_in, in_len, d_out);
-    if (curve == ZK_CURVE_BN254) return ntt_run<CurveBn>(c, kind, log_n, d_in, in_len, d_out);
-    return ZK_ERR_BAD_ARG;
+    for (uint32_t base = 0; base < n_polys; base += 16) {
+        const uint32_t cnt = n_polys - base < 16 ? n_polys - base : 16;
+        int rc;
+        if (curve == ZK_CURVE_BLS12_381) rc = ntt_run<CurveBls>(c, kind, log_n, cnt, d_ins + base, in_lens + base, d_outs + base);
+        else if (curve == ZK_CURVE_BN254) rc = ntt_run<CurveBn>(c, kind, log_n, cnt, d_ins + base, in_lens + base, d_outs + base);
+        else return ZK_ERR_BAD_ARG;
+        if (rc) return rc;
+    }
+    return ZK_OK;
 }
 
 int ntt_prepare(zk_ctx* c, int curve, uint32_t log_n) {

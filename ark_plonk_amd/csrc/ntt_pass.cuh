@@ -37,6 +37,13 @@ struct NttPassArgs {
     uint32_t n_tiles;
     uint32_t quarter;       // first pass of a multi-pass transform whose input fills at most N/4 (coset_fft of n coefficients on
                             // the 4n domain): only rows < 2^S / 4 are non-zero, so the first two stages are plain copies
+    // batch of independent transforms of one kind and size in ONE launch (blockIdx.y = polynomial): the four wire iffts of
+    // prover.rs:196-203, the four sigma ffts of permutation/mod.rs:671-674, the coset ffts of quotient_poly.rs:72-120.  A single
+    // 2^20 transform is only 2048 wavefront-tiles -- two per SIMD, short of the three the kernel's registers allow.
+    uint32_t n_batch;       // 0: one transform (in / out / in_len above)
+    const void* ins[16];
+    void* outs[16];
+    uint64_t in_lens[16];
 };
 
 __host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
@@ -165,6 +172,14 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= a.n_tiles) return;
+    const void* in = a.in;
+    void* out = a.out;
+    uint64_t in_len = a.in_len;
+    if (a.n_batch) {
+        in = a.ins[blockIdx.y];
+        out = a.outs[blockIdx.y];
+        in_len = a.in_lens[blockIdx.y];
+    }
     lds_u32* sc = (lds_u32*)scratch[wv];
     const uint32_t c = lane & ((1u << LC) - 1u);
     const uint32_t v = lane >> LC;
@@ -180,8 +195,8 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
     for (int e = 0; e < 8; ++e) {
         const uint64_t row = bitrev32((v << 3) | e, S);      // DIT consumes bit-reversed rows
         const uint64_t idx = base + (row << a.log_m);
-        if (active && idx < a.in_len) {
-            x[e] = ld_u<F>(a.in, idx);
+        if (active && idx < in_len) {
+            x[e] = ld_u<F>(in, idx);
             if (a.pre_mul) x[e] = F::mul(x[e], ld_u<F>(a.pre_mul, idx));
         } else {
             x[e] = F::zero();
@@ -193,7 +208,7 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
     for (int e = 0; e < 8; ++e) {
         const uint64_t k = S >= 3 ? (((uint64_t)e << (S - 3)) | v) : e;
         F w = ld_u<F>(a.tw_pass, (k << a.log_m) + col);
-        st_u<F>(a.out, base + (k << a.log_m), F::mul(x[e], w));
+        st_u<F>(out, base + (k << a.log_m), F::mul(x[e], w));
     }
 }
 
@@ -206,6 +221,14 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= a.n_tiles) return;
+    const void* in = a.in;
+    void* out = a.out;
+    uint64_t in_len = a.in_len;
+    if (a.n_batch) {
+        in = a.ins[blockIdx.y];
+        out = a.outs[blockIdx.y];
+        in_len = a.in_lens[blockIdx.y];
+    }
     lds_u32* sc = (lds_u32*)scratch[wv];
     // block index digits: b = k1 * 2^log_rest + rho ; this tile gathers 2^logc consecutive k1
     const uint32_t log_nb = a.log_n - S;
@@ -225,8 +248,8 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
         const uint32_t cb = q >> S, row = q & (L - 1);
         const uint64_t b = ((((uint64_t)g << a.logc) + cb) << log_rest) | rho;
         const uint64_t idx = (b << S) + row;
-        if (cb < (1u << a.logc) && idx < a.in_len) {
-            x[e] = ld_u<F>(a.in, idx);
+        if (cb < (1u << a.logc) && idx < in_len) {
+            x[e] = ld_u<F>(in, idx);
             if (a.pre_mul) x[e] = F::mul(x[e], ld_u<F>(a.pre_mul, idx));
         } else {
             x[e] = F::zero();
@@ -248,6 +271,6 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
         // brings the lazily reduced value (< 20 r) back under 2r for the canonical store
         F y = F::mul(x[e], sc_mul);
         if (a.post_mul) y = F::mul(y, ld_u<F>(a.post_mul, oidx));
-        st_u<F>(a.out, oidx, y);
+        st_u<F>(out, oidx, y);
     }
 }

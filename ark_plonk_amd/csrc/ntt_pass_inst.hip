@@ -16,9 +16,10 @@ extern "C" int ZK_LAUNCHER_NAME(ZK_NTT_S)(int final_pass, const NttPassArgs* a, 
     // one wavefront per tile of 512 elements, four tiles per workgroup
     const unsigned waves = a->n_tiles < 4 ? a->n_tiles : 4;
     const unsigned blocks = (a->n_tiles + waves - 1) / waves;
+    const unsigned polys = a->n_batch ? a->n_batch : 1;
     if (final_pass)
-        hipLaunchKernelGGL((ntt_pass_final<FrSel, S>), dim3(blocks), dim3(64 * waves), 0, st, *a);
+        hipLaunchKernelGGL((ntt_pass_final<FrSel, S>), dim3(blocks, polys), dim3(64 * waves), 0, st, *a);
     else
-        hipLaunchKernelGGL((ntt_pass_mid<FrSel, S>), dim3(blocks), dim3(64 * waves), 0, st, *a);
+        hipLaunchKernelGGL((ntt_pass_mid<FrSel, S>), dim3(blocks, polys), dim3(64 * waves), 0, st, *a);
     return (int)hipGetLastError();
 }

@@ -114,9 +114,10 @@ class Radix2EvaluationDomain:
     def coset_ifft(self, evals):
         return self._run(KIND_COSET_IFFT, evals)
 
-    def batch(self, kind: int, polys):
+    def batch(self, kind: int, polys, outs=None):
         """n_polys transforms of one kind sharing the plan (the 13 coset_fft of quotient_poly.rs:72-120):
-        host arrays -> zk_ntt_batch, device tensors -> zk_ntt_batch_dev.  Returns the list of outputs."""
+        host arrays -> zk_ntt_batch, device tensors -> zk_ntt_batch_dev (every pass of the whole batch is ONE launch).
+        outs (device tensors only): preallocated result tensors of size() elements each.  Returns the list of outputs."""
         import ctypes
         polys = list(polys)
         k = len(polys)
@@ -125,7 +126,7 @@ class Radix2EvaluationDomain:
         cid, n = self.curve.curve_id, self._size
         ctx = self._ctx_for(polys[0])
         ins = (ctypes.c_void_p * k)()
-        outs = (ctypes.c_void_p * k)()
+        outs_p = (ctypes.c_void_p * k)()
         lens = (ctypes.c_size_t * k)()
         if _is_torch(polys[0]):
             import torch
@@ -134,10 +135,15 @@ class Radix2EvaluationDomain:
                 lens[i] = check_dev_tensor(x, 4, ctx.device)
                 if lens[i] > n:
                     raise ValueError("input longer than the domain")
-                res.append(torch.empty((n, 4), dtype=x.dtype, device=x.device))
-                ins[i], outs[i] = x.data_ptr(), res[i].data_ptr()
+                if outs is not None:
+                    if check_dev_tensor(outs[i], 4, ctx.device) != n:
+                        raise ValueError("output tensor must hold exactly domain.size() elements")
+                    res.append(outs[i])
+                else:
+                    res.append(torch.empty((n, 4), dtype=x.dtype, device=x.device))
+                ins[i], outs_p[i] = x.data_ptr(), res[i].data_ptr()
             ctx.use_torch_stream()
-            check(lib().zk_ntt_batch_dev(ctx.handle, cid, kind, self._log, k, ins, lens, outs), "zk_ntt_batch_dev")
+            check(lib().zk_ntt_batch_dev(ctx.handle, cid, kind, self._log, k, ins, lens, outs_p), "zk_ntt_batch_dev")
             return res
         arrs = [as_host_u64(x, 4) for x in polys]
         res = [np.empty((n, 4), dtype=np.uint64) for _ in arrs]
@@ -145,8 +151,8 @@ class Radix2EvaluationDomain:
             if a.shape[0] > n:
                 raise ValueError("input longer than the domain")
             lens[i] = a.shape[0]
-            ins[i], outs[i] = a.ctypes.data, res[i].ctypes.data
-        check(lib().zk_ntt_batch(ctx.handle, cid, kind, self._log, k, ins, lens, outs), "zk_ntt_batch")
+            ins[i], outs_p[i] = a.ctypes.data, res[i].ctypes.data
+        check(lib().zk_ntt_batch(ctx.handle, cid, kind, self._log, k, ins, lens, outs_p), "zk_ntt_batch")
         return res
 
     def _in_place(self, kind, buf):

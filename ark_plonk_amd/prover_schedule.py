@@ -28,7 +28,8 @@ from .msm import CommitterKey, sum_partials_batch
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
-                 grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform"):
+                 grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
+                 ntt_batch: bool = True):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -57,6 +58,11 @@ class ProofSchedule:
         # the 4n quotient evaluations computed on the device from the 13 coset-FFT outputs
         # and (synthetic) prover-key evaluations instead of taken as a synthetic input
         self.quotient = quotient
+        # Independent transforms the reference issues back to back go out as ONE zk_ntt_batch_dev (one launch per pass,
+        # blockIdx.y = polynomial): the four wire iffts (prover.rs:196-203), h_1 / h_2 (prover.rs:302-305), the four sigma ffts
+        # (permutation/mod.rs:671-674) and the twelve coset ffts of quotient_poly.rs:72-120.  ntt_batch=False issues them one by one,
+        # as a patched ark-poly (which sees one fft_in_place at a time) would.
+        self.ntt_batch = ntt_batch
         self._cache = {}
         self.msms_run = 0
         self._cur_id = 0
@@ -96,11 +102,12 @@ class ProofSchedule:
         self.ev4n = torch.empty((4 * n, 4), dtype=torch.int64, device=dev)
         self.quot = rnd(4 * n)                            # quotient evaluations over the coset
         self.scratch_n = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        from .quotient import COLUMNS
+        if quotient or ntt_batch:     # the twelve coset-fft outputs live side by side (a batch writes them in one launch)
+            self.cos = {name: torch.empty((4 * n, 4), dtype=torch.int64, device=dev) for name in COLUMNS[:12]}
         if quotient:
-            from .quotient import COLUMNS
             self.key4n = {name: rnd(4 * n) for name in COLUMNS[12:]}     # selector evaluations of the prover key over the coset
             self.sigma4n = [rnd(4 * n) for _ in range(4)]
-            self.cos = {name: torch.empty((4 * n, 4), dtype=torch.int64, device=dev) for name in COLUMNS[:12]}
             self.q_chal = {name: np.array([0x1111 * (k + 1), 0x2222, 0x3333, 0x0444], dtype=np.uint64)
                            for k, name in enumerate(__import__("ark_plonk_amd.quotient", fromlist=["CHALLENGES"]).CHALLENGES)}
         # shard of the SRS this rank owns
@@ -172,19 +179,25 @@ class ProofSchedule:
         self.msms_run = 0
         c = self.coef
         # Round 1: 4 ifft + 4 commits (prover.rs:196-203, 213)
-        for i in range(4):
-            c[i] = d.ifft(self.evals[i])
+        if self.ntt_batch:
+            c[0:4] = d.batch(1, self.evals)
+        else:
+            for i in range(4):
+                c[i] = d.ifft(self.evals[i])
         out += self._commit_round(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         c[4] = d.ifft(self.aux_evals[0])          # table_poly
         c[5] = d.ifft(self.aux_evals[1])          # f_poly
         out += self._commit_round([c[5]], labels=["f"])
-        c[6] = d.ifft(self.aux_evals[2])          # h1
-        c[7] = d.ifft(self.aux_evals[3])          # h2
+        if self.ntt_batch:
+            c[6], c[7] = d.batch(1, self.aux_evals[2:4])
+        else:
+            c[6] = d.ifft(self.aux_evals[2])          # h1
+            c[7] = d.ifft(self.aux_evals[3])          # h2
         out += self._commit_round([c[6]], labels=["h1"])     # two PC::commit calls of one polynomial each (prover.rs:312-317)
         out += self._commit_round([c[7]], labels=["h2"])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
-        sig = [d.fft(self.sigma[i]) for i in range(4)]
+        sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
         if self.grand_products:
             from . import permutation
@@ -200,8 +213,12 @@ class ProofSchedule:
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         c[11] = d.ifft(self.aux_evals[7])         # l1
         names = ("l1", "z", "w_l", "w_r", "w_o", "w_4", "z2", "f", "table", "h1", "h2", "pi")
-        for name, poly in zip(names, (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])):
-            d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)   # coset_fft, n coefficients zero-extended to 4n
+        qpolys = (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])
+        if self.ntt_batch:
+            d4.batch(2, qpolys, outs=[self.cos[name] for name in names])          # coset_fft, n coefficients zero-extended to 4n
+        else:
+            for name, poly in zip(names, qpolys):
+                d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
         quot = self.quot

@@ -199,6 +199,9 @@ def parse_args():
                     help="the 16 MSMs of prover.rs:579-618 as ONE batch instead of the reference's four calls (needs those calls merged in the caller)")
     ap.add_argument("--quotient", action="store_true",
                     help="also compute the 4n quotient evaluations on the device (SURVEY.md 8f N1) inside each step")
+    ap.add_argument("--no-ntt-batch", action="store_true",
+                    help="issue every transform as its own zk_ntt_dev call (a patched ark-poly sees one fft at a time) instead of batching the "
+                         "independent adjacent ones (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts) into one launch per pass")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
     ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
     return ap.parse_args()
@@ -280,7 +283,8 @@ def main():
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
-                kw = dict(dedup=dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5, data=args.data)
+                kw = dict(dedup=dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5, data=args.data,
+                          ntt_batch=not args.no_ntt_batch)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
@@ -437,7 +441,9 @@ def main():
         "config": {"workload": f"per-proof hot path of Prover::prove at n=2^{log_n}: 13 ifft(n)+4 fft(n)+13 coset_fft(4n)+"
                                f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident"
                                + (", wire columns as BenchCircuit builds them (periodic {6,7,-20,1} rows + 3 blinding rows)" if args.data != "uniform" else ""),
-                   "log_n": log_n, "curve": cv.name, "parallelism": par, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows"},
+                   "log_n": log_n, "curve": cv.name, "parallelism": par, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows",
+                   "ntt_calls": "one zk_ntt_dev per transform" if args.no_ntt_batch else
+                                "adjacent independent transforms as zk_ntt_batch_dev (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts), the rest single"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_note": "each of the W digits of a scalar gathers its own 128-B row of the window table instead of re-deriving "

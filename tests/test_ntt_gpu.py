@@ -148,3 +148,39 @@ def test_linearity_2_24(ctx):
     dom.coset_ifft_in_place(fa)
     fb = dom.fft(a)
     assert torch.equal(fa, fb)
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 9), (0, 16), (1, 18), (0, 20)])
+def test_batched_launch_equals_single_transforms(cid, log_n, ctx):
+    """zk_ntt_batch_dev runs every pass of the whole batch as one launch (blockIdx.y = polynomial): 1-, 2- and 3-pass sizes,
+    ragged inputs (the coset ffts of the prover have n coefficients on the 4n domain: the first-stage shortcuts apply to
+    the batch only if every input fits a quarter), in place, more than 16 polynomials (two launches)."""
+    import torch
+    n = 1 << log_n
+    dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
+    g = torch.Generator(device="cuda").manual_seed(100 + log_n)
+    shift = 2 if cid == 1 else 0
+
+    def rnd(rows):
+        t = torch.randint(0, 1 << 62, (rows, 4), dtype=torch.int64, device="cuda", generator=g)
+        t[:, 3] >>= shift
+        return t
+
+    for kind in range(4):
+        lens = [n // 4, n // 4, n // 4 - 1, 1, n // 4] if kind == 2 else [n, n - 1, n // 4, 0, n, 7, n]
+        if log_n == 9:
+            lens = lens * 3                      # 15 / 21 polynomials: past the 16 one launch takes
+        polys = [rnd(ln) for ln in lens]
+        exp = [dom._run(kind, p) for p in polys]
+        got = dom.batch(kind, polys)
+        for e, o in zip(exp, got):
+            assert torch.equal(e, o), (kind, log_n)
+        if kind == 2:                              # one input longer than a quarter switches the shortcut off for the batch
+            polys2 = polys[:2] + [rnd(n // 4 + 1)]
+            got2 = dom.batch(kind, polys2)
+            assert torch.equal(got2[0], exp[0]) and torch.equal(got2[2], dom._run(kind, polys2[2]))
+        full = [rnd(n) for _ in range(3)]
+        exp_f = [dom._run(kind, p) for p in full]
+        dom.batch(kind, full, outs=full)           # in place
+        for e, o in zip(exp_f, full):
+            assert torch.equal(e, o)

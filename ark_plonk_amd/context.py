@@ -94,7 +94,7 @@ class Context:
         check(lib().zk_io_stats(self.handle, ctypes.byref(a), ctypes.byref(b), 1 if reset else 0), "zk_io_stats")
         return {"h2d_bytes": a.value, "d2h_bytes": b.value}
 
-    def set_staging(self, pinned_ring: bool = True):
+    def set_staging(self, pinned_ring: bool = False):
         check(lib().zk_ctx_set_staging(self.handle, 1 if pinned_ring else 0), "zk_ctx_set_staging")
 
     # -- profiling

@@ -231,7 +231,8 @@ struct zk_ctx {
     int stage_next = 0;
     hipEvent_t ev_up[16] = {};     // "input of job k is on the device" (copy stream -> main stream)
     uint64_t h2d_bytes = 0, d2h_bytes = 0;   // PCIe volume of the host-pointer entry points (zk_io_stats)
-    int staging_mode = 1;                     // 1 = pinned staging ring, 0 = plain hipMemcpyAsync from the caller's (pageable) buffer
+    int staging_mode = 0;                     // 0 = plain hipMemcpyAsync from the caller's (pageable) buffer: measured 56 GB/s on the MI355X
+                                              // hosts, the same as pinned memory (tools/pcie_probe.py); 1 = the ctx's pinned staging ring (49 GB/s)
 
     // N3: opt-in content-addressed commitment cache -- key = (srs id, input kind, length, 256-bit
     // digest of the coefficient vector computed on the device); value = the affine commitment

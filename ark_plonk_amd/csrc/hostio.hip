@@ -2,10 +2,13 @@
 // zk_msm_g1_srs: the calls a Rust shim binds) and the content digests of the SRS / commitment caches.
 //
 // The reference hands over ordinary heap slices (`domain.ifft(&w_l_scalar)` prover.rs:196-203, `PC::commit(ck, polys)`
-// prover.rs:213), i.e. pageable memory.  A hipMemcpyAsync from pageable memory is staged by the runtime on the calling
-// thread; here the staging is explicit: a ring of pinned 8 MiB slots per ctx, the caller's bytes copied into a slot by
-// the ctx's host pool (several cores share one slot, a single core's memcpy is slower than the PCIe link) and sent by DMA
-// while the next slot is being filled.  Pinned or hipHostRegister-ed caller buffers are detected and sent directly.
+// prover.rs:213), i.e. pageable memory.  Two ways to move it (zk_ctx_set_staging):
+//   0 (default)  hipMemcpyAsync straight from / to the caller's buffer.  Measured on the MI355X hosts (tools/pcie_probe.py,
+//                profiles/r02_notes.md): 56 GB/s in both directions, the same as pinned memory -- the runtime's own staging
+//                keeps the link busy.
+//   1            an explicit ring of pinned 8 MiB slots per ctx, the caller's bytes copied into a slot by the ctx's host pool
+//                and sent by DMA while the next slot is being filled: 49 GB/s there, kept for hosts where mode 0 is slow.
+// Pinned or hipHostRegister-ed caller buffers are detected and always sent directly.
 #include "ctx.h"
 
 namespace {

@@ -251,7 +251,6 @@ int dispatch_pass(zk_ctx* c, int s, bool final_pass, const NttPassArgs& a) {
     if (s < 3 || s > 9) return ZK_ERR_UNSUPPORTED;
     NttPassLauncher fn = zk_ntt_pass_launcher(C::ID, s);
     if (!fn) return ZK_ERR_UNSUPPORTED;
-    ProfScope ps(c, "ntt_pass");
     hipError_t e = (hipError_t)fn(final_pass ? 1 : 0, &a, c->stream);
     ZK_HIP_TRY(e);
     return ZK_OK;
@@ -315,6 +314,7 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, uint32_t n_polys, const void* c
     const Fr to_rp = rprime_plain<C>();
     uint32_t log_mprev = log_n;
     NttPassArgs a;
+    ProfScope ps(c, "ntt_pass");       // one scope per call (all passes of the transform or batch): an event pair costs ~14 us of host time
     for (int p = 0; p < pl->n_pass; ++p) {
         const int s = pl->s[p];
         const bool last = (p + 1 == pl->n_pass);

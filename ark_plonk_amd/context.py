@@ -98,8 +98,9 @@ class Context:
         check(lib().zk_ctx_set_staging(self.handle, 1 if pinned_ring else 0), "zk_ctx_set_staging")
 
     # -- profiling
-    def profile(self, on: bool = True):
-        check(lib().zk_profile_enable(self.handle, 1 if on else 0))
+    def profile(self, on=True):
+        """True / 1: every kernel scope; 2: msm_accumulate only; False / 0: off."""
+        check(lib().zk_profile_enable(self.handle, int(on)))
 
     def profile_reset(self):
         check(lib().zk_profile_reset(self.handle))

@@ -16,6 +16,7 @@ void zk_note_hip_error(hipError_t e, const char* what, const char* file, int lin
 ProfScope::ProfScope(zk_ctx* ctx, const char* nm) : ProfScope(ctx, nm, ctx->stream) {}
 ProfScope::ProfScope(zk_ctx* ctx, const char* nm, hipStream_t stream) : c(ctx), name(nm), st(stream) {
     if (!c->profiling) return;
+    if (c->profile_level == 2 && strcmp(nm, "msm_accumulate") != 0) return;   // level 2: the dominant kernel only
     auto take = [&]() -> hipEvent_t {
         if (!c->event_pool.empty()) {
             hipEvent_t e = c->event_pool.back();
@@ -221,6 +222,7 @@ int zk_profile_enable(zk_ctx* c, int on) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
     c->profiling = on != 0;
+    c->profile_level = on;
     return ZK_OK;
 }
 int zk_profile_reset(zk_ctx* c) {

@@ -198,6 +198,7 @@ struct zk_ctx {
     std::unique_ptr<HostPool> pool;   // created with the ctx (7 workers + the calling thread)
     int msm_window = 0;  // 0 = auto
     bool profiling = false;
+    int profile_level = 0;   // 1: every scope; 2: msm_accumulate only (an event pair costs ~14 us of host time and a bubble on the stream)
     std::map<std::string, ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
 

@@ -92,9 +92,19 @@ __global__ void __launch_bounds__(TERM_T) gp_lookup_terms(LookupArgs<Fr> a, uint
     st_fr<Fr>(D, i, den);
 }
 
+// The numerator scan (prefix) and the denominator scan (suffix) are independent and latency-bound (a few hundred
+// wavefronts walking dependent products): every phase handles both in ONE launch, blockIdx.y = 0 numerators, 1 denominators.
+struct GpPair {
+    void* x[2];        // the two vectors (scanned in place)
+    void* p[2];        // chunk products
+    void* a[2];        // chunk carries (+ total)
+};
+
 // phase 1: P[c] = prod of chunk c
 template <class Fr>
-__global__ void gp_chunk_prod(const void* X, uint64_t n, void* P, uint64_t n_chunks) {
+__global__ void gp_chunk_prod(GpPair g, uint64_t n, uint64_t n_chunks) {
+    const void* X = g.x[blockIdx.y];
+    void* P = g.p[blockIdx.y];
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
@@ -106,8 +116,11 @@ __global__ void gp_chunk_prod(const void* X, uint64_t n, void* P, uint64_t n_chu
 // phase 2 (one workgroup): A[c] = product of the chunk products before c (suffix == 0) or after c
 // (suffix == 1) -- the value entering chunk c; A[n_chunks] = product of everything.
 template <class Fr>
-__global__ void __launch_bounds__(SCAN_T) gp_scan_chunks(const void* P, uint64_t n_chunks, int suffix, void* A) {
+__global__ void __launch_bounds__(SCAN_T) gp_scan_chunks(GpPair g, uint64_t n_chunks) {
     extern __shared__ uint4 sh[];
+    const void* P = g.p[blockIdx.x];
+    void* A = g.a[blockIdx.x];
+    const int suffix = (int)blockIdx.x;       // numerators: prefix products; denominators: suffix products
     const uint32_t u = threadIdx.x;
     const uint64_t per = (n_chunks + SCAN_T - 1) / SCAN_T;
     const uint64_t lo = (uint64_t)u * per < n_chunks ? (uint64_t)u * per : n_chunks;
@@ -146,7 +159,10 @@ __global__ void __launch_bounds__(SCAN_T) gp_scan_chunks(const void* P, uint64_t
 // phase 3, in place: exclusive prefix products (suffix == 0: X[i] <- prod_{j<i}) or inclusive suffix
 // products (suffix == 1: X[i] <- prod_{j>=i})
 template <class Fr>
-__global__ void gp_apply(void* X, uint64_t n, const void* A, int suffix, uint64_t n_chunks) {
+__global__ void gp_apply(GpPair g, uint64_t n, uint64_t n_chunks) {
+    void* X = g.x[blockIdx.y];
+    const void* A = g.a[blockIdx.y];
+    const int suffix = (int)blockIdx.y;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
@@ -188,16 +204,17 @@ int finish_product(zk_ctx* c, uint64_t n, void* d_out, uint64_t* last_mont) {
     const int T = 256;
     const unsigned cb = (unsigned)((n_chunks + T - 1) / T);
     const size_t shmem = (size_t)SCAN_T * 32;
-    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb), dim3(T), 0, st, N, n, PNc, n_chunks);
-    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb), dim3(T), 0, st, D, n, PDc, n_chunks);
-    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(1), dim3(SCAN_T), shmem, st, PNc, n_chunks, 0, ANc);
-    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(1), dim3(SCAN_T), shmem, st, PDc, n_chunks, 1, ADc);
+    GpPair g;
+    g.x[0] = N; g.x[1] = D;
+    g.p[0] = PNc; g.p[1] = PDc;
+    g.a[0] = ANc; g.a[1] = ADc;
+    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb, 2), dim3(T), 0, st, g, n, n_chunks);
+    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(2), dim3(SCAN_T), shmem, st, g, n_chunks);
     ZK_HIP_TRY(hipGetLastError());
     Fr tot[2];   // total numerator product, total denominator product
     ZK_HIP_TRY(hipMemcpyAsync(&tot[0], (char*)ANc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
     ZK_HIP_TRY(hipMemcpyAsync(&tot[1], (char*)ADc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb), dim3(T), 0, st, N, n, ANc, 0, n_chunks);
-    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb), dim3(T), 0, st, D, n, ADc, 1, n_chunks);
+    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb, 2), dim3(T), 0, st, g, n, n_chunks);
     ZK_HIP_TRY(hipStreamSynchronize(st));
     if (tot[1].is_zero()) return ZK_ERR_NOT_INVERTIBLE;
     Fr inv_t = Fr::inverse(tot[1]);

@@ -264,7 +264,7 @@ def main():
         return hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in points)).hexdigest()
 
     def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps, log_n: int = args.log_n, precompute: bool = not args.no_precompute,
-                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup):
+                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
         n_streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
         streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
@@ -283,8 +283,8 @@ def main():
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
-                kw = dict(dedup=dedup, grand_products=args.grand_products, quotient=args.quotient, fuse_round5=args.fuse_round5, data=args.data,
-                          ntt_batch=not args.no_ntt_batch)
+                kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, fuse_round5=args.fuse_round5,
+                          data=args.data, ntt_batch=not args.no_ntt_batch)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
@@ -294,7 +294,9 @@ def main():
                     pts = sched.run_once()
             lanes.append({"ctx": cx, "stream": st, "ck": ck, "sched": sched, "pts": pts, "k": steps // S + (1 if i < steps % S else 0)})
         barrier()
-        ctx.profile(not args.no_profile)
+        # inside the timed region only the dominant kernel is bracketed by events (58 scopes per proof); the full per-kernel
+        # breakdown (~200 scopes, ~2 ms per proof of instrumentation) is taken on extra proofs right after it
+        ctx.profile(0 if args.no_profile else 2)
         ctx.profile_reset()
         if S == 1:
             t0 = time.perf_counter()
@@ -332,8 +334,23 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient")}
+        prof = {"msm_accumulate": ctx.profile_get("msm_accumulate")}
         msms_run = lanes[0]["sched"].msms_run        # of the last timed proof (the digest run below repeats proof 0)
+        kb = 0
+        if not args.no_profile:
+            kb = 2
+            ctx.profile(1)
+            ctx.profile_reset()
+            for _ in range(kb):
+                lanes[0]["sched"].run_once()
+            barrier()
+            ctx.profile(False)
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient"):
+                prof[k] = ctx.profile_get(k)
+            prof["breakdown_accumulate"] = ctx.profile_get("msm_accumulate")
+        else:
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "breakdown_accumulate"):
+                prof[k] = (0.0, 0)
         digs = []
         if args.check:
             for ln in lanes:
@@ -342,7 +359,7 @@ def main():
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
-               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": msms_run,
+               "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": msms_run, "kb": kb,
                "windows": ck0.table_windows()}
         if dedup == "abi":
             for ln in lanes:
@@ -413,7 +430,9 @@ def main():
                                       "constant of the kernel build named in `commit`, not a counter of the run that printed this line"}
         except Exception:
             traffic = None
-    msm_total_s = (acc_ms + sort_ms + red_ms) * 1e-3
+    kb = max(r["kb"], 1)                 # proofs of the breakdown pass (all scopes on, right after the timed region)
+    bacc_ms, _ = r["prof"]["breakdown_accumulate"]
+    msm_total_s = (bacc_ms + sort_ms + red_ms) * 1e-3
     valu = None
     W = r["windows"]
     if acc_n and W and cv.curve_id == 0:
@@ -451,21 +470,23 @@ def main():
                      "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes,
                      "valu": valu},
         # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
-        "msm_g1_adds_per_s": ((29 * kp * ark_adds(n, sbits)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
-                              if (msm_total_s and S == 1 and not args.dedup) else None),
-        "msm_ms_per_proof": msm_total_s / kp * 1e3,
-        "ntt_GBps": (r["ntt_bytes"] * kp) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
-        "ntt_ms_per_proof": ntt_ms / kp,
+        "msm_g1_adds_per_s": ((29 * kb * ark_adds(n, sbits)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
+                              if (msm_total_s and not args.dedup) else None),
+        "msm_ms_per_proof": msm_total_s / kb * 1e3,
+        "ntt_GBps": (r["ntt_bytes"] * kb) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
+        "ntt_ms_per_proof": ntt_ms / kb,
+        "breakdown_note": f"msm_* / ntt_* are per-kernel-scope HIP-event times of {kb} extra proofs run right after the timed region with every scope on; "
+                          "inside the timed region only msm_accumulate carries events (roofline)",
     }
     if args.grand_products:
         gp_ms, gp_n = r["prof"]["grand_product"]
         line["config"]["workload"] += " + z and z2 grand products on device"
-        line["grand_product_ms_per_proof"] = gp_ms / kp
+        line["grand_product_ms_per_proof"] = gp_ms / kb
     if args.fuse_round5:
         line["config"]["workload"] += "; round 5's four PC calls merged into one batch"
     if args.quotient:
         line["config"]["workload"] += " + pointwise quotient on device"
-        line["quotient_ms_per_proof"] = r["prof"]["quotient"][0] / kp
+        line["quotient_ms_per_proof"] = r["prof"]["quotient"][0] / kb
     if args.dedup:
         line["config"]["workload"] += f" -- WITH the commitment cache (zk_ctx_set_commit_cache): {r['msms_run']} MSMs computed per proof, the rest served from the cache"
     if S > 1:
@@ -509,6 +530,14 @@ def main():
                         "how": "zk_ctx_set_commit_cache(1): 256-bit device digest of every coefficient vector; prover.rs:569-607 re-commits 12 polynomials",
                         "commitments_match": (r3["digest"] == r["digest"]) if args.check else None}
             leg("dedup", dedup_leg)
+        def glue_leg():
+            k2 = max(2, min(steps, 3))
+            r5 = timed_region(False, 1, k2, warmup=1, glue=True)
+            return {"proofs_per_s": k2 / r5["dt"], "ms_per_proof": r5["dt"] / k2 * 1e3,
+                    "quotient_ms_per_proof": r5["prof"]["quotient"][0] / max(r5["kb"], 1), "grand_product_ms_per_proof": r5["prof"]["grand_product"][0] / max(r5["kb"], 1),
+                    "what": "SURVEY.md 8f N1 + N2 inside the step: z and z2 built on the device (zk_perm_product_dev / zk_lookup_product_dev) and the 4n quotient "
+                            "evaluations computed on the device (zk_quotient_evals_dev) from the 12 coset-fft outputs, instead of taken as synthetic inputs"}
+        leg("with_device_glue", glue_leg)
         if not args.no_precompute:
             def nopre_leg():
                 k2 = max(2, min(steps, 3))

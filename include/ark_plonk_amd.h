@@ -82,8 +82,9 @@ int zk_io_stats(zk_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset
  * copies slowly).  Tuning hook, see tools/pcie_probe.py. */
 int zk_ctx_set_staging(zk_ctx* ctx, int mode);
 
-/* Per-kernel HIP-event timing (bench.py roofline leg). When enabled every launch of the hot
- * kernels is bracketed by hipEventRecord on the ctx stream. */
+/* Per-kernel HIP-event timing (bench.py roofline leg). on = 1: every launch of the hot kernels is bracketed by
+ * hipEventRecord on the ctx stream (≈ 200 scopes, ≈ 2 ms per 2^20 proof); on = 2: only the dominant kernel, msm_accumulate
+ * (58 scopes per proof) -- what bench.py keeps on inside its timed region; 0: off. */
 int zk_profile_enable(zk_ctx* ctx, int on);
 int zk_profile_reset(zk_ctx* ctx);
 /* name: "ntt_pass", "msm_accumulate", "msm_sort", "msm_reduce", ...; returns total ms and launch count */

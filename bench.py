@@ -561,6 +561,11 @@ def main():
                 if lg == log_n:
                     d["speedup_vs_one_gpu_replica"] = (dt / steps) / (rs["dt"] / steps)
                     d["commitments_match_replicas"] = (rs["digest"] == r["digest"]) if args.check else None
+                elif args.check:
+                    # the unsharded form of the same size, one proof per rank on its own GPU (2^22: 8 GiB of window table per rank)
+                    ru = timed_region(False, steps=1, log_n=lg, warmup=0)
+                    d["commitments_match_unsharded"] = ru["digest"] == rs["digest"]
+                    d["unsharded_ms_per_proof"] = ru["dt"] * 1e3
                 return d
             return run
         leg("msm_sharded", shard_leg(log_n))

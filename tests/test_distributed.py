@@ -143,3 +143,31 @@ def test_bench_two_ranks_matches_one_rank():
     d3 = two_ranks(["--mode", "shard"])
     assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"
     assert d1["commitments_sha256"] == d3["commitments_sha256"]
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-launches itself as N ranks through torch.distributed.run (one per GPU,
+    rendezvous on 127.0.0.1) before touching the GPU; under an external torchrun it does not.  CPU check of the command line."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.self_launch(8) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main(): N > 1 and no WORLD_SIZE -> self-launch and exit with the children's code, nothing else imported or run
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7

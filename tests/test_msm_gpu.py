@@ -360,3 +360,47 @@ def test_quad_cooperative_group_law(cid, ctx):
     mask = ctypes.c_uint32(0)
     _lib.check(_lib.lib().zk_selftest_quad_dev(ctx.handle, cid, 6000, ctypes.byref(bad), ctypes.byref(mask)))
     assert bad.value == 0, f"{bad.value} mismatching quads, case mask {mask.value:#x}"
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("table", [False, True])
+def test_repeated_and_opposite_points_take_the_general_law(cid, table, ctx, oracle_cpu):
+    """Doubling and cancellation inside the bucket accumulation at scale (the golden edge cases have a handful of points): an SRS
+    made of 32 distinct points repeated 256 times each, with scalars drawn from a handful of values and their negatives, puts
+    equal and opposite points next to each other in most buckets of both MSM paths; then an MSM that cancels to infinity, then
+    the same buffers again with generic scalars."""
+    import torch
+    cv = bo.CURVES[cid]
+    n = 1 << 13
+    rng = np.random.default_rng(99 + cid)
+    ks = np.zeros((32, 4), dtype=np.uint64)
+    ks[:, 0] = rng.integers(1, 1 << 40, size=32, dtype=np.uint64)
+    d_k = torch.from_numpy(np.tile(ks, (n // 32, 1)).view(np.int64)).cuda()
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, d_k.data_ptr(), n, bases.data_ptr()))
+    vals = bo.seeded_scalars(cv, 4321, 6)
+    pool = vals + [cv.r - v for v in vals] + [0, 1, cv.r - 1]
+    scal = zk.curves.ints_to_limbs([pool[int(i)] for i in rng.integers(0, len(pool), size=n)], 4)
+    bases_h = bases.cpu().numpy().view(np.uint64)
+    exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases_h, scal)
+    ck = zk.CommitterKey(bases, cid, ctx)
+    if table:
+        ck.precompute()
+    got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
+    assert_point(got, exp_xy, exp_inf, cid)
+    # everything cancels: sum_i s_i P_i + sum_i (r - s_i) P_i = infinity
+    half = n // 2
+    s2 = scal.copy()
+    s2[half:] = zk.curves.ints_to_limbs([(cv.r - v) % cv.r for v in zk.curves.limbs_to_ints(scal[:half])], 4)
+    bases2 = torch.cat([bases[:half], bases[:half]])
+    ck2 = zk.CommitterKey(bases2, cid, ctx)
+    if table:
+        ck2.precompute()
+    assert ck2.msm(torch.from_numpy(s2.view(np.int64)).cuda()).infinity
+    ck2.close()
+    # the same buffers again with generic scalars
+    scal3 = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases_h, scal3)
+    assert_point(ck.msm(torch.from_numpy(scal3.view(np.int64)).cuda()), exp_xy, exp_inf, cid)
+    ck.close()

@@ -162,9 +162,9 @@ struct DevBuf {
 };
 
 struct MsmBufs {
-    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, seg3, win, tmp, scalars, stage, upload;
+    DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, seg2, seg3, win, tmp, scalars, stage, upload;
     void release() {
-        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg3, &win, &tmp, &scalars, &stage, &upload};
+        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg2, &seg3, &win, &tmp, &scalars, &stage, &upload};
         for (DevBuf* b : all) b->release();
     }
 };

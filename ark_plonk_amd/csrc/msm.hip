@@ -1245,6 +1245,40 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
 }
 
+// Work-efficient level of the wide reduction: a node (run, acc) stands for m = 2^logm consecutive buckets,
+//   run = sum B_i,  acc = sum (i + 1) B_i   (i local to the node);
+// K = 2^logk neighbouring nodes make one node of K*m buckets:  run' = sum_j run_j,  acc' = sum_j acc_j + m * sum_j j * run_j
+// -- 3 additions per child instead of the log2(chains) of the Hillis-Steele scan in msm_win_finish_q, which is what made
+// 2^17 level-1 nodes per job (window tables with c = 20) cost more than the level below them.  One quad per output node.
+// in: jobs.seg_run / seg_acc (n_out * K nodes);  out: jobs.win_s (run') / jobs.win_t (acc'), internal point form.
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_node_reduce_q(RJobs jobs, uint32_t n_out, uint32_t logk, uint32_t logm) {
+    const void* in_run = jobs.seg_run[blockIdx.y];
+    const void* in_acc = jobs.seg_acc[blockIdx.y];
+    void* out_run = jobs.win_s[blockIdx.y];
+    void* out_acc = jobs.win_t[blockIdx.y];
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t id = tid >> 2, role = tid & 3;
+    const bool live = id < n_out;                  // no early exit: wave shuffles inside qadd
+    const uint32_t K = 1u << logk;
+    const uint64_t first = (uint64_t)(live ? id : 0) * K;
+    F run = F::zero(), wsum = F::zero(), asum = F::zero();
+#pragma unroll 1
+    for (int j = (int)K - 1; j >= 1; --j) {
+        run = qadd<F>(run, live ? ld_coord<F>(in_run, first + (uint32_t)j, role) : F::zero(), role);
+        wsum = qadd<F>(wsum, run, role);           // after the loop: sum_j j * run_j
+        asum = qadd<F>(asum, live ? ld_coord<F>(in_acc, first + (uint32_t)j, role) : F::zero(), role);
+    }
+    run = qadd<F>(run, live ? ld_coord<F>(in_run, first, role) : F::zero(), role);
+    asum = qadd<F>(asum, live ? ld_coord<F>(in_acc, first, role) : F::zero(), role);
+    for (uint32_t t = 0; t < logm; ++t) wsum = qdbl<F>(wsum, role);
+    asum = qadd<F>(asum, wsum, role);
+    if (live) {
+        st_coord<F>(out_run, id, role, run);
+        st_coord<F>(out_acc, id, role, asum);
+    }
+}
+
 // arkworks-layout affine (x||y Montgomery words) -> internal points.  Accepted encodings of the point at infinity:
 // the flag, x = y = 0, and GroupAffine::zero() = (0, 1) (Montgomery one) -- what this library itself emits for an
 // infinite result and what an arkworks caller holds; (0, 1) lies on neither supported curve (b = 4 / b = 3).
@@ -1352,19 +1386,25 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
 }
 
 // Reduction for window tables with c > 16 (nb = 2^(c-1) >= 2^16 shared buckets), all on the device:
-//   level 1  msm_seg_reduce      one LANE per segment of 4 buckets: with >= 16 Ki segments per job the launch is throughput-bound,
+//   level 1  msm_seg_reduce      one LANE per node of 4 buckets: with >= 16 Ki nodes per job the launch is throughput-bound,
 //                                where the single-lane group law costs 13.5 product-times per addition against the quad form's 18
-//   level 2  msm_win_finish_q    VW = nb / 512 virtual windows of 128 chains -> S_v = sum_l (l+1) B_{v,l},  T_v = sum_l B_{v,l}, kept on the
-//                                device in the internal point form
-//   level 3  msm_seg_reduce_q + msm_win_finish_q over the two arrays S and T of every job (2 n_jobs "jobs", every element present):
+//   level 2  msm_node_reduce_q   4 nodes -> one node of 16 buckets, 3 additions per child (quads)
+//   level 3  msm_win_finish_q    VW = nb / 2048 virtual windows of 128 nodes -> S_v = sum_l (l+1) B_{v,l},  T_v = sum_l B_{v,l}, kept on
+//                                the device in the internal point form
+//   level 4  msm_seg_reduce_q + msm_win_finish_q over the two arrays S and T of every job (2 n_jobs "jobs", every element present):
 //                                sum_v S_v,  K = sum_v (v+1) T_v,  sum_v T_v  -> pinned host memory, arkworks layout
-//   host     total = sum_v S_v + 512 * (K - sum_v T_v)      (bucket j = 512 v + l has weight j + 1)
+//   host     total = sum_v S_v + 2048 * (K - sum_v T_v)      (bucket j = 2048 v + l has weight j + 1)
+constexpr uint32_t WIDE_LOGG1 = 2;     // buckets per level-1 node
+constexpr uint32_t WIDE_LOGK2 = 2;     // level-1 nodes per level-2 node
+constexpr uint32_t WIDE_CHAINS = 128;  // level-2 nodes per virtual window
+constexpr uint32_t WIDE_VB = WIDE_CHAINS << (WIDE_LOGG1 + WIDE_LOGK2);   // buckets per virtual window (2048)
 template <class F>
-int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, void* const* d_vw, void* const* d_seg3,
+int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, void* const* d_vw, void* const* d_seg3, void* const* d_seg2,
                       char* h_out, size_t h_stride, hipStream_t st) {
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     ProfScope ps(c, "msm_reduce", st);
-    const uint32_t VW = gr.W;
+    const uint32_t VW = nb / WIDE_VB;
+    if (VW == 0 || VW > 2048) return ZK_ERR_UNSUPPORTED;
     {   // chunk-edge partials -> buckets (queues cleared by the job's sort)
         const int T = 128;
         if (n_jobs <= 2) {
@@ -1377,54 +1417,78 @@ int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb
         hipLaunchKernelGGL(msm_combine_wave<F>, dim3(256, n_jobs), dim3(256), 0, st, jobs);
         hipLaunchKernelGGL(msm_combine_block<F>, dim3(64, n_jobs), dim3(256), 4 * PT, st, jobs, nb);
     }
-    {   // level 1
+    const uint32_t n1 = nb >> WIDE_LOGG1, n2 = n1 >> WIDE_LOGK2;
+    {   // level 1: flat over all buckets (one "window" of nb buckets, nodes of 4)
+        MsmGeom g1;
+        memset(&g1, 0, sizeof g1);
+        g1.W = 1;
+        g1.B = nb;
+        g1.nb = nb;
+        g1.logG = WIDE_LOGG1;
+        g1.ns = n1;
         const int T = 128;
-        unsigned sblocks = (unsigned)(((uint64_t)gr.W * gr.ns + T - 1) / T);
-        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
+        unsigned sblocks = (unsigned)(((uint64_t)n1 + T - 1) / T);
+        hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, g1);
     }
-    RJobs j2 = jobs;
+    RJobs j2 = jobs;      // level 2: seg_run / seg_acc (n1 nodes) -> d_seg2 (n2 nodes: run | acc)
     for (uint32_t k = 0; k < n_jobs; ++k) {
-        j2.win_s[k] = (uint32_t*)d_vw[k];
-        j2.win_t[k] = (uint32_t*)((char*)d_vw[k] + (size_t)VW * PT);
+        j2.win_s[k] = (uint32_t*)d_seg2[k];
+        j2.win_t[k] = (uint32_t*)((char*)d_seg2[k] + (size_t)n2 * PT);
     }
-    {   // level 2: 128 chains per virtual window
-        uint32_t chains = 1;
-        while (chains < gr.ns) chains <<= 1;
-        size_t shmem = (size_t)chains * PT;
+    {
+        unsigned blocks = (unsigned)(((uint64_t)n2 * 4 + 255) / 256);
+        hipLaunchKernelGGL(msm_node_reduce_q<F>, dim3(blocks, n_jobs), dim3(256), 0, st, j2, n2, WIDE_LOGK2, WIDE_LOGG1);
+    }
+    RJobs j3 = jobs;      // level 3: virtual windows of 128 level-2 nodes (16 buckets each)
+    MsmGeom gv;
+    memset(&gv, 0, sizeof gv);
+    gv.W = VW;
+    gv.B = WIDE_VB;
+    gv.nb = nb;
+    gv.logG = WIDE_LOGG1 + WIDE_LOGK2;
+    gv.ns = WIDE_CHAINS;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        j3.seg_run[k] = d_seg2[k];
+        j3.seg_acc[k] = (char*)d_seg2[k] + (size_t)n2 * PT;
+        j3.win_s[k] = (uint32_t*)d_vw[k];
+        j3.win_t[k] = (uint32_t*)((char*)d_vw[k] + (size_t)VW * PT);
+    }
+    {
+        const size_t shmem = (size_t)WIDE_CHAINS * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(VW, n_jobs), dim3(4 * chains), shmem, st, j2, gr, 1u);
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(VW, n_jobs), dim3(4 * WIDE_CHAINS), shmem, st, j3, gv, 1u);
     }
-    MsmGeom g3 = gr;
-    g3.W = 1;
-    g3.B = VW;
-    g3.nb = VW;
-    g3.logG = VW <= 1024 ? 2 : 3;
-    g3.ns = VW >> g3.logG;
-    g3.logq = 0;
-    if (g3.ns == 0 || g3.ns > 256) return ZK_ERR_UNSUPPORTED;
-    RJobs j3;
-    memset(&j3, 0, sizeof j3);
+    MsmGeom g4;           // level 4: the VW pairs (S_v, T_v) of every job
+    memset(&g4, 0, sizeof g4);
+    g4.W = 1;
+    g4.B = VW;
+    g4.nb = VW;
+    g4.logG = VW <= 4 ? 0 : VW <= 1024 ? 2 : 3;
+    g4.ns = VW >> g4.logG;
+    if (g4.ns == 0 || g4.ns > 256) return ZK_ERR_UNSUPPORTED;
+    RJobs j4;
+    memset(&j4, 0, sizeof j4);
     const size_t PHB = h_stride / 4;      // bytes of one host point
     for (uint32_t k = 0; k < n_jobs; ++k)
         for (uint32_t a = 0; a < 2; ++a) {
             const uint32_t j = 2 * k + a;
-            j3.buckets[j] = (char*)d_vw[k] + (size_t)a * VW * PT;
-            j3.offsets[j] = nullptr;
-            j3.seg_run[j] = (char*)d_seg3[k] + (size_t)a * 2 * g3.ns * PT;
-            j3.seg_acc[j] = (char*)d_seg3[k] + ((size_t)a * 2 + 1) * g3.ns * PT;
-            j3.win_s[j] = (uint32_t*)(h_out + (size_t)k * h_stride + (size_t)a * 2 * PHB);
-            j3.win_t[j] = (uint32_t*)(h_out + (size_t)k * h_stride + ((size_t)a * 2 + 1) * PHB);
+            j4.buckets[j] = (char*)d_vw[k] + (size_t)a * VW * PT;
+            j4.offsets[j] = nullptr;
+            j4.seg_run[j] = (char*)d_seg3[k] + (size_t)a * 2 * g4.ns * PT;
+            j4.seg_acc[j] = (char*)d_seg3[k] + ((size_t)a * 2 + 1) * g4.ns * PT;
+            j4.win_s[j] = (uint32_t*)(h_out + (size_t)k * h_stride + (size_t)a * 2 * PHB);
+            j4.win_t[j] = (uint32_t*)(h_out + (size_t)k * h_stride + ((size_t)a * 2 + 1) * PHB);
         }
     {
-        unsigned sblocks = (unsigned)(((uint64_t)g3.ns * 4 + 255) / 256);
-        hipLaunchKernelGGL(msm_seg_reduce_q<F>, dim3(sblocks, 2 * n_jobs), dim3(256), 0, st, j3, g3);
+        unsigned sblocks = (unsigned)(((uint64_t)g4.ns * 4 + 255) / 256);
+        hipLaunchKernelGGL(msm_seg_reduce_q<F>, dim3(sblocks, 2 * n_jobs), dim3(256), 0, st, j4, g4);
         uint32_t chains = 1;
-        while (chains < g3.ns) chains <<= 1;
+        while (chains < g4.ns) chains <<= 1;
         size_t shmem = (size_t)chains * PT;
         if (shmem > 48 * 1024)
             ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(1, 2 * n_jobs), dim3(4 * chains), shmem, st, j3, g3, 0u);
+        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(1, 2 * n_jobs), dim3(4 * chains), shmem, st, j4, g4, 0u);
     }
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
@@ -1683,7 +1747,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     pl.g1.W = 1;
     pl.g1.nb = pl.g.B;
     pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows (wide: windows of 512 buckets)
-    pl.gv.W = pl.wide ? pl.g.B / 512 : PRE_VW;
+    pl.gv.W = pl.wide ? pl.g.B / WIDE_VB : PRE_VW;
     pl.gv.B = pl.g.B / pl.gv.W;
     pl.gv.nb = pl.g.B;
     pl.gv.logG = 2;
@@ -1712,12 +1776,15 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
     if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
     if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
-    if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
     if (pl.wide) {
-        if ((rc = mb.win.ensure((size_t)2 * pl.gv.W * PT))) return rc;     // S_v | T_v of the virtual windows, internal form
-        if ((rc = mb.seg3.ensure((size_t)4 * 256 * PT))) return rc;         // level 3: (run, acc) of <= 256 segments for each of S, T
-    } else if ((rc = mb.win.ensure(pl.win_bytes))) {
-        return rc;
+        const size_t n1 = pl.g.B >> WIDE_LOGG1, n2 = n1 >> WIDE_LOGK2;
+        if ((rc = mb.seg.ensure(n1 * 2 * PT))) return rc;                   // level 1: (run, acc) of the 4-bucket nodes
+        if ((rc = mb.seg2.ensure(n2 * 2 * PT))) return rc;                  // level 2: 16-bucket nodes
+        if ((rc = mb.win.ensure((size_t)2 * pl.gv.W * PT))) return rc;     // level 3: S_v | T_v of the virtual windows, internal form
+        if ((rc = mb.seg3.ensure((size_t)4 * 256 * PT))) return rc;         // level 4: (run, acc) of <= 256 segments for each of S, T
+    } else {
+        if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
+        if ((rc = mb.win.ensure(pl.win_bytes))) return rc;
     }
     return ZK_OK;
 }
@@ -1854,7 +1921,7 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         jobs.buckets[k] = mb.buckets.p;
         jobs.q[k] = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
         jobs.seg_run[k] = mb.seg.p;
-        jobs.seg_acc[k] = (char*)mb.seg.p + (size_t)p0.gv.W * p0.gv.ns * PT;
+        jobs.seg_acc[k] = (char*)mb.seg.p + (p0.wide ? (size_t)(p0.g.B >> WIDE_LOGG1) : (size_t)p0.gv.W * p0.gv.ns) * PT;
         // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
         // buffer (hipHostMalloc memory is device-visible): no copy launches at the tail of the call
         jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
@@ -1865,11 +1932,13 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
     if (p0.wide) {
         void* d_vw[MAX_JOBS];
         void* d_seg3[MAX_JOBS];
+        void* d_seg2[MAX_JOBS];
         for (uint32_t k = 0; k < n_jobs; ++k) {
             d_vw[k] = mbs[k].win.p;
             d_seg3[k] = mbs[k].seg3.p;
+            d_seg2[k] = mbs[k].seg2.p;
         }
-        return queue_reduce_wide<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, d_vw, d_seg3, (char*)h_win, p0.win_bytes, st);
+        return queue_reduce_wide<F>(c, jobs, n_jobs, p0.g1.nb, d_vw, d_seg3, d_seg2, (char*)h_win, p0.win_bytes, st);
     }
     return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
 }

@@ -54,6 +54,10 @@ LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
 MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
 # issue cycles of one mixed addition at the kernel's 2 waves/SIMD (220 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
 MADD_CYCLES_2WAVES = 3542 * 4.77 + 126 * 4.70 + 468 * 4.45 + 627 * 2.64
+# measured on MI355X (tools/experiments/clock_probe.hip, profiles/r02_clock_probe.txt): what a stream of nothing but independent
+# v_mad_u64_u32 reaches, by HIP events, at 2 and at 8 waves per SIMD -- the nominal 16 lanes x 1024 SIMDs x 2.4 GHz is 3.93e13
+PURE_MAD_RATE_2_WAVES = 2.66e13
+PURE_MAD_RATE_8_WAVES = 3.41e13
 CURVE_TITLE = {"bls12_381": "BLS12-381", "bn254": "BN254"}
 
 
@@ -451,7 +455,11 @@ def main():
         bound2 = LANES * CLOCK_HZ / MADD_CYCLES_2WAVES
         valu = {"mixed_adds_per_scalar": W, "mixed_adds_per_s": madds / avg_s, "u32_mac_per_s": mac_s, "peak_u32_mac_per_s": peak_mac_s,
                 "frac_of_mad_peak": mac_s / peak_mac_s,
-                "issue_bound_mixed_adds_per_s_at_2_waves_per_simd": bound2, "frac_of_issue_bound": madds / avg_s / bound2}
+                "issue_bound_mixed_adds_per_s_at_2_waves_per_simd": bound2, "frac_of_issue_bound": madds / avg_s / bound2,
+                "mads_vs_measured_pure_mad_stream_at_2_waves_per_simd": mac_s / PURE_MAD_RATE_2_WAVES,
+                "mads_vs_measured_pure_mad_stream_at_8_waves_per_simd": mac_s / PURE_MAD_RATE_8_WAVES,
+                "note": "the kernel issues 1221 other vector instructions per 3542 mads on top of this mad rate; a 3-waves-per-SIMD variant "
+                        "(166 VGPRs) was measured no faster: bound by the vector pipe at the clock the chip holds, not by occupancy (profiles/r02_notes.md)"}
     kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
     S = r["streams"]
     if world == 1:

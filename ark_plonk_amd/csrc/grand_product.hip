@@ -7,8 +7,8 @@
 //     z[0] = 1,   z[i+1] = z[i] * num_i / den_i,   the (n+1)-th value dropped.
 // Here, with PN_i = prod_{j<i} num_j, SD_i = prod_{j>=i} den_j and T = prod_j den_j:
 //     z[i] = PN_i / prod_{j<i} den_j = PN_i * SD_i * T^-1
-// i.e. two product scans (prefix of num, suffix of den: chunk products -> one-workgroup scan of the
-// chunk products -> per-chunk replay), ONE field inversion on the host, one elementwise product.
+// i.e. two product scans (prefix of num, suffix of den: wave-level scans of 256 positions -> one-workgroup scan of the
+// tile totals), ONE field inversion on the host, one elementwise product that also applies the tile carries.
 // Field elements are canonical Montgomery residues, so the result is bit-identical with the serial loop.
 // A zero denominator makes the reference panic (`inverse().unwrap()`); here it is ZK_ERR_NOT_INVERTIBLE.
 #include "ctx.h"
@@ -33,8 +33,6 @@ ZK_D void st_fr(void* base, uint64_t idx, const Fr& r) {
 
 constexpr uint32_t TERM_T = 256;     // lanes per workgroup of the term kernels
 constexpr uint32_t TERM_ROWS = 8;    // rows per lane (row = blk*T*ROWS + j*T + lane: coalesced)
-constexpr uint32_t CHUNK = 64;       // rows per lane in the scan phases
-constexpr uint32_t SCAN_T = 1024;    // lanes of the single scan workgroup
 
 template <class Fr>
 struct PermArgs {
@@ -92,133 +90,134 @@ __global__ void __launch_bounds__(TERM_T) gp_lookup_terms(LookupArgs<Fr> a, uint
     st_fr<Fr>(D, i, den);
 }
 
-// The numerator scan (prefix) and the denominator scan (suffix) are independent and latency-bound (a few hundred
-// wavefronts walking dependent products): every phase handles both in ONE launch, blockIdx.y = 0 numerators, 1 denominators.
+// Round 2: the scans are latency-bound (a few hundred wavefronts walking dependent products), so the dependent chain is what
+// to cut.  Numerators need exclusive PREFIX products, denominators inclusive SUFFIX products; a suffix over i is a prefix over the
+// mirrored position n-1-i, so both run the same code, blockIdx.y = 0 numerators, 1 denominators:
+//   gp_wave_scan    a wavefront owns 256 logical positions (4 per lane): 3 serial products per lane, a 6-step shuffle scan of
+//                   the lane totals, 4 products to place the results -- 13 dependent products -- and its total goes to P[tile]
+//   gp_scan_tiles   one workgroup per array scans the tile totals (prefix)
+//   gp_combine      z[i] = (carryN * locN_i) * (carryD * locD_i) * T^-1, elementwise
+// 13 + ~18 + 4 dependent products instead of the 64 + 42 + 64 of the chunked version of round 1.
+constexpr uint32_t WS_PER = 4;                 // positions per lane
+constexpr uint32_t WS_TILE = 64 * WS_PER;      // positions per wavefront
+constexpr uint32_t SCAN_T = 1024;              // lanes of the tile-total scan workgroup
+
 struct GpPair {
-    void* x[2];        // the two vectors (scanned in place)
-    void* p[2];        // chunk products
-    void* a[2];        // chunk carries (+ total)
+    void* x[2];        // numerators / denominators, scanned in place
+    void* p[2];        // tile totals
+    void* a[2];        // tile carries (+ total)
 };
 
-// phase 1: P[c] = prod of chunk c
 template <class Fr>
-__global__ void gp_chunk_prod(GpPair g, uint64_t n, uint64_t n_chunks) {
-    const void* X = g.x[blockIdx.y];
-    void* P = g.p[blockIdx.y];
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
-    Fr acc = ld_fr<Fr>(X, lo);
-    for (uint64_t i = lo + 1; i < hi; ++i) acc = Fr::mul(acc, ld_fr<Fr>(X, i));
-    st_fr<Fr>(P, c, acc);
+ZK_D Fr shfl_up_fr(const Fr& v, int d) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) r.v[i] = __shfl_up(v.v[i], d, 64);
+    return r;
 }
 
-// phase 2 (one workgroup): A[c] = product of the chunk products before c (suffix == 0) or after c
-// (suffix == 1) -- the value entering chunk c; A[n_chunks] = product of everything.
 template <class Fr>
-__global__ void __launch_bounds__(SCAN_T) gp_scan_chunks(GpPair g, uint64_t n_chunks) {
+__global__ void __launch_bounds__(256) gp_wave_scan(GpPair g, uint64_t n, uint64_t n_tiles) {
+    const uint32_t mirrored = blockIdx.y;                       // 1: logical position q <-> element n-1-q (suffix products)
+    void* X = g.x[mirrored];
+    void* P = g.p[mirrored];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;                                // the whole wavefront leaves together
+    const uint64_t q0 = tile * WS_TILE + (uint64_t)lane * WS_PER;
+    const Fr one = Fr::one();
+    Fr inc[WS_PER];                                             // inclusive products inside the lane
+#pragma unroll
+    for (uint32_t k = 0; k < WS_PER; ++k) {
+        const uint64_t q = q0 + k;
+        const Fr e = q < n ? ld_fr<Fr>(X, mirrored ? n - 1 - q : q) : one;
+        inc[k] = k == 0 ? e : Fr::mul(inc[k - 1], e);
+    }
+    Fr scan = inc[WS_PER - 1];                                  // inclusive scan of the lane totals over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Fr o = shfl_up_fr<Fr>(scan, d);
+        if ((int)lane >= d) scan = Fr::mul(scan, o);
+    }
+    Fr excl = shfl_up_fr<Fr>(scan, 1);                          // product of the lanes before this one
+    if (lane == 0) excl = one;
+#pragma unroll
+    for (uint32_t k = 0; k < WS_PER; ++k) {
+        const uint64_t q = q0 + k;
+        if (q >= n) break;
+        // numerators: exclusive (positions before q); denominators: inclusive (mirrored positions up to q = elements from i on)
+        const Fr v = mirrored ? Fr::mul(excl, inc[k]) : (k == 0 ? excl : Fr::mul(excl, inc[k - 1]));
+        st_fr<Fr>(X, mirrored ? n - 1 - q : q, v);
+    }
+    if (lane == 63) st_fr<Fr>(P, tile, scan);
+}
+
+// one workgroup per array: A[c] = product of the tile totals before c;  A[n_tiles] = product of everything
+template <class Fr>
+__global__ void __launch_bounds__(SCAN_T) gp_scan_tiles(GpPair g, uint64_t n_tiles) {
     extern __shared__ uint4 sh[];
     const void* P = g.p[blockIdx.x];
     void* A = g.a[blockIdx.x];
-    const int suffix = (int)blockIdx.x;       // numerators: prefix products; denominators: suffix products
     const uint32_t u = threadIdx.x;
-    const uint64_t per = (n_chunks + SCAN_T - 1) / SCAN_T;
-    const uint64_t lo = (uint64_t)u * per < n_chunks ? (uint64_t)u * per : n_chunks;
-    const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
+    const uint64_t per = (n_tiles + SCAN_T - 1) / SCAN_T;
+    const uint64_t lo = (uint64_t)u * per < n_tiles ? (uint64_t)u * per : n_tiles;
+    const uint64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
     Fr loc = Fr::one();
     for (uint64_t c = lo; c < hi; ++c) loc = Fr::mul(loc, ld_fr<Fr>(P, c));
-    // inclusive Hillis-Steele scan of the lane products (towards lane 0 for suffix, towards the last lane else)
-    Fr inc = loc;
+    Fr inc = loc;                                               // inclusive Hillis-Steele scan of the lane products
     for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
         st_fr<Fr>(sh, u, inc);
         __syncthreads();
-        const bool has = suffix ? (u + d < SCAN_T) : (u >= d);
-        if (has) inc = Fr::mul(inc, ld_fr<Fr>(sh, suffix ? u + d : u - d));
+        if (u >= d) inc = Fr::mul(inc, ld_fr<Fr>(sh, u - d));
         __syncthreads();
     }
     st_fr<Fr>(sh, u, inc);
     __syncthreads();
-    Fr carry = Fr::one();
-    if (suffix) {
-        if (u + 1 < SCAN_T) carry = ld_fr<Fr>(sh, u + 1);
-        for (uint64_t c = hi; c-- > lo;) {
-            st_fr<Fr>(A, c, carry);
-            carry = Fr::mul(carry, ld_fr<Fr>(P, c));
-        }
-        if (u == 0) st_fr<Fr>(A, n_chunks, inc);
-    } else {
-        if (u >= 1) carry = ld_fr<Fr>(sh, u - 1);
-        for (uint64_t c = lo; c < hi; ++c) {
-            st_fr<Fr>(A, c, carry);
-            carry = Fr::mul(carry, ld_fr<Fr>(P, c));
-        }
-        if (u == SCAN_T - 1) st_fr<Fr>(A, n_chunks, inc);
+    Fr carry = u >= 1 ? ld_fr<Fr>(sh, u - 1) : Fr::one();
+    for (uint64_t c = lo; c < hi; ++c) {
+        st_fr<Fr>(A, c, carry);
+        carry = Fr::mul(carry, ld_fr<Fr>(P, c));
     }
+    if (u == SCAN_T - 1) st_fr<Fr>(A, n_tiles, inc);
 }
 
-// phase 3, in place: exclusive prefix products (suffix == 0: X[i] <- prod_{j<i}) or inclusive suffix
-// products (suffix == 1: X[i] <- prod_{j>=i})
+// z[i] = PN_i * SD_i * T^-1 with PN_i = carryN[tile(i)] * locN_i and SD_i = carryD[tile(n-1-i)] * locD_i
 template <class Fr>
-__global__ void gp_apply(GpPair g, uint64_t n, uint64_t n_chunks) {
-    void* X = g.x[blockIdx.y];
-    const void* A = g.a[blockIdx.y];
-    const int suffix = (int)blockIdx.y;
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t lo = c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
-    Fr carry = ld_fr<Fr>(A, c);
-    if (suffix) {
-        for (uint64_t i = hi; i-- > lo;) {
-            carry = Fr::mul(carry, ld_fr<Fr>(X, i));
-            st_fr<Fr>(X, i, carry);
-        }
-    } else {
-        for (uint64_t i = lo; i < hi; ++i) {
-            Fr x = ld_fr<Fr>(X, i);
-            st_fr<Fr>(X, i, carry);
-            carry = Fr::mul(carry, x);
-        }
-    }
-}
-
-// z[i] = PN_i * SD_i * T^-1
-template <class Fr>
-__global__ void gp_combine(const void* PN, const void* SD, Fr inv_t, uint64_t n, void* out) {
+__global__ void gp_combine(GpPair g, Fr inv_t, uint64_t n, void* out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    st_fr<Fr>(out, i, Fr::mul(Fr::mul(ld_fr<Fr>(PN, i), ld_fr<Fr>(SD, i)), inv_t));
+    const Fr pn = Fr::mul(ld_fr<Fr>(g.a[0], i / WS_TILE), ld_fr<Fr>(g.x[0], i));
+    const Fr sd = Fr::mul(ld_fr<Fr>(g.a[1], (n - 1 - i) / WS_TILE), ld_fr<Fr>(g.x[1], i));
+    st_fr<Fr>(out, i, Fr::mul(Fr::mul(pn, sd), inv_t));
 }
 
 // N (numerators) and D (denominators) are in c->io_a / c->io_b; finishes the product into d_out
 template <class Fr>
 int finish_product(zk_ctx* c, uint64_t n, void* d_out, uint64_t* last_mont) {
-    void* N = c->io_a.p;
-    void* D = c->io_b.p;
-    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    const uint64_t n_tiles = (n + WS_TILE - 1) / WS_TILE;
     int rc;
-    // chunk products | chunk carries (+ total), for N then D
-    if ((rc = c->msm_tmp.ensure(4 * (n_chunks + 1) * 32))) return rc;
+    // tile totals | tile carries (+ total), for N then D
+    if ((rc = c->msm_tmp.ensure(4 * (n_tiles + 1) * 32))) return rc;
     char* t = (char*)c->msm_tmp.p;
-    void *PNc = t, *ANc = t + (n_chunks + 1) * 32, *PDc = t + 2 * (n_chunks + 1) * 32, *ADc = t + 3 * (n_chunks + 1) * 32;
-    hipStream_t st = c->stream;
-    const int T = 256;
-    const unsigned cb = (unsigned)((n_chunks + T - 1) / T);
-    const size_t shmem = (size_t)SCAN_T * 32;
     GpPair g;
-    g.x[0] = N; g.x[1] = D;
-    g.p[0] = PNc; g.p[1] = PDc;
-    g.a[0] = ANc; g.a[1] = ADc;
-    hipLaunchKernelGGL(gp_chunk_prod<Fr>, dim3(cb, 2), dim3(T), 0, st, g, n, n_chunks);
-    hipLaunchKernelGGL(gp_scan_chunks<Fr>, dim3(2), dim3(SCAN_T), shmem, st, g, n_chunks);
+    g.x[0] = c->io_a.p;
+    g.x[1] = c->io_b.p;
+    g.p[0] = t;
+    g.a[0] = t + (n_tiles + 1) * 32;
+    g.p[1] = t + 2 * (n_tiles + 1) * 32;
+    g.a[1] = t + 3 * (n_tiles + 1) * 32;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(gp_wave_scan<Fr>, dim3((unsigned)((n_tiles + 3) / 4), 2), dim3(256), 0, st, g, n, n_tiles);
+    hipLaunchKernelGGL(gp_scan_tiles<Fr>, dim3(2), dim3(SCAN_T), (size_t)SCAN_T * 32, st, g, n_tiles);
     ZK_HIP_TRY(hipGetLastError());
     Fr tot[2];   // total numerator product, total denominator product
-    ZK_HIP_TRY(hipMemcpyAsync(&tot[0], (char*)ANc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
-    ZK_HIP_TRY(hipMemcpyAsync(&tot[1], (char*)ADc + n_chunks * 32, 32, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(gp_apply<Fr>, dim3(cb, 2), dim3(T), 0, st, g, n, n_chunks);
+    ZK_HIP_TRY(hipMemcpyAsync(&tot[0], (char*)g.a[0] + n_tiles * 32, 32, hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipMemcpyAsync(&tot[1], (char*)g.a[1] + n_tiles * 32, 32, hipMemcpyDeviceToHost, st));
     ZK_HIP_TRY(hipStreamSynchronize(st));
     if (tot[1].is_zero()) return ZK_ERR_NOT_INVERTIBLE;
     Fr inv_t = Fr::inverse(tot[1]);
-    hipLaunchKernelGGL(gp_combine<Fr>, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, N, D, inv_t, n, d_out);
+    const int T = 256;
+    hipLaunchKernelGGL(gp_combine<Fr>, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, g, inv_t, n, d_out);
     ZK_HIP_TRY(hipGetLastError());
     if (last_mont) {
         Fr last = Fr::mul(tot[0], inv_t);

@@ -6,6 +6,8 @@
 //   zk::DeviceVec               -- device-resident Fr vector (what stays on the GPU between fft and commit)
 //   zk::permutation_evals / lookup_permutation_evals / quotient_evals
 //                               <- permutation/mod.rs:652-822, quotient_poly.rs:34-178
+//   zk::Transcript              <- merlin::Transcript + TranscriptProtocol (transcript.rs:16-49); zk::serialize(...) <- ark-serialize
+//                                  encodings of Fr / G1Affine
 // The reference is Rust and infallible at these call sites; here failures throw zk::Error.
 #pragma once
 #include <cstdint>
@@ -214,6 +216,53 @@ class CommitterKey {
     Context* ctx_;
     int curve_;
     zk_srs* h_ = nullptr;
+};
+
+// ark-serialize 0.3 CanonicalSerialize (compressed) of a commitment / a scalar
+inline std::vector<uint8_t> serialize(const G1Affine& p, int curve = ZK_CURVE_BLS12_381) {
+    std::vector<uint8_t> out(zk_g1_compressed_size(curve));
+    check(zk_g1_serialize_compressed(curve, p.xy.data(), p.infinity ? 1 : 0, out.data()), "zk_g1_serialize_compressed");
+    return out;
+}
+inline std::vector<uint8_t> serialize_fr(const uint64_t* fr_mont, int curve = ZK_CURVE_BLS12_381) {
+    std::vector<uint8_t> out(zk_fr_serialized_size(curve));
+    check(zk_fr_serialize(curve, fr_mont, out.data()), "zk_fr_serialize");
+    return out;
+}
+
+// merlin::Transcript with plonk-core's TranscriptProtocol on top (transcript.rs:16-49)
+class Transcript {
+  public:
+    explicit Transcript(const std::string& label, int curve = ZK_CURVE_BLS12_381)
+        : h_(zk_transcript_new((const uint8_t*)label.data(), label.size())), curve_(curve) {
+        if (!h_) throw Error(ZK_ERR_BAD_ARG, "zk_transcript_new");
+    }
+    Transcript(const Transcript& o) : h_(zk_transcript_clone(o.h_)), curve_(o.curve_) {      // prover.rs:179 clones the preprocessed one
+        if (!h_) throw Error(ZK_ERR_BAD_ARG, "zk_transcript_clone");
+    }
+    Transcript& operator=(const Transcript&) = delete;
+    ~Transcript() { zk_transcript_free(h_); }
+    void append_message(const std::string& label, const std::vector<uint8_t>& msg) {
+        check(zk_transcript_append_message(h_, (const uint8_t*)label.data(), label.size(), msg.data(), msg.size()), "zk_transcript_append_message");
+    }
+    void append(const std::string& label, const G1Affine& commitment) {
+        check(zk_transcript_append_g1(h_, curve_, (const uint8_t*)label.data(), label.size(), commitment.xy.data(), commitment.infinity ? 1 : 0),
+              "zk_transcript_append_g1");
+    }
+    void append(const std::string& label, const uint64_t* fr_mont) {
+        check(zk_transcript_append_fr(h_, curve_, (const uint8_t*)label.data(), label.size(), fr_mont), "zk_transcript_append_fr");
+    }
+    // challenge_scalar: 31 challenge bytes read as a little-endian integer, returned in Montgomery form
+    std::vector<uint64_t> challenge_scalar(const std::string& label) {
+        std::vector<uint64_t> out(4);
+        check(zk_transcript_challenge_scalar(h_, curve_, (const uint8_t*)label.data(), label.size(), out.data()), "zk_transcript_challenge_scalar");
+        return out;
+    }
+    void circuit_domain_sep(uint64_t n) { check(zk_transcript_circuit_domain_sep(h_, n), "zk_transcript_circuit_domain_sep"); }
+
+  private:
+    zk_transcript* h_;
+    int curve_;
 };
 
 // Permutation::compute_permutation_poly up to its ifft (permutation/mod.rs:652-747): z over the domain

@@ -53,7 +53,27 @@ int main(int argc, char** argv) {
         auto round = ck.commit_round({&d_coeffs, &d_coeffs});
         std::printf("commit_round %s\n", (round[0].xy == single.xy && round[1].xy == single.xy && !single.infinity) ? "ok" : "MISMATCH");
         print("commit_x", single.xy, 6);
-        return (back == ev && round[0].xy == single.xy) ? 0 : 1;
+        // the unchanged caller's PC::commit(ck, polys): host vectors, one call for the whole slice (prover.rs:213)
+        auto host_round = ck.commit({&coeffs, &ev, &coeffs});
+        zk::CommitterKey again(ctx, srs);                 // PC::trim on the next gen_proof: the same bytes -> the resident SRS and table
+        auto ev_commit = again.commit(ev);
+        std::printf("host_batch %s\n", (host_round[0].xy == single.xy && host_round[2].xy == single.xy && host_round[1].xy == ev_commit.xy) ? "ok" : "MISMATCH");
+        // round 1 of the prover's transcript: four wire commitments in, zeta out (prover.rs:217-226)
+        zk::Transcript pre("example");
+        pre.circuit_domain_sep(n);
+        zk::Transcript t(pre);
+        t.append("w_l", single);
+        t.append("w_r", ev_commit);
+        t.append("w_o", single);
+        t.append("w_4", ev_commit);
+        auto zeta = t.challenge_scalar("zeta");
+        t.append("zeta", zeta.data());
+        print("zeta", zeta, 4);
+        auto enc = zk::serialize(single);
+        std::printf("commit_ser");
+        for (uint8_t b : enc) std::printf(" %02x", b);
+        std::printf("\n");
+        return (back == ev && round[0].xy == single.xy && host_round[0].xy == single.xy) ? 0 : 1;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 2;

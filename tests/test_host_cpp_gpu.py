@@ -40,7 +40,7 @@ def test_cpp_example_matches_python_mirror(tmp_path, ctx):
     run = subprocess.run([exe, str(log_n)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     lines = dict(ln.split(" ", 1) for ln in run.stdout.strip().splitlines())
-    assert lines["roundtrip"] == "ok" and lines["commit_round"] == "ok"
+    assert lines["roundtrip"] == "ok" and lines["commit_round"] == "ok" and lines["host_batch"] == "ok"
     n = 1 << log_n
     ev = _inputs(n)
     dom = zk.Radix2EvaluationDomain.new(n, 0, ctx)
@@ -54,5 +54,16 @@ def test_cpp_example_matches_python_mirror(tmp_path, ctx):
     _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, torch.from_numpy(ks.view(np.int64)).cuda().data_ptr(), n, bases.data_ptr()))
     ck = zk.CommitterKey(bases, 0, ctx)
     cm = ck.commit(coeffs)
+    cm_ev = ck.commit(torch.from_numpy(ev.view(np.int64)).cuda())
     ck.close()
     assert lines["commit_x"].split() == [f"{int(v):016x}" for v in cm.x]
+    # the C++ Transcript / serialize mirror against the Python one (both over the C ABI) on the same commitments
+    from ark_plonk_amd import transcript as tr
+    pre = tr.Transcript(b"example", 0)
+    pre.circuit_domain_sep(n)
+    t = pre.clone()
+    for lb, pt in (("w_l", cm), ("w_r", cm_ev), ("w_o", cm), ("w_4", cm_ev)):
+        t.append(lb, pt)
+    zeta = t.challenge_scalar("zeta")
+    assert lines["zeta"].split() == [f"{int(v):016x}" for v in zeta]
+    assert bytes(int(b, 16) for b in lines["commit_ser"].split()) == tr.g1_serialize(cm, 0)

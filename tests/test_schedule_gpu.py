@@ -71,3 +71,50 @@ def test_schedule_with_device_quotient(ctx):
     same = [a == b for a, b in zip(base, q)]
     assert all(same[:9]) and not any(same[9:13]) and all(same[13:])
     ck.close()
+
+
+def test_config1_plumbing_size_end_to_end_vs_cpu_oracle(ctx, oracle_cpu):
+    """BASELINE config 1 (examples/simple_circuit.rs: padded size 2^9, SRS of 2^10): the whole per-proof schedule on the GPU --
+    31 transforms, 27 commitments, 2 openings, per-window MSM path (the SRS is below the table threshold) -- against the same
+    schedule recomputed with the CPU restatement of the ark 0.3 algorithms: all 29 points equal."""
+    import torch
+    cid, log_n = 0, 9
+    n = 1 << log_n
+    cv = zk.get_curve(cid)
+    ks = np.zeros((2 * n, 4), dtype=np.uint64)
+    ks[:, 0] = 7 + 5 * np.arange(2 * n, dtype=np.uint64)
+    bases = torch.empty((2 * n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, torch.from_numpy(ks.view(np.int64)).cuda().data_ptr(), 2 * n, bases.data_ptr()))
+    ck = zk.CommitterKey(bases, cv, ctx)
+    sched = ProofSchedule(log_n, ctx, ck, cv)
+    got = sched.run_once(proof_id=0)
+    srs_h = bases.cpu().numpy().view(np.uint64)
+    H = lambda t: t.cpu().numpy().view(np.uint64)          # noqa: E731
+    ifft = lambda e: oracle_cpu.ntt(cid, 1, log_n, H(e))   # noqa: E731
+    c = [ifft(sched.evals[i]) for i in range(4)]
+    c += [ifft(sched.aux_evals[k]) for k in range(6)]       # table f h1 h2 z z2
+    c.append(ifft(sched.aux_evals[6]))                       # pi
+    c.append(ifft(sched.aux_evals[7]))                       # l1 (stands in for lin)
+    t = oracle_cpu.ntt(cid, 3, log_n + 2, H(sched.quot))
+    sig = [H(s) for s in sched.sigma]
+    commit = lambda p: oracle_cpu.kzg_commit(cid, srs_h, p)  # noqa: E731
+
+    def opening(polys):
+        comb = np.zeros((n, 4), dtype=np.uint64)
+        chi_pow = oracle_cpu.convert(cid, "fr", True, np.array([[1, 0, 0, 0]], dtype=np.uint64))
+        for p in polys:
+            term = oracle_cpu.fr_op(cid, "mul", p, np.repeat(chi_pow, p.shape[0], axis=0))
+            comb[: p.shape[0]] = oracle_cpu.fr_op(cid, "add", comb[: p.shape[0]], term)
+            chi_pow = oracle_cpu.fr_op(cid, "mul", chi_pow, sched.chi_mont.reshape(1, 4))
+        return commit(oracle_cpu.kzg_witness(cid, comb, sched.z_mont))
+
+    aw = [c[11], sig[0], sig[1], sig[2], c[5], c[7], c[4]]
+    saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]
+    exp = [commit(p) for p in c[:4]] + [commit(c[5]), commit(c[6]), commit(c[7]), commit(c[8]), commit(c[9])]
+    exp += [commit(t[i * n:(i + 1) * n]) for i in range(4)]
+    exp += [commit(p) for p in aw] + [opening(aw + c[:4])] + [commit(p) for p in saw] + [opening(saw)]
+    assert len(exp) == 29
+    for k, (g, (xy, inf)) in enumerate(zip(got, exp)):
+        assert g.infinity == bool(inf) and np.array_equal(g.xy(), xy), k
+    ck.close()

@@ -422,10 +422,15 @@ size_t zk_proof_serialized_size(int curve_id, uint32_t n_custom_evals, const uin
 
 int zk_proof_serialize(int curve_id, const zk_proof* p, uint8_t* out, size_t cap, size_t* written) {
     if (!p || !out) return ZK_ERR_BAD_ARG;
+    if (!p->commitments || !p->commitment_inf || !p->openings || !p->opening_inf || !p->evals) return ZK_ERR_BAD_ARG;
+    if (p->n_custom_evals && (!p->custom_labels || !p->custom_evals)) return ZK_ERR_BAD_ARG;
     const size_t g = zk_g1_compressed_size(curve_id), f = zk_fr_serialized_size(curve_id);
     if (!g) return ZK_ERR_BAD_ARG;
     std::vector<uint32_t> ll(p->n_custom_evals);
-    for (uint32_t i = 0; i < p->n_custom_evals; ++i) ll[i] = (uint32_t)strlen(p->custom_labels[i]);
+    for (uint32_t i = 0; i < p->n_custom_evals; ++i) {
+        if (!p->custom_labels[i]) return ZK_ERR_BAD_ARG;
+        ll[i] = (uint32_t)strlen(p->custom_labels[i]);
+    }
     const size_t need = zk_proof_serialized_size(curve_id, p->n_custom_evals, ll.data());
     if (cap < need) return ZK_ERR_BAD_ARG;
     const int L = curve_id == ZK_CURVE_BLS12_381 ? 6 : 4;

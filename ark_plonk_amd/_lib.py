@@ -113,6 +113,8 @@ SYMBOLS = {
                                 c_void_p, c_void_p]),
     "zk_kzg_witness_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
                                    c_void_p, ctypes.POINTER(c_size_t)]),
+    "zk_poly_evaluate_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_poly_lincomb_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_size_t]),
     "zk_g1_fixed_base_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "zk_fr_mul_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "zk_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),

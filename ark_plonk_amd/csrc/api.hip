@@ -873,6 +873,20 @@ int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* co
     return ZK_OK;
 }
 
+int zk_poly_evaluate_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont,
+                         uint64_t* out_mont) {
+    if (!c || (n_polys && (!d_polys || !lens || !points_mont || !out_mont))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return poly_evaluate_dev(c, curve_id, n_polys, d_polys, lens, points_mont, out_mont);
+}
+
+int zk_poly_lincomb_dev(zk_ctx* c, int curve_id, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,
+                        void* d_out, size_t out_len) {
+    if (!c || (n_terms && (!d_polys || !lens || !coeffs_mont)) || (out_len && !d_out)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return poly_lincomb_dev(c, curve_id, n_terms, d_polys, lens, coeffs_mont, d_out, out_len);
+}
+
 int zk_io_stats(zk_ctx* c, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);

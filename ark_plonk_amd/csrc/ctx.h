@@ -321,6 +321,10 @@ int lookup_product_dev(zk_ctx* c, int curve, size_t n, const void* d_f, const vo
                        const uint64_t* delta_mont, const uint64_t* eps_mont, void* d_out, uint64_t* last_mont);
 int quad_selftest_dev(zk_ctx* c, int curve, uint32_t n_quads, uint32_t* out2);
 int quotient_evals_dev(zk_ctx* c, int curve, uint32_t log_n, const zk_quotient_args* q, void* d_out);
+int poly_evaluate_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont,
+                      uint64_t* out_mont);
+int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,
+                     void* d_out, size_t out_len);
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                          const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);
 

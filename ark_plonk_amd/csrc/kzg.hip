@@ -1,5 +1,8 @@
 // KZG10 opening helpers: random linear combination of polynomials and the
-// witness polynomial (p(X) - p(z)) / (X - z), on the device.
+// witness polynomial (p(X) - p(z)) / (X - z), on the device -- and, with the same pieces, the two O(n) operations of the
+// prover's last round (linearisation_poly.rs:164-350): `poly.evaluate(&point)` for the 23 evaluations of a proof
+// (zk_poly_evaluate_dev) and the scalar-weighted sum of ~19 polynomials that is the linearisation polynomial
+// (zk_poly_lincomb_dev).
 //
 // Replaces the CPU work ark-poly-commit 0.3 does inside `PolynomialCommitment::open` before its MSM
 // (reference call sites: proof_system/prover.rs:582-591 -- 11 polynomials at z -- and :609-618 --
@@ -61,7 +64,7 @@ ZK_D void st_l(void* base, uint64_t idx, const FU& x) {
 template <class FU>
 ZK_D FU unpack(const Packed& p) { return FU::split_words(p.w); }
 
-constexpr int MAX_POLYS = 16;
+constexpr int MAX_POLYS = 32;
 struct RlcArgs {
     const void* poly[MAX_POLYS];
     uint64_t len[MAX_POLYS];
@@ -74,7 +77,7 @@ template <class FU>
 __global__ void kzg_rlc(RlcArgs a, uint64_t m, void* comb) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    FU acc = FU::zero();                     // <= 16 terms < 2r each
+    FU acc = FU::zero();                     // <= 32 terms < 2r each
     for (uint32_t k = 0; k < a.n_polys; ++k) {
         if (i < a.len[k]) acc = FU::add(acc, FU::mul(ld_u<FU>(a.poly[k], i), unpack<FU>(a.chi_pow[k])));
     }
@@ -154,6 +157,142 @@ __global__ void kzg_witness(const void* comb, uint64_t m, Packed zp, const void*
     }
 }
 
+// ---- evaluations: out[y] = p_y(z_y) for n_polys polynomials in one launch pair ----------------------------------------
+struct EvalArgs {
+    const void* poly[MAX_POLYS];
+    uint64_t len[MAX_POLYS];
+    Packed z[MAX_POLYS];         // the point of polynomial y, R' form
+    Packed zk[MAX_POLYS];        // z^CHUNK, R' form
+    uint32_t n_polys;
+    uint64_t max_chunks;
+};
+constexpr uint32_t FOLD_T = 256;
+
+// phase 1 (grid: chunks x polys): H[y][t] = sum_{j < CHUNK} c_y[t*CHUNK + j] z_y^j
+template <class FU>
+__global__ void poly_chunk_horner(EvalArgs a, void* H) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    const uint64_t m = a.len[y];
+    if (t * CHUNK >= m) return;
+    const FU z = unpack<FU>(a.z[y]);
+    const uint64_t lo = t * CHUNK;
+    const uint64_t hi = lo + CHUNK < m ? lo + CHUNK : m;
+    FU acc = FU::zero();
+    for (uint64_t j = hi; j-- > lo;) acc = FU::add(ld_u<FU>(a.poly[y], j), FU::mul(acc, z));
+    st_l<FU>(H, (uint64_t)y * a.max_chunks + t, acc);
+}
+
+// phase 2 (one workgroup per polynomial): p(z) = sum_t H[t] (z^CHUNK)^t.  Lane u folds its `per` consecutive chunks by
+// Horner, scales the result by (zk^per)^u (square and multiply on the lane index) and the workgroup adds the lanes up.
+template <class FU>
+__global__ void __launch_bounds__(FOLD_T) poly_chunk_fold(EvalArgs a, const void* H, void* out) {
+    __shared__ uint4 sh[FOLD_T * 3];
+    const uint32_t u = threadIdx.x, y = blockIdx.x;
+    const uint64_t n_chunks = (a.len[y] + CHUNK - 1) / CHUNK;
+    const uint64_t per = (n_chunks + FOLD_T - 1) / FOLD_T;
+    const uint64_t lo = (uint64_t)u * per < n_chunks ? (uint64_t)u * per : n_chunks;
+    const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
+    const FU zk = unpack<FU>(a.zk[y]);
+    FU h = FU::zero();
+    for (uint64_t t = hi; t-- > lo;) h = FU::add(ld_l<FU>(H, (uint64_t)y * a.max_chunks + t), FU::mul(h, zk));
+    // Q = zk^per (the same on every lane), then Q^u
+    FU Q = FU::one(), b = zk;
+    for (uint64_t e = per; e; e >>= 1) {
+        if (e & 1) Q = FU::mul(Q, b);
+        b = FU::mul(b, b);
+    }
+    FU s = FU::one();
+    b = Q;
+    for (uint32_t e = u; e; e >>= 1) {
+        if (e & 1) s = FU::mul(s, b);
+        b = FU::mul(b, b);
+    }
+    h = FU::mul(h, s);                      // < 2r
+    // tree sum; every level re-normalises (x * 1 in the R' form keeps the value, brings it under 2r)
+    st_l<FU>(sh, u, h);
+    for (uint32_t d = FOLD_T / 2; d >= 1; d >>= 1) {
+        __syncthreads();
+        if (u < d) {
+            h = FU::mul(FU::add(h, ld_l<FU>(sh, u + d)), FU::one());
+            st_l<FU>(sh, u, h);
+        }
+    }
+    if (u == 0) st_u<FU>(out, y, h);
+}
+
+template <class C>
+int poly_evaluate(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont, uint64_t* out_mont) {
+    typedef typename C::Fr Fr;
+    typedef typename C::FrU FU;
+    if (n_polys > (uint32_t)MAX_POLYS) return ZK_ERR_UNSUPPORTED;
+    if (n_polys == 0) return ZK_OK;
+    Fr to_rp;
+    FU::one().pack_words(to_rp.v);
+    EvalArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_polys = n_polys;
+    uint64_t m = 0;
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        if (lens[k] && !d_polys[k]) return ZK_ERR_BAD_ARG;
+        Fr z;
+        memcpy(z.v, points_mont + 4 * k, 32);
+        if (Fr::reduce_once(z) != z) return ZK_ERR_BAD_ARG;      // not a reduced field element
+        const Fr zr = Fr::mul(z, to_rp), zkr = Fr::mul(Fr::pow_u64(z, CHUNK), to_rp);
+        memcpy(a.z[k].w, zr.v, 32);
+        memcpy(a.zk[k].w, zkr.v, 32);
+        a.poly[k] = d_polys[k];
+        a.len[k] = lens[k];
+        m = lens[k] > m ? lens[k] : m;
+    }
+    a.max_chunks = (m + CHUNK - 1) / CHUNK;
+    int rc;
+    if ((rc = c->io_b.ensure((size_t)n_polys * (a.max_chunks + 1) * 48 + (size_t)n_polys * 32))) return rc;
+    void* H = c->io_b.p;
+    void* d_out = (char*)c->io_b.p + (size_t)n_polys * (a.max_chunks + 1) * 48;
+    hipStream_t st = c->stream;
+    {
+        ProfScope ps(c, "poly_evaluate");
+        const int T = 128;
+        if (a.max_chunks)
+            hipLaunchKernelGGL(poly_chunk_horner<FU>, dim3((unsigned)((a.max_chunks + T - 1) / T), n_polys), dim3(T), 0, st, a, H);
+        hipLaunchKernelGGL(poly_chunk_fold<FU>, dim3(n_polys), dim3(FOLD_T), 0, st, a, (const void*)H, d_out);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    ZK_HIP_TRY(hipMemcpyAsync(out_mont, d_out, (size_t)n_polys * 32, hipMemcpyDeviceToHost, st));
+    ZK_HIP_TRY(hipStreamSynchronize(st));
+    c->d2h_bytes += (uint64_t)n_polys * 32;
+    return ZK_OK;
+}
+
+template <class C>
+int poly_lincomb(zk_ctx* c, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont, void* d_out, size_t out_len) {
+    typedef typename C::Fr Fr;
+    typedef typename C::FrU FU;
+    if (n_terms > (uint32_t)MAX_POLYS) return ZK_ERR_UNSUPPORTED;
+    if (out_len == 0) return ZK_OK;
+    Fr to_rp;
+    FU::one().pack_words(to_rp.v);
+    RlcArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_polys = n_terms;
+    for (uint32_t k = 0; k < n_terms; ++k) {
+        if (lens[k] && !d_polys[k]) return ZK_ERR_BAD_ARG;
+        Fr cf;
+        memcpy(cf.v, coeffs_mont + 4 * k, 32);
+        if (Fr::reduce_once(cf) != cf) return ZK_ERR_BAD_ARG;
+        const Fr r = Fr::mul(cf, to_rp);
+        memcpy(a.chi_pow[k].w, r.v, 32);
+        a.poly[k] = d_polys[k];
+        a.len[k] = lens[k] < out_len ? lens[k] : out_len;
+    }
+    ProfScope ps(c, "poly_lincomb");
+    const int T = 256;
+    hipLaunchKernelGGL(kzg_rlc<FU>, dim3((unsigned)((out_len + T - 1) / T)), dim3(T), 0, c->stream, a, (uint64_t)out_len, d_out);
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 template <class C>
 int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
                  const uint64_t* chal_mont, void** d_w, size_t* wlen) {
@@ -211,6 +350,20 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
 }
 
 }  // namespace
+
+int poly_evaluate_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont,
+                      uint64_t* out_mont) {
+    if (curve == ZK_CURVE_BLS12_381) return poly_evaluate<CurveBls>(c, n_polys, d_polys, lens, points_mont, out_mont);
+    if (curve == ZK_CURVE_BN254) return poly_evaluate<CurveBn>(c, n_polys, d_polys, lens, points_mont, out_mont);
+    return ZK_ERR_BAD_ARG;
+}
+
+int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,
+                     void* d_out, size_t out_len) {
+    if (curve == ZK_CURVE_BLS12_381) return poly_lincomb<CurveBls>(c, n_terms, d_polys, lens, coeffs_mont, d_out, out_len);
+    if (curve == ZK_CURVE_BN254) return poly_lincomb<CurveBn>(c, n_terms, d_polys, lens, coeffs_mont, d_out, out_len);
+    return ZK_ERR_BAD_ARG;
+}
 
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                          const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen) {

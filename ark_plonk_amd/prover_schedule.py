@@ -29,7 +29,7 @@ class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
-                 ntt_batch: bool = True):
+                 ntt_batch: bool = True, linearisation: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -58,6 +58,11 @@ class ProofSchedule:
         # the 4n quotient evaluations computed on the device from the 13 coset-FFT outputs
         # and (synthetic) prover-key evaluations instead of taken as a synthetic input
         self.quotient = quotient
+        # round 5 before its commitments (linearisation_poly.rs:164-350): the 23 evaluations of the proof and the 19-term
+        # linearisation polynomial computed on the device from the round's polynomials and (synthetic) prover-key
+        # polynomials, instead of a stand-in polynomial being committed as `lin`
+        self.linearisation = linearisation
+        self.last_evals = None
         # Independent transforms the reference issues back to back go out as ONE zk_ntt_batch_dev (one launch per pass,
         # blockIdx.y = polynomial): the four wire iffts (prover.rs:196-203), h_1 / h_2 (prover.rs:302-305), the four sigma ffts
         # (permutation/mod.rs:671-674) and the twelve coset ffts of quotient_poly.rs:72-120.  ntt_batch=False issues them one by one,
@@ -110,6 +115,13 @@ class ProofSchedule:
             self.sigma4n = [rnd(4 * n) for _ in range(4)]
             self.q_chal = {name: np.array([0x1111 * (k + 1), 0x2222, 0x3333, 0x0444], dtype=np.uint64)
                            for k, name in enumerate(__import__("ark_plonk_amd.quotient", fromlist=["CHALLENGES"]).CHALLENGES)}
+        if linearisation:
+            from . import linearisation as lin_mod
+            self.key_polys = {name: rnd(n) for name in lin_mod.KEY_POLYS[:12]}       # selector polynomials of the prover key
+            for k, name in enumerate(lin_mod.KEY_POLYS[12:]):
+                self.key_polys[name] = self.sigma[k]
+            self.lin_chal = {name: np.array([0x1357 * (k + 1), 0x2468, 0x3579, 0x0123], dtype=np.uint64)
+                             for k, name in enumerate(lin_mod.CHALLENGES)}
         # shard of the SRS this rank owns
         self.lo = rank * n // world
         self.hi = (rank + 1) * n // world
@@ -229,7 +241,13 @@ class ProofSchedule:
         out += self._commit_round([t[i * n:(i + 1) * n] for i in range(4)], labels=["t1", "t2", "t3", "t4"])   # t_1..t_4 (prover.rs:455-469)
         # Round 5 (prover.rs:569-618): aw commits (7), opening of the 7 + 4 wire polynomials at z, saw commits (7),
         # opening at z*omega.  aw = [lin, sigma_1..3 of the prover key, f, h_2, table]; saw = [z, w_l, w_r, w_4, h_1, z_2, table]
-        aw = [c[11], self.sigma[0], self.sigma[1], self.sigma[2], c[5], c[7], c[4]]      # c[11] stands in for lin_poly
+        lin_poly = c[11]                                                                  # c[11] stands in for lin_poly ...
+        if self.linearisation:                                                            # ... unless it is computed (prover.rs:485-555)
+            from . import linearisation as lin_mod
+            lin_poly, self.last_evals = lin_mod.compute(d, self.key_polys, dict(self.lin_chal, z_challenge=self.z_mont), {
+                "w_l": c[0], "w_r": c[1], "w_o": c[2], "w_4": c[3], "t_1": t[0:n], "t_2": t[n:2 * n], "t_3": t[2 * n:3 * n], "t_4": t[3 * n:4 * n],
+                "z": c[8], "z2": c[9], "f": c[5], "h1": c[6], "h2": c[7], "table": c[4]})
+        aw = [lin_poly, self.sigma[0], self.sigma[1], self.sigma[2], c[5], c[7], c[4]]
         aw_labels = ["lin", "sigma1", "sigma2", "sigma3", "f", "h2", "table"]
         aw_open = aw + [c[0], c[1], c[2], c[3]]   # prover.rs:582-591
         saw = [c[8], c[0], c[1], c[3], c[6], c[9], c[4]]

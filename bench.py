@@ -287,7 +287,7 @@ def main():
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
-                kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, fuse_round5=args.fuse_round5,
+                kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, fuse_round5=args.fuse_round5,
                           data=args.data, ntt_batch=not args.no_ntt_batch)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
@@ -349,11 +349,11 @@ def main():
                 lanes[0]["sched"].run_once()
             barrier()
             ctx.profile(False)
-            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient"):
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb"):
                 prof[k] = ctx.profile_get(k)
             prof["breakdown_accumulate"] = ctx.profile_get("msm_accumulate")
         else:
-            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "breakdown_accumulate"):
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb", "breakdown_accumulate"):
                 prof[k] = (0.0, 0)
         digs = []
         if args.check:
@@ -552,8 +552,12 @@ def main():
             r5 = timed_region(False, 1, k2, warmup=1, glue=True)
             return {"proofs_per_s": k2 / r5["dt"], "ms_per_proof": r5["dt"] / k2 * 1e3,
                     "quotient_ms_per_proof": r5["prof"]["quotient"][0] / max(r5["kb"], 1), "grand_product_ms_per_proof": r5["prof"]["grand_product"][0] / max(r5["kb"], 1),
-                    "what": "SURVEY.md 8f N1 + N2 inside the step: z and z2 built on the device (zk_perm_product_dev / zk_lookup_product_dev) and the 4n quotient "
-                            "evaluations computed on the device (zk_quotient_evals_dev) from the 12 coset-fft outputs, instead of taken as synthetic inputs"}
+                    "evaluations_ms_per_proof": r5["prof"]["poly_evaluate"][0] / max(r5["kb"], 1),
+                    "linearisation_ms_per_proof": r5["prof"]["poly_lincomb"][0] / max(r5["kb"], 1),
+                    "what": "SURVEY.md 8f N1 + N2 and round 5's O(n) work inside the step: z and z2 built on the device (zk_perm_product_dev / "
+                            "zk_lookup_product_dev), the 4n quotient evaluations computed on the device (zk_quotient_evals_dev) from the 12 coset-fft "
+                            "outputs, the 23 evaluations of the proof (zk_poly_evaluate_dev) and the 19-term linearisation polynomial "
+                            "(zk_poly_lincomb_dev; linearisation_poly.rs:164-350) -- instead of synthetic inputs / a stand-in polynomial"}
         leg("with_device_glue", glue_leg)
         if not args.no_precompute:
             def nopre_leg():

@@ -6,6 +6,7 @@
 //   zk::DeviceVec               -- device-resident Fr vector (what stays on the GPU between fft and commit)
 //   zk::permutation_evals / lookup_permutation_evals / quotient_evals
 //                               <- permutation/mod.rs:652-822, quotient_poly.rs:34-178
+//   zk::evaluate / zk::lincomb  <- DensePolynomial::evaluate and the scalar * polynomial sums of linearisation_poly.rs:203-336
 //   zk::Transcript              <- merlin::Transcript + TranscriptProtocol (transcript.rs:16-49); zk::serialize(...) <- ark-serialize
 //                                  encodings of Fr / G1Affine
 // The reference is Rust and infallible at these call sites; here failures throw zk::Error.
@@ -294,6 +295,37 @@ inline DeviceVec lookup_permutation_evals(Context& ctx, int curve, const DeviceV
 inline DeviceVec quotient_evals(const Radix2EvaluationDomain& d, const zk_quotient_args& args) {
     DeviceVec out(d.context(), 4 * d.size());
     check(zk_quotient_evals_dev(d.context().handle(), d.curve(), d.log_size_of_group(), &args, out.data()), "zk_quotient_evals_dev");
+    return out;
+}
+// `DensePolynomial::evaluate` for a batch (linearisation_poly.rs:203-261: 16 polynomials at z, 7 at z*omega): polys[k] at
+// points_mont[4k..4k+4) -> 4 Montgomery limbs per polynomial
+inline std::vector<uint64_t> evaluate(Context& ctx, int curve, const std::vector<const DeviceVec*>& polys, const std::vector<uint64_t>& points_mont) {
+    if (points_mont.size() != 4 * polys.size()) throw Error(ZK_ERR_BAD_ARG, "one point per polynomial");
+    std::vector<const void*> ptrs(polys.size());
+    std::vector<size_t> lens(polys.size());
+    for (size_t k = 0; k < polys.size(); ++k) {
+        ptrs[k] = polys[k]->data();
+        lens[k] = polys[k]->size();
+    }
+    std::vector<uint64_t> out(4 * polys.size());
+    check(zk_poly_evaluate_dev(ctx.handle(), curve, (uint32_t)polys.size(), ptrs.data(), lens.data(), points_mont.data(), out.data()),
+          "zk_poly_evaluate_dev");
+    return out;
+}
+// sum_k coeffs[k] * polys[k]: the `&poly * scalar` / `+` chains of the linearisation polynomial (linearisation_poly.rs:288-336)
+inline DeviceVec lincomb(Context& ctx, int curve, const std::vector<const DeviceVec*>& polys, const std::vector<uint64_t>& coeffs_mont) {
+    if (coeffs_mont.size() != 4 * polys.size()) throw Error(ZK_ERR_BAD_ARG, "one coefficient per polynomial");
+    std::vector<const void*> ptrs(polys.size());
+    std::vector<size_t> lens(polys.size());
+    size_t m = 0;
+    for (size_t k = 0; k < polys.size(); ++k) {
+        ptrs[k] = polys[k]->data();
+        lens[k] = polys[k]->size();
+        m = lens[k] > m ? lens[k] : m;
+    }
+    DeviceVec out(ctx, m);
+    check(zk_poly_lincomb_dev(ctx.handle(), curve, (uint32_t)polys.size(), ptrs.data(), lens.data(), coeffs_mont.data(), out.data(), m),
+          "zk_poly_lincomb_dev");
     return out;
 }
 

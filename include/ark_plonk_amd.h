@@ -234,6 +234,24 @@ int zk_kzg_open(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const uint64_t* cons
 int zk_kzg_witness_dev(zk_ctx* ctx, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                        const uint64_t* z_mont, const uint64_t* challenge_mont, void* d_out, size_t* out_len);
 
+/* ---- the O(n) work of the prover's last round (linearisation_poly.rs:164-350), device-resident ------------------ */
+/* `DensePolynomial::evaluate(&point)` for a batch: out[k] = polys[k](points[k]), k < n_polys <= 32, one launch pair for
+ * the batch.  The reference evaluates 16 polynomials at z and 7 at z*omega per proof (linearisation_poly.rs:203-261: the
+ * ProofEvaluations of proof.rs:41-103).  polys: device pointers to Montgomery coefficient vectors of lens[k] elements
+ * (lens[k] == 0 -> 0); points_mont: n_polys x 4 limbs (host), reduced; out_mont: n_polys x 4 limbs (host), Montgomery,
+ * reduced.  Blocks until the values are in out_mont. */
+int zk_poly_evaluate_dev(zk_ctx* ctx, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
+                         const uint64_t* points_mont, uint64_t* out_mont);
+
+/* out[i] = sum_k coeffs[k] * polys[k][i] for i < out_len (a polynomial shorter than out_len counts as zero-extended, a longer
+ * one is cut): the scalar-times-polynomial sums the reference builds with `&poly * scalar` and `+` -- the linearisation
+ * polynomial (linearisation_poly.rs:288-336 with widget/arithmetic.rs:66-82, permutation.rs:156-291, widget/lookup.rs:154-203,
+ * widget/mod.rs:96-104; 19 terms), the compressed lookup columns (sum zeta^k col_k).  n_terms <= 32; coeffs_mont: n_terms x
+ * 4 limbs (host), reduced (pass the negated scalar for a subtracted term); d_out: device, out_len x 4 limbs, Montgomery,
+ * reduced; may alias one of the inputs.  Queued on the ctx stream (no host synchronisation). */
+int zk_poly_lincomb_dev(zk_ctx* ctx, int curve_id, uint32_t n_terms, const void* const* d_polys, const size_t* lens,
+                        const uint64_t* coeffs_mont, void* d_out, size_t out_len);
+
 /* ---- N2: grand-product builders, feeding the iNTT on device ------------------------ */
 /* Evaluations of the permutation polynomial z over the size-2^log_n domain, i.e. everything
  * `Permutation::compute_permutation_poly` (permutation/mod.rs:652-752) does before its `domain.ifft`:

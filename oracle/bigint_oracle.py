@@ -345,6 +345,47 @@ def _delta4(f, p):
     return f * (f - 1) % p * (f - 2) % p * (f - 3) % p
 
 
+def range_constraint(p, s, a, b, c, d, d_n):
+    """`Range::constraints` (widget/range.rs:47-63): the factor of the range selector, at one point or at the evaluations."""
+    k = s * s % p
+    return (_delta4((c - 4 * d) % p, p) + _delta4((b - 4 * c) % p, p) * k + _delta4((a - 4 * b) % p, p) * k * k
+            + _delta4((d_n - 4 * a) % p, p) * k * k * k) % p * s % p
+
+
+def logic_constraint(p, s, a, b, c, d, a_n, b_n, d_n, q_c):
+    """`Logic::constraints` + `delta_xor_and` (widget/logic.rs:65-133)."""
+    k = s * s % p
+    la, lb, ld, w = (a_n - 4 * a) % p, (b_n - 4 * b) % p, (d_n - 4 * d) % p, c
+    F = w * (w * (4 * w - 18 * (la + lb) + 81) + 18 * (la * la + lb * lb) - 81 * (la + lb) + 83) % p
+    E = (3 * (la + lb + ld) - 2 * F) % p
+    B = q_c * (9 * ld - 3 * (la + lb)) % p
+    return (_delta4(la, p) + _delta4(lb, p) * k + _delta4(ld, p) * k * k + (w - la * lb) * k * k * k + (B + E) * k * k * k * k) % p * s % p
+
+
+def fixed_base_constraint(p, s, a, b, c, d, a_n, b_n, d_n, q_l, q_r, q_c, ca, cd):
+    """`FixedBaseScalarMul::constraints` (widget/ecc/fixed_base_scalar_mul.rs:88-156)."""
+    k = s * s % p
+    bit = (d_n - d - d) % p
+    bit_cons = bit * (bit - 1) % p * (bit + 1) % p
+    y_alpha = (bit * bit * (q_r - 1) + 1) % p
+    x_alpha = q_l * bit % p
+    xy_cons = (bit * q_c - c) * k % p
+    x_acc = ((a_n + a_n * c * a * b * cd) - (x_alpha * b + y_alpha * a)) * k * k % p
+    y_acc = ((b_n - b_n * c * a * b * cd) - (y_alpha * b - ca * x_alpha * a)) * k * k * k % p
+    return (bit_cons + x_acc + y_acc + xy_cons) % p * s % p
+
+
+def curve_add_constraint(p, s, a, b, c, d, a_n, b_n, d_n, ca, cd):
+    """`CurveAddition::constraints` (widget/ecc/curve_addition.rs:62-97)."""
+    k = s * s % p
+    x1, x3, y1, y3, x2, y2, x1y2 = a, a_n, b, b_n, c, d, d_n
+    y1x2, y1y2, x1x2 = y1 * x2 % p, y1 * y2 % p, x1 * x2 % p
+    xy = (x1 * y2 - x1y2) % p
+    x3c = ((x1y2 + y1x2) - (x3 + x3 * cd * x1y2 * y1x2)) * k % p
+    y3c = ((y1y2 - ca * x1x2) - (y3 - y3 * cd * x1y2 * y1x2)) * k * k % p
+    return (xy + x3c + y3c) % p * s % p
+
+
 def quotient_at(curve: Curve, log_n: int, i: int, col, ch) -> int:
     """One evaluation of the quotient over the 4n coset: plonk-core/src/proof_system/quotient_poly.rs:34-178
     (`compute`) at index i, i.e. (gate_constraints[i] + permutation[i] + lookup[i]) / v_h_coset_4n[i].
@@ -358,37 +399,11 @@ def quotient_at(curve: Curve, log_n: int, i: int, col, ch) -> int:
     q_l, q_r, q_c = col["q_l"][i], col["q_r"][i], col["q_c"][i]
     # -- gate constraints, quotient_poly.rs:182-268
     arith = (a * b * col["q_m"][i] + a * q_l + b * q_r + c * col["q_o"][i] + d * col["q_4"][i] + q_c) % p * col["q_arith"][i] % p  # arithmetic.rs:51-63
-    s = ch["range"]                                                                                     # range.rs:47-63
-    k = s * s % p
-    rng = (_delta4((c - 4 * d) % p, p) + _delta4((b - 4 * c) % p, p) * k + _delta4((a - 4 * b) % p, p) * k * k
-           + _delta4((d_n - 4 * a) % p, p) * k * k * k) % p * s % p * col["q_range"][i] % p
-    s = ch["logic"]                                                                                     # logic.rs:65-133
-    k = s * s % p
-    la, lb, ld, w = (a_n - 4 * a) % p, (b_n - 4 * b) % p, (d_n - 4 * d) % p, c
-    F = w * (w * (4 * w - 18 * (la + lb) + 81) + 18 * (la * la + lb * lb) - 81 * (la + lb) + 83) % p
-    E = (3 * (la + lb + ld) - 2 * F) % p
-    B = q_c * (9 * ld - 3 * (la + lb)) % p
-    logic = (_delta4(la, p) + _delta4(lb, p) * k + _delta4(ld, p) * k * k + (w - la * lb) * k * k * k + (B + E) * k * k * k * k) % p * s % p \
-        * col["q_logic"][i] % p
-    s = ch["fixed"]                                                                                     # ecc/fixed_base_scalar_mul.rs:88-156
-    k = s * s % p
     ca, cd = ch["coeff_a"], ch["coeff_d"]
-    bit = (d_n - d - d) % p
-    bit_cons = bit * (bit - 1) % p * (bit + 1) % p
-    y_alpha = (bit * bit * (q_r - 1) + 1) % p
-    x_alpha = q_l * bit % p
-    xy_cons = (bit * q_c - c) * k % p
-    x_acc = ((a_n + a_n * c * a * b * cd) - (x_alpha * b + y_alpha * a)) * k * k % p
-    y_acc = ((b_n - b_n * c * a * b * cd) - (y_alpha * b - ca * x_alpha * a)) * k * k * k % p
-    fixed = (bit_cons + x_acc + y_acc + xy_cons) % p * s % p * col["q_fixed"][i] % p
-    s = ch["var"]                                                                                       # ecc/curve_addition.rs:62-97
-    k = s * s % p
-    x1, x3, y1, y3, x2, y2, x1y2 = a, a_n, b, b_n, c, d, d_n
-    y1x2, y1y2, x1x2 = y1 * x2 % p, y1 * y2 % p, x1 * x2 % p
-    xy = (x1 * y2 - x1y2) % p
-    x3c = ((x1y2 + y1x2) - (x3 + x3 * cd * x1y2 * y1x2)) * k % p
-    y3c = ((y1y2 - ca * x1x2) - (y3 - y3 * cd * x1y2 * y1x2)) * k * k % p
-    var = (xy + x3c + y3c) % p * s % p * col["q_var"][i] % p
+    rng = range_constraint(p, ch["range"], a, b, c, d, d_n) * col["q_range"][i] % p
+    logic = logic_constraint(p, ch["logic"], a, b, c, d, a_n, b_n, d_n, q_c) * col["q_logic"][i] % p
+    fixed = fixed_base_constraint(p, ch["fixed"], a, b, c, d, a_n, b_n, d_n, q_l, q_r, q_c, ca, cd) * col["q_fixed"][i] % p
+    var = curve_add_constraint(p, ch["var"], a, b, c, d, a_n, b_n, d_n, ca, cd) * col["q_var"][i] % p
     gate = (arith + col["pi"][i] + rng + logic + fixed + var) % p                                        # quotient_poly.rs:262-266
     # -- permutation, proof_system/permutation.rs:62-153
     al, be, ga = ch["alpha"], ch["beta"], ch["gamma"]
@@ -418,6 +433,79 @@ def quotient_at(curve: Curve, log_n: int, i: int, col, ch) -> int:
 
 def quotient_evals(curve: Curve, log_n: int, col, ch) -> list:
     return [quotient_at(curve, log_n, i, col, ch) for i in range(4 << log_n)]
+
+
+LIN_POLYS = ("w_l", "w_r", "w_o", "w_4", "t_1", "t_2", "t_3", "t_4", "z", "z2", "f", "h1", "h2", "table")
+LIN_KEY = ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "q_arith", "q_range", "q_logic", "q_fixed", "q_var", "q_lookup",
+           "sigma0", "sigma1", "sigma2", "sigma3")
+
+
+def poly_scale(poly, s, p):
+    return [c * s % p for c in poly]
+
+
+def poly_add(*polys, p):
+    m = max(len(q) for q in polys)
+    return [sum(q[i] for q in polys if i < len(q)) % p for i in range(m)]
+
+
+def linearisation(curve: Curve, log_n: int, key, polys, ch):
+    """plonk-core/src/proof_system/linearisation_poly.rs:164-350 (`compute`) on canonical integers.
+    key: name -> coefficient list for LIN_KEY (the prover key's polynomials); polys: name -> coefficient list for LIN_POLYS;
+    ch: the challenge dict of quotient_at plus "z" (z_challenge).
+    Returns (coefficients of the linearisation polynomial, evaluations: name -> value with the reference's field names)."""
+    p = curve.r
+    n = 1 << log_n
+    z = ch["z"]
+    zw = z * curve.root_of_unity(log_n) % p                                                   # :200-201
+    ev = lambda name, x: horner((key[name] if name in key else polys[name]), x, p)            # noqa: E731  DensePolynomial::evaluate
+    a, b, c, d = ev("w_l", z), ev("w_r", z), ev("w_o", z), ev("w_4", z)                       # :203-206
+    s1, s2, s3 = ev("sigma0", z), ev("sigma1", z), ev("sigma2", z)                            # :214-219
+    z_next = ev("z", zw)                                                                      # :220
+    q_arith, q_lookup = ev("q_arith", z), ev("q_lookup", z)                                   # :230-233
+    q_c, q_l, q_r = ev("q_c", z), ev("q_l", z), ev("q_r", z)                                  # :236-238
+    a_n, b_n, d_n = ev("w_l", zw), ev("w_r", zw), ev("w_4", zw)                               # :239-241
+    z2_next, h1_e, h1_next, h2_e = ev("z2", zw), ev("h1", z), ev("h1", zw), ev("h2", z)       # :255-258
+    f_e, t_e, t_next = ev("f", z), ev("table", z), ev("table", zw)                            # :259-261
+    vanishing = (pow(z, n, p) - 1) % p                                                        # :267-269
+    z_n = (vanishing + 1) % p
+    l1 = vanishing * pow(n * (z - 1) % p, -1, p) % p                                          # proof.rs:622-633
+    ca, cd = ch["coeff_a"], ch["coeff_d"]
+    # gate constraints, :353-411
+    arith = poly_scale(poly_add(poly_scale(key["q_m"], a * b % p, p), poly_scale(key["q_l"], a, p), poly_scale(key["q_r"], b, p),
+                                poly_scale(key["q_o"], c, p), poly_scale(key["q_4"], d, p), key["q_c"], p=p), q_arith, p)   # arithmetic.rs:66-82
+    rng = poly_scale(key["q_range"], range_constraint(p, ch["range"], a, b, c, d, d_n), p)                                   # widget/mod.rs:96-104
+    logic = poly_scale(key["q_logic"], logic_constraint(p, ch["logic"], a, b, c, d, a_n, b_n, d_n, q_c), p)
+    fixed = poly_scale(key["q_fixed"], fixed_base_constraint(p, ch["fixed"], a, b, c, d, a_n, b_n, d_n, q_l, q_r, q_c, ca, cd), p)
+    var = poly_scale(key["q_var"], curve_add_constraint(p, ch["var"], a, b, c, d, a_n, b_n, d_n, ca, cd), p)
+    gate = poly_add(arith, rng, logic, fixed, var, p=p)
+    # permutation, proof_system/permutation.rs:156-291
+    al, be, ga = ch["alpha"], ch["beta"], ch["gamma"]
+    bz = be * z % p
+    ident = (a + bz + ga) * (b + PERM_K[1] * bz + ga) % p * (c + PERM_K[2] * bz + ga) % p * (d + PERM_K[3] * bz + ga) % p * al % p
+    copy = (a + be * s1 + ga) * (b + be * s2 + ga) % p * (c + be * s3 + ga) % p * (be * z_next % p) % p * al % p
+    perm = poly_add(poly_scale(polys["z"], ident, p), poly_scale(key["sigma3"], -copy % p, p),
+                    poly_scale(polys["z"], l1 * al % p * al % p, p), p=p)
+    # lookup, widget/lookup.rs:154-203
+    de, ep, ze, ls = ch["delta"], ch["epsilon"], ch["zeta"], ch["lookup"]
+    opd = (1 + de) % p
+    e1d = ep * opd % p
+    tuple_ = (a + ze * (b + ze * (c + ze * d))) % p
+    la = poly_scale(key["q_lookup"], (tuple_ - f_e) * ls % p, p)
+    lb = poly_scale(polys["z2"], (opd * (ep + f_e) % p * (e1d + t_e + de * t_next) % p * ls % p * ls + l1 * ls * ls * ls) % p, p)
+    lc_ = poly_scale(polys["h1"], (-z2_next * ls * ls) % p * ((e1d + h2_e + de * h1_next) % p) % p, p)
+    look = poly_add(la, lb, lc_, p=p)
+    # :322-331
+    qt = poly_add(poly_scale(polys["t_4"], z_n, p), polys["t_3"], p=p)
+    qt = poly_add(poly_scale(qt, z_n, p), polys["t_2"], p=p)
+    qt = poly_add(poly_scale(qt, z_n, p), polys["t_1"], p=p)
+    neg_q = poly_scale(qt, -vanishing % p, p)
+    lin = poly_add(gate, perm, look, neg_q, p=p)
+    evals = {"a_eval": a, "b_eval": b, "c_eval": c, "d_eval": d, "left_sigma_eval": s1, "right_sigma_eval": s2, "out_sigma_eval": s3,
+             "permutation_eval": z_next, "q_lookup_eval": q_lookup, "z2_next_eval": z2_next, "h1_eval": h1_e, "h1_next_eval": h1_next,
+             "h2_eval": h2_e, "f_eval": f_e, "table_eval": t_e, "table_next_eval": t_next,
+             "q_arith_eval": q_arith, "q_c_eval": q_c, "q_l_eval": q_l, "q_r_eval": q_r, "a_next_eval": a_n, "b_next_eval": b_n, "d_next_eval": d_n}
+    return lin, evals
 
 
 def ark_window_size(n: int) -> int:

@@ -156,3 +156,51 @@ def test_quotient_oracle_matches_fixtures(cid):
         c2 = dict(col)
         c2[sel] = [0] * len(col[sel])
         assert bo.quotient_at(cv, 2, 5, c2, ch) != base, sel
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_linearisation_oracle_matches_fixtures_and_the_quotient_identity(cid):
+    """oracle/bigint_oracle.py linearisation (linearisation_poly.rs:164-350) vs tests/golden/linearisation.npz, and pinned on the
+    quotient oracle: at a point x of the 4n coset taken as z_challenge, the quotient numerator N(x) = quotient_at(x) * Z_H(x) is
+    the linearisation polynomial at x plus Z_H(x) t(x) plus the terms the verifier adds back (proof.rs:556-611
+    compute_quotient_evaluation: pi(z), the constant part of the copy product, L_1(z) alpha^2, the lookup constants) -- for ANY
+    polynomials, so every scalar and sign of the linearisation is checked against the widgets' quotient terms."""
+    import ark_plonk_amd.curves as cvs
+    from tests.golden.gen_golden_linearisation import CHALLENGES, EVAL_NAMES, LOG_N, case
+    g = np.load(os.path.join(ROOT, "tests", "golden", "linearisation.npz"))
+    cv = bo.CURVES[cid]
+    p = cv.r
+    ints = lambda a: cvs.fr_from_mont(cid, a)  # noqa: E731
+    key = {name: ints(g[f"{cv.name}_key_{name}"]) for name in bo.LIN_KEY}
+    polys = {name: ints(g[f"{cv.name}_poly_{name}"]) for name in bo.LIN_POLYS}
+    ch = dict(zip(CHALLENGES, ints(g[f"{cv.name}_challenges"])))
+    k2, p2, c2 = case(cv, LOG_N, 0x9100 + 0x100 * cid)
+    assert (k2, p2, c2) == (key, polys, ch)                      # the generator is deterministic
+    lin, ev = bo.linearisation(cv, LOG_N, key, polys, ch)
+    assert lin == ints(g[f"{cv.name}_lin"]) and [ev[k] for k in EVAL_NAMES] == ints(g[f"{cv.name}_evals"])
+    # -- the identity, at coset point i
+    n, n4 = 1 << LOG_N, 4 << LOG_N
+    col = {name: bo.ntt(cv, 2, LOG_N + 2, src) for name, src in list(key.items()) + [(k, polys[k]) for k in
+                                                                                       ("w_l", "w_r", "w_o", "w_4", "z", "z2", "f", "table", "h1", "h2")]}
+    pi = bo.seeded_scalars(cv, 0x77, n)
+    l1_evals = [1] + [0] * (n - 1)
+    col["pi"] = bo.ntt(cv, 2, LOG_N + 2, pi)
+    col["l1"] = bo.ntt(cv, 2, LOG_N + 2, bo.ntt(cv, 1, LOG_N, l1_evals))
+    for i in (1, 6, 19):
+        x = cv.fr_generator * pow(cv.root_of_unity(LOG_N + 2), i, p) % p
+        chx = dict(ch, z=x)
+        lin_x, e = bo.linearisation(cv, LOG_N, key, polys, chx)
+        zh = (pow(x, n, p) - 1) % p
+        numerator = bo.quotient_at(cv, LOG_N, i, col, chx) * zh % p
+        xn = pow(x, n, p)
+        t_x = sum(bo.horner(polys[f"t_{k + 1}"], x, p) * pow(xn, k, p) for k in range(4)) % p
+        l1 = col["l1"][i]
+        al, be, ga, de, ep, ls = (chx[k] for k in ("alpha", "beta", "gamma", "delta", "epsilon", "lookup"))
+        copy_rest = (e["a_eval"] + be * e["left_sigma_eval"] + ga) * (e["b_eval"] + be * e["right_sigma_eval"] + ga) % p \
+            * (e["c_eval"] + be * e["out_sigma_eval"] + ga) % p * (e["d_eval"] + ga) % p * e["permutation_eval"] % p * al % p
+        e1d = ep * (1 + de) % p
+        h1_x = e["h1_eval"]
+        look_rest = e["z2_next_eval"] * ls * ls % p * (e1d + de * e["h2_eval"]) % p * (e1d + e["h2_eval"] + de * e["h1_next_eval"]) % p
+        back = (bo.horner(lin_x, x, p) + zh * t_x + bo.horner(pi, x, p) - copy_rest - l1 * al * al - look_rest - l1 * ls * ls * ls) % p
+        assert back == numerator, i
+        assert h1_x == col["h1"][i] and e["a_next_eval"] == col["w_l"][(i + 4) % n4]

@@ -118,3 +118,20 @@ def test_config1_plumbing_size_end_to_end_vs_cpu_oracle(ctx, oracle_cpu):
     for k, (g, (xy, inf)) in enumerate(zip(got, exp)):
         assert g.infinity == bool(inf) and np.array_equal(g.xy(), xy), k
     ck.close()
+
+
+def test_schedule_with_linearisation_on_device(ctx):
+    """linearisation=True: `lin` is the 19-term sum built from the round's polynomials and the 23 evaluations come back
+    (linearisation_poly.rs:164-350); everything that does not depend on `lin` is unchanged."""
+    from ark_plonk_amd import linearisation
+    cv = zk.get_curve("bls12_381")
+    log_n = 10
+    ck = _ck(ctx, cv, 1 << log_n)
+    plain = ProofSchedule(log_n, ctx, ck, cv).run_once(proof_id=0)
+    s = ProofSchedule(log_n, ctx, ck, cv, linearisation=True)
+    got = s.run_once(proof_id=0)
+    changed = [k for k in range(29) if got[k] != plain[k]]
+    assert changed == [13, 20]                       # commit(lin) and the opening at z (aw_open holds lin)
+    assert set(s.last_evals) == set(linearisation.PROOF_EVALS + linearisation.CUSTOM_EVALS)
+    again = s.run_once(proof_id=0)
+    assert again == got

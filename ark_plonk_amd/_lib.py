@@ -18,6 +18,7 @@ ZK_ERR_OOM = -4
 ZK_ERR_NO_DEVICE = -5
 ZK_ERR_UNSUPPORTED = -6
 ZK_ERR_NOT_INVERTIBLE = -7
+ZK_ERR_NOT_INDEXED = -8
 
 c_void_p = ctypes.c_void_p
 c_size_t = ctypes.c_size_t
@@ -113,6 +114,9 @@ SYMBOLS = {
                                 c_void_p, c_void_p]),
     "zk_kzg_witness_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p,
                                    c_void_p, ctypes.POINTER(c_size_t)]),
+    "zk_lookup_query_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
+    "zk_lookup_combine_split_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p,
+                                            ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "zk_poly_evaluate_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
     "zk_poly_lincomb_dev": (c_int, [c_void_p, c_int, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_size_t]),
     "zk_g1_fixed_base_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -31,7 +31,8 @@ def jobs():
         ("api.o", "api.hip", [], HOST_HDRS),
         ("hostio.o", "hostio.hip", [], HOST_HDRS),
         ("wire.o", "wire.hip", [], HOST_HDRS),
-        ("kzg.o", "kzg.hip", [], HOST_HDRS),
+        ("kzg.o", "kzg.hip", [], HOST_HDRS + ["fr_io.cuh"]),
+        ("lookup.o", "lookup.hip", [], HOST_HDRS + ["fr_io.cuh"]),
         ("grand_product.o", "grand_product.hip", [], HOST_HDRS),
         ("quotient.o", "quotient.hip", [], HOST_HDRS),
         ("quadtest.o", "quadtest.hip", [], HOST_HDRS + ["ecq.cuh"]),

@@ -132,6 +132,7 @@ const char* zk_strerror(int code) {
     case ZK_ERR_NO_DEVICE: return "no usable HIP device";
     case ZK_ERR_UNSUPPORTED: return "size not supported";
     case ZK_ERR_NOT_INVERTIBLE: return "zero denominator in a grand product";
+    case ZK_ERR_NOT_INDEXED: return "lookup query value not in the table";
     default: return "unknown error";
     }
 }
@@ -871,6 +872,23 @@ int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* co
         ZK_HIP_TRY(hipMemcpyAsync(d_out, d_w, wlen * 32, hipMemcpyDeviceToDevice, c->stream));
     }
     return ZK_OK;
+}
+
+int zk_lookup_query_dev(zk_ctx* c, int curve_id, size_t n, const void* d_q_lookup, size_t q_len, const void* const d_wires[4], const uint64_t* zeta_mont,
+                        const void* d_table_compressed, void* d_out) {
+    if (!c || !zeta_mont) return ZK_ERR_BAD_ARG;
+    if (n && (!d_wires || !d_wires[0] || !d_wires[1] || !d_wires[2] || !d_wires[3] || !d_table_compressed || !d_out || (q_len && !d_q_lookup)))
+        return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return lookup_query_dev(c, curve_id, n, d_q_lookup, q_len, d_wires, zeta_mont, d_table_compressed, d_out);
+}
+
+int zk_lookup_combine_split_dev(zk_ctx* c, int curve_id, const void* d_t, size_t n_t, const void* d_f, size_t n_f, void* d_h1, void* d_h2,
+                                size_t* len_h1, size_t* len_h2) {
+    if (!c || !len_h1 || !len_h2 || (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254)) return ZK_ERR_BAD_ARG;
+    if ((n_t && !d_t) || (n_f && !d_f) || ((n_t + n_f) && (!d_h1 || !d_h2))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return lookup_combine_split_dev(c, d_t, n_t, d_f, n_f, d_h1, d_h2, len_h1, len_h2);
 }
 
 int zk_poly_evaluate_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont,

@@ -321,6 +321,10 @@ int lookup_product_dev(zk_ctx* c, int curve, size_t n, const void* d_f, const vo
                        const uint64_t* delta_mont, const uint64_t* eps_mont, void* d_out, uint64_t* last_mont);
 int quad_selftest_dev(zk_ctx* c, int curve, uint32_t n_quads, uint32_t* out2);
 int quotient_evals_dev(zk_ctx* c, int curve, uint32_t log_n, const zk_quotient_args* q, void* d_out);
+int lookup_query_dev(zk_ctx* c, int curve, size_t n, const void* d_q, size_t q_len, const void* const* d_w, const uint64_t* zeta_mont,
+                     const void* d_table, void* d_out);
+int lookup_combine_split_dev(zk_ctx* c, const void* d_t, size_t n_t, const void* d_f, size_t n_f, void* d_h1, void* d_h2, size_t* len_h1,
+                             size_t* len_h2);
 int poly_evaluate_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* points_mont,
                       uint64_t* out_mont);
 int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,

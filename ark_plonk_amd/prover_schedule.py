@@ -29,7 +29,7 @@ class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
-                 ntt_batch: bool = True, linearisation: bool = False):
+                 ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -63,6 +63,9 @@ class ProofSchedule:
         # polynomials, instead of a stand-in polynomial being committed as `lin`
         self.linearisation = linearisation
         self.last_evals = None
+        # round 2 (prover.rs:228-317): the compressed table, the compressed query column and h_1 / h_2 (MultiSet::combine_split)
+        # built on the device from four table columns, q_lookup and the wire columns, instead of taken as synthetic inputs
+        self.lookup_round2 = lookup_round2
         # Independent transforms the reference issues back to back go out as ONE zk_ntt_batch_dev (one launch per pass,
         # blockIdx.y = polynomial): the four wire iffts (prover.rs:196-203), h_1 / h_2 (prover.rs:302-305), the four sigma ffts
         # (permutation/mod.rs:671-674) and the twelve coset ffts of quotient_poly.rs:72-120.  ntt_batch=False issues them one by one,
@@ -115,6 +118,22 @@ class ProofSchedule:
             self.sigma4n = [rnd(4 * n) for _ in range(4)]
             self.q_chal = {name: np.array([0x1111 * (k + 1), 0x2222, 0x3333, 0x0444], dtype=np.uint64)
                            for k, name in enumerate(__import__("ark_plonk_amd.quotient", fromlist=["CHALLENGES"]).CHALLENGES)}
+        if lookup_round2:
+            # a table of n / 4 distinct rows padded to n with its first row (repeats adjacent, as a padded table's are), lookup
+            # gates on about half of the rows (never row 0, which _set_proof varies per proof); a lookup row's wires hold a
+            # table row, as a satisfied circuit's do
+            self.table_cols = [rnd(n) for _ in range(4)]
+            rep = torch.arange(n, device=dev)
+            rep[max(n // 4, 1):] = 0
+            self.table_cols = [col[rep].contiguous() for col in self.table_cols]
+            q = torch.randint(0, 2, (n,), device=dev, generator=g)
+            q[0] = 0
+            self.q_lookup = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+            self.q_lookup[:, 0] = q                       # any non-zero value selects (prover.rs:265 `is_zero`)
+            row = torch.randint(0, n, (n,), device=dev, generator=g)
+            for k in range(4):
+                self.evals[k] = torch.where(q.bool().unsqueeze(1), self.table_cols[k][row], self.evals[k]).contiguous()
+            self.zeta_mont = np.array([0x0badcafe, 0x12345678, 0x9abcdef0, 0x01234567], dtype=np.uint64)
         if linearisation:
             from . import linearisation as lin_mod
             self.key_polys = {name: rnd(n) for name in lin_mod.KEY_POLYS[:12]}       # selector polynomials of the prover key
@@ -198,14 +217,21 @@ class ProofSchedule:
                 c[i] = d.ifft(self.evals[i])
         out += self._commit_round(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
-        c[4] = d.ifft(self.aux_evals[0])          # table_poly
-        c[5] = d.ifft(self.aux_evals[1])          # f_poly
+        t_ev, f_ev, h1_ev, h2_ev = self.aux_evals[0:4]
+        if self.lookup_round2:
+            from . import lookup
+            t_ev = lookup.compress_table(self.table_cols, self.zeta_mont, self.cv, self.ctx)                          # prover.rs:229-237
+            f_ev = lookup.compress_query(self.q_lookup, self.evals, self.zeta_mont, t_ev, curve=self.cv, ctx=self.ctx)   # :244-276
+        c[4] = d.ifft(t_ev)                       # table_poly
+        c[5] = d.ifft(f_ev)                       # f_poly
         out += self._commit_round([c[5]], labels=["f"])
+        if self.lookup_round2:
+            h1_ev, h2_ev = lookup.combine_split(t_ev, f_ev, self.cv, self.ctx)                                        # :295-297
         if self.ntt_batch:
-            c[6], c[7] = d.batch(1, self.aux_evals[2:4])
+            c[6], c[7] = d.batch(1, [h1_ev, h2_ev])
         else:
-            c[6] = d.ifft(self.aux_evals[2])          # h1
-            c[7] = d.ifft(self.aux_evals[3])          # h2
+            c[6] = d.ifft(h1_ev)                      # h1
+            c[7] = d.ifft(h2_ev)                      # h2
         out += self._commit_round([c[6]], labels=["h1"])     # two PC::commit calls of one polynomial each (prover.rs:312-317)
         out += self._commit_round([c[7]], labels=["h2"])
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
@@ -217,8 +243,7 @@ class ProofSchedule:
         c[8] = d.ifft(z_evals)                    # z
         out += self._commit_round([c[8]], labels=["z"])
         if self.grand_products:
-            z2_evals = permutation.lookup_permutation_evals(self.ctx, self.cv, self.aux_evals[1], self.aux_evals[0], self.aux_evals[2],
-                                                            self.aux_evals[3], self.chi_mont, self.z_mont)  # f, t, h1, h2; delta, epsilon
+            z2_evals = permutation.lookup_permutation_evals(self.ctx, self.cv, f_ev, t_ev, h1_ev, h2_ev, self.chi_mont, self.z_mont)  # delta, epsilon
         c[9] = d.ifft(z2_evals)                   # z2
         out += self._commit_round([c[9]], labels=["z2"])
         c[10] = d.ifft(self.aux_evals[6])         # pi

@@ -287,7 +287,7 @@ def main():
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
-                kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, fuse_round5=args.fuse_round5,
+                kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, lookup_round2=glue, fuse_round5=args.fuse_round5,
                           data=args.data, ntt_batch=not args.no_ntt_batch)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
@@ -349,11 +349,11 @@ def main():
                 lanes[0]["sched"].run_once()
             barrier()
             ctx.profile(False)
-            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb"):
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb", "lookup_query", "lookup_combine_split"):
                 prof[k] = ctx.profile_get(k)
             prof["breakdown_accumulate"] = ctx.profile_get("msm_accumulate")
         else:
-            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb", "breakdown_accumulate"):
+            for k in ("ntt_pass", "msm_sort", "msm_reduce", "grand_product", "quotient", "poly_evaluate", "poly_lincomb", "lookup_query", "lookup_combine_split", "breakdown_accumulate"):
                 prof[k] = (0.0, 0)
         digs = []
         if args.check:
@@ -554,7 +554,9 @@ def main():
                     "quotient_ms_per_proof": r5["prof"]["quotient"][0] / max(r5["kb"], 1), "grand_product_ms_per_proof": r5["prof"]["grand_product"][0] / max(r5["kb"], 1),
                     "evaluations_ms_per_proof": r5["prof"]["poly_evaluate"][0] / max(r5["kb"], 1),
                     "linearisation_ms_per_proof": r5["prof"]["poly_lincomb"][0] / max(r5["kb"], 1),
-                    "what": "SURVEY.md 8f N1 + N2 and round 5's O(n) work inside the step: z and z2 built on the device (zk_perm_product_dev / "
+                    "lookup_round2_ms_per_proof": (r5["prof"]["lookup_query"][0] + r5["prof"]["lookup_combine_split"][0]) / max(r5["kb"], 1),
+                    "what": "SURVEY.md 8f N1 + N2 and the O(n) work of rounds 2 and 5 inside the step: the compressed table / query columns and "
+                            "h_1, h_2 (zk_lookup_query_dev, zk_lookup_combine_split_dev; prover.rs:228-317), z and z2 built on the device (zk_perm_product_dev / "
                             "zk_lookup_product_dev), the 4n quotient evaluations computed on the device (zk_quotient_evals_dev) from the 12 coset-fft "
                             "outputs, the 23 evaluations of the proof (zk_poly_evaluate_dev) and the 19-term linearisation polynomial "
                             "(zk_poly_lincomb_dev; linearisation_poly.rs:164-350) -- instead of synthetic inputs / a stand-in polynomial"}

@@ -60,6 +60,7 @@ class DeviceVec {
     DeviceVec(DeviceVec&& o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
     void* data() const { return p_; }
     size_t size() const { return n_; }
+    void truncate(size_t n) { n_ = n < n_ ? n : n_; }       // keep the allocation, shorten the logical length
     std::vector<uint64_t> to_host() const {
         std::vector<uint64_t> h(4 * n_);
         if (n_) check(zk_dev_download(ctx_->handle(), h.data(), p_, n_ * 32), "zk_dev_download");
@@ -295,6 +296,32 @@ inline DeviceVec lookup_permutation_evals(Context& ctx, int curve, const DeviceV
 inline DeviceVec quotient_evals(const Radix2EvaluationDomain& d, const zk_quotient_args& args) {
     DeviceVec out(d.context(), 4 * d.size());
     check(zk_quotient_evals_dev(d.context().handle(), d.curve(), d.log_size_of_group(), &args, out.data()), "zk_quotient_evals_dev");
+    return out;
+}
+// MultiSet::combine_split (lookup/multiset.rs:131-176): t.combine_split(&f) -> (h_1, h_2); Error::ElementNotIndexed -> zk::Error(ZK_ERR_NOT_INDEXED)
+inline std::pair<DeviceVec, DeviceVec> combine_split(Context& ctx, int curve, const DeviceVec& t, const DeviceVec& f) {
+    const size_t cap = (t.size() + f.size() + 1) / 2;
+    DeviceVec h1(ctx, cap), h2(ctx, cap);
+    size_t l1 = 0, l2 = 0;
+    check(zk_lookup_combine_split_dev(ctx.handle(), curve, t.data(), t.size(), f.data(), f.size(), h1.data(), h2.data(), &l1, &l2),
+          "zk_lookup_combine_split_dev");
+    h1.truncate(l1);
+    h2.truncate(l2);
+    return {std::move(h1), std::move(h2)};
+}
+// prover.rs:244-279: the compressed query column over wires[0]->size() rows
+inline DeviceVec lookup_query(Context& ctx, int curve, const DeviceVec& q_lookup, const DeviceVec* const wires[4], const uint64_t* zeta_mont,
+                              const DeviceVec& table_compressed) {
+    const size_t n = wires[0]->size();
+    const void* w[4];
+    for (int k = 0; k < 4; ++k) {
+        if (wires[k]->size() != n) throw Error(ZK_ERR_BAD_ARG, "column length");
+        w[k] = wires[k]->data();
+    }
+    if (table_compressed.size() == 0) throw Error(ZK_ERR_BAD_ARG, "empty table");
+    DeviceVec out(ctx, n);
+    check(zk_lookup_query_dev(ctx.handle(), curve, n, q_lookup.data(), q_lookup.size(), w, zeta_mont, table_compressed.data(), out.data()),
+          "zk_lookup_query_dev");
     return out;
 }
 // `DensePolynomial::evaluate` for a batch (linearisation_poly.rs:203-261: 16 polynomials at z, 7 at z*omega): polys[k] at

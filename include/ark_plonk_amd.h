@@ -59,6 +59,7 @@ typedef struct zk_srs zk_srs;
 #define ZK_ERR_NO_DEVICE (-5)
 #define ZK_ERR_UNSUPPORTED (-6)
 #define ZK_ERR_NOT_INVERTIBLE (-7) /* a grand-product denominator is zero (the reference panics: `inverse().unwrap()`) */
+#define ZK_ERR_NOT_INDEXED (-8)    /* a lookup query value is not in the table (the reference's Error::ElementNotIndexed) */
 
 const char* zk_strerror(int code);
 
@@ -251,6 +252,24 @@ int zk_poly_evaluate_dev(zk_ctx* ctx, int curve_id, uint32_t n_polys, const void
  * reduced; may alias one of the inputs.  Queued on the ctx stream (no host synchronisation). */
 int zk_poly_lincomb_dev(zk_ctx* ctx, int curve_id, uint32_t n_terms, const void* const* d_polys, const size_t* lens,
                         const uint64_t* coeffs_mont, void* d_out, size_t out_len);
+
+/* ---- round 2 of the prover (prover.rs:228-317): the lookup query column and the sorted table/query halves ------------ */
+/* prover.rs:244-279: out[i] = w_l[i] + zeta w_r[i] + zeta^2 w_o[i] + zeta^3 w_4[i] (`MultiSet::compress` of the four query
+ * columns, util.rs `lc`) where q_lookup[i] != 0, and d_table_compressed[0] -- the first row of the compressed table, the
+ * reference's dummy value -- where q_lookup[i] == 0 or i >= q_len (the reference pads q_lookup with zeros to n).
+ * All vectors device-resident Montgomery, n rows; the compressed table itself is zk_poly_lincomb_dev over the four table
+ * columns with coefficients 1, zeta, zeta^2, zeta^3 (prover.rs:229-237). */
+int zk_lookup_query_dev(zk_ctx* ctx, int curve_id, size_t n, const void* d_q_lookup, size_t q_len, const void* const d_wires[4],
+                        const uint64_t* zeta_mont, const void* d_table_compressed, void* d_out);
+
+/* `MultiSet::combine_split` (lookup/multiset.rs:131-176), t.combine_split(&f): the values of t and f grouped by value in the
+ * order of first appearance in t, every group written half to d_h1 ("evens") and half to d_h2 ("odds"), the odd element of
+ * odd-sized groups alternately to h1 / h2 starting with h1.  d_t: n_t (< 2^24) elements, d_f: n_f elements; d_h1 / d_h2: room for
+ * (n_t + n_f + 1) / 2 elements each; *len_h1 / *len_h2 receive the lengths (they differ by at most one).
+ * ZK_ERR_NOT_INDEXED when f holds a value t does not (Error::ElementNotIndexed; nothing is written).  Values are compared as
+ * 32-byte strings: pass reduced elements, as everywhere.  Blocks once (16-byte read-back of the lengths and the error flag). */
+int zk_lookup_combine_split_dev(zk_ctx* ctx, int curve_id, const void* d_t, size_t n_t, const void* d_f, size_t n_f, void* d_h1, void* d_h2,
+                                size_t* len_h1, size_t* len_h2);
 
 /* ---- N2: grand-product builders, feeding the iNTT on device ------------------------ */
 /* Evaluations of the permutation polynomial z over the size-2^log_n domain, i.e. everything

@@ -508,6 +508,55 @@ def linearisation(curve: Curve, log_n: int, key, polys, ch):
     return lin, evals
 
 
+def multiset_compress(columns, alpha, p):
+    """`MultiSet::compress` (lookup/multiset.rs:207-213) = util.rs `lc`: v_0 + alpha v_1 + ... + alpha^k v_k, row by row."""
+    return [sum(col[i] * pow(alpha, k, p) for k, col in enumerate(columns)) % p for i in range(len(columns[0]))]
+
+
+def combine_split(t, f):
+    """`MultiSet::combine_split` (lookup/multiset.rs:131-176).  A Python dict keeps insertion order, as the reference's IndexMap
+    does.  Returns (evens, odds) or raises KeyError for Error::ElementNotIndexed."""
+    counters = {}
+    for e in t:
+        counters[e] = counters.get(e, 0) + 1
+    for e in f:
+        if e not in counters:
+            raise KeyError("ElementNotIndexed")
+        counters[e] += 1
+    evens, odds, parity = [], [], 0
+    for e, count in counters.items():
+        evens += [e] * (count // 2)
+        odds += [e] * (count // 2)
+        if count % 2 == 1:
+            if parity == 1:
+                odds.append(e)
+                parity = 0
+            else:
+                evens.append(e)
+                parity = 1
+    return evens, odds
+
+
+def lookup_round2(curve: Curve, n: int, table_cols, q_lookup, wires, zeta):
+    """prover.rs:228-317 up to the iffts: (compressed table, compressed query f, h_1, h_2) as evaluation vectors.
+    table_cols: 4 lists of n; q_lookup: list of <= n (zero-padded, :252-254); wires: 4 lists of n (already padded, :188-192)."""
+    p = curve.r
+    t = multiset_compress(table_cols, zeta, p)                                    # :229-237
+    q = list(q_lookup) + [0] * (n - len(q_lookup))
+    f_cols = [[], [], [], []]
+    for i in range(n):                                                            # :259-273
+        if q[i] == 0:
+            f_cols[0].append(t[0])
+            for k in (1, 2, 3):
+                f_cols[k].append(0)
+        else:
+            for k in range(4):
+                f_cols[k].append(wires[k][i])
+    f = multiset_compress(f_cols, zeta, p)                                        # :276
+    h1, h2 = combine_split(t, f)                                                  # :295-297
+    return t, f, h1, h2
+
+
 def ark_window_size(n: int) -> int:
     """ark-ec 0.3 variable_base.rs: c = 3 if n < 32 else ln_without_floats(n) + 2,
     ln_without_floats(a) = log2(a) * 69 / 100 with log2 = ceil(log2)."""

@@ -204,3 +204,17 @@ def test_linearisation_oracle_matches_fixtures_and_the_quotient_identity(cid):
         back = (bo.horner(lin_x, x, p) + zh * t_x + bo.horner(pi, x, p) - copy_rest - l1 * al * al - look_rest - l1 * ls * ls * ls) % p
         assert back == numerator, i
         assert h1_x == col["h1"][i] and e["a_next_eval"] == col["w_l"][(i + 4) % n4]
+
+
+def test_combine_split_oracle_on_the_reference_vector():
+    """The reference's own known-answer test for `MultiSet::combine_split` (lookup/multiset.rs:335-392 `test_combine_split`,
+    run there for BLS12-381 and BLS12-377 Fr): t = 0..6, f = [3,6,0,5,4,3,2,0,0,1,2]; and the Plonkup paper's example quoted in
+    the function's doc comment (multiset.rs:125-130)."""
+    t = [0, 1, 2, 3, 4, 5, 6]
+    f = [3, 6, 0, 5, 4, 3, 2, 0, 0, 1, 2]
+    evens, odds = bo.combine_split(t, f)
+    assert evens == [0, 0, 1, 2, 2, 3, 4, 5, 6] and odds == [0, 0, 1, 2, 3, 3, 4, 5, 6]
+    h1, h2 = bo.combine_split([2, 4, 1, 3], [2, 3, 3, 2])
+    assert h1 == [2, 2, 1, 3] and h2 == [2, 4, 3, 3]
+    with pytest.raises(KeyError):
+        bo.combine_split([1, 2, 3], [4])

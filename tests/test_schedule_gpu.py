@@ -135,3 +135,27 @@ def test_schedule_with_linearisation_on_device(ctx):
     assert set(s.last_evals) == set(linearisation.PROOF_EVALS + linearisation.CUSTOM_EVALS)
     again = s.run_once(proof_id=0)
     assert again == got
+
+
+def test_schedule_with_round2_on_device(ctx):
+    """lookup_round2=True: table / f / h_1 / h_2 come from four table columns, q_lookup and the wires (prover.rs:228-317);
+    h_1 and h_2 have n rows each, the run is reproducible, and with the grand products on, z_2 closes (its last step returns to 1
+    only if (f, t, h_1, h_2) really are a Plonkup instance: zk_lookup_product_dev reports the closing value)."""
+    import torch
+    from ark_plonk_amd import lookup, permutation
+    cv = zk.get_curve("bls12_381")
+    log_n = 10
+    n = 1 << log_n
+    ck = _ck(ctx, cv, n)
+    s = ProofSchedule(log_n, ctx, ck, cv, lookup_round2=True, grand_products=True)
+    a = s.run_once(proof_id=0)
+    b = s.run_once(proof_id=0)
+    assert a == b and len(a) == 29
+    t = lookup.compress_table(s.table_cols, s.zeta_mont, cv, ctx)
+    f = lookup.compress_query(s.q_lookup, s.evals, s.zeta_mont, t, curve=cv, ctx=ctx)
+    h1, h2 = lookup.combine_split(t, f, cv, ctx)
+    assert h1.shape[0] == n and h2.shape[0] == n
+    z2, last = permutation.lookup_permutation_evals(ctx, cv, f, t, h1, h2, s.chi_mont, s.z_mont, return_last=True)
+    one = zk.curves.fr_to_mont(cv, [1])[0]
+    assert np.array_equal(np.asarray(last, dtype=np.uint64).reshape(4), one)
+    assert np.array_equal(z2[0].cpu().numpy().view(np.uint64), one)

@@ -10,10 +10,9 @@
 //                               when f holds a value t lacks, then walks the buckets in order writing count/2 copies to each half
 //                               and the odd one alternately to evens / odds.
 //    Here: an open-addressing table over the 32-byte values of t (slot = first claim by CAS, then atomicMin so that the slot names
-//    the FIRST index of its value in t, whatever order the lanes arrive in), counts by atomicAdd (a wave adds the lanes that share
-//    its first lane's slot in one atomic: the reference pads every non-lookup row with one value, so one bucket can hold most of
-//    f), three exclusive scans over t's positions (odd-bucket parity; evens and odds offsets, packed in one 64-bit scan) and an
-//    output-parallel fill that finds its bucket by binary search in the offsets.  No sort, like the reference; results are the
+//    the FIRST index of its value in t, whatever order the lanes arrive in), counts by atomicAdd (one atomic per distinct slot in a
+//    wavefront: the reference pads every non-lookup row with one value, so one bucket can hold most of f), exclusive scans over
+//    t's positions (odd-bucket parity; evens and odds offsets, packed in one 64-bit scan) and an output-parallel fill that finds its bucket by binary search in the offsets.  No sort, like the reference; results are the
 //    reference's exactly because the emission order is a function of (first index in t, count) only.
 #include "ctx.h"
 #include "fr_io.cuh"
@@ -47,20 +46,52 @@ ZK_D uint32_t el_hash(const El& e) {
     return (uint32_t)h;
 }
 
-// one atomic for the lanes that share the first active lane's slot, one each for the others
-ZK_D void count_add(uint32_t* cnt, uint32_t s, bool live) {
-    const uint64_t act = __ballot(live);
-    if (!act) return;
-    const int lead = __ffsll((long long)act) - 1;
-    const uint32_t s0 = __shfl(s, lead, 64);
-    const uint64_t same = __ballot(live && s == s0);
-    if (live) {
-        if (s == s0) {
-            if ((int)(threadIdx.x & 63) == lead) atomicAdd(&cnt[s0], (uint32_t)__popcll(same));
-        } else {
-            atomicAdd(&cnt[s], 1u);
+// One atomic per DISTINCT slot among the live lanes of a wavefront (the reference pads every non-lookup row of the query and
+// every padding row of the table with one value, so one slot can take most of the traffic: ~9 ns per atomic on one address,
+// 12 ms per proof before this).  add != 0: cnt[slot] += lanes in the group; add == 0: slots[slot] = min(slots[slot], the group's
+// smallest index) -- lane order is index order, so that is the group's first lane.
+ZK_D void wave_group_update(uint32_t* arr, uint32_t s, uint32_t i, bool live, bool add) {
+    uint64_t todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t s0 = __shfl(s, lead, 64);
+        const uint64_t same = __ballot(live && s == s0) & todo;
+        if (lane == lead) {
+            if (add) atomicAdd(&arr[s0], (uint32_t)__popcll(same));
+            else atomicMin(&arr[s0], i);
         }
+        todo &= ~same;
     }
+}
+
+// Lanes of a wavefront that hold the same 32-byte value elect their first lane (returns its id; the own id for a value no other
+// lane holds).  Without it every lane of the first few thousand wavefronts CASes the one slot of the padding value at once:
+// ls_insert_table took 1.36 ms at n = 2^20 with 3/4 of the table padded, 78 % of the whole function.
+ZK_D int wave_value_leader(const El& v, uint32_t h, bool live) {
+    const int lane = threadIdx.x & 63;
+    int leader = lane;
+    uint64_t todo = __ballot(live);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t h0 = __shfl(h, lead, 64);
+        uint64_t same = __ballot(live && h == h0) & todo;
+        if (same & (same - 1)) {                  // someone shares the leader's hash: compare the values (wave-uniform branch)
+            bool eq = h == h0;
+            eq = eq && v.a.x == __shfl(v.a.x, lead, 64);
+            eq = eq && v.a.y == __shfl(v.a.y, lead, 64);
+            eq = eq && v.a.z == __shfl(v.a.z, lead, 64);
+            eq = eq && v.a.w == __shfl(v.a.w, lead, 64);
+            eq = eq && v.b.x == __shfl(v.b.x, lead, 64);
+            eq = eq && v.b.y == __shfl(v.b.y, lead, 64);
+            eq = eq && v.b.z == __shfl(v.b.z, lead, 64);
+            eq = eq && v.b.w == __shfl(v.b.w, lead, 64);
+            same = (__ballot(live && eq) & todo) | (1ull << lead);
+        }
+        if ((same >> lane) & 1) leader = lead;
+        todo &= ~same;
+    }
+    return leader;
 }
 
 // t -> table.  slots[s] = smallest index i of the value stored at s; slot_of[i] = the slot of t[i]; cnt[s] += 1 per element
@@ -68,25 +99,33 @@ __global__ void __launch_bounds__(256) ls_insert_table(const void* t, uint32_t n
                                                       uint32_t* cnt) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n_t;
-    uint32_t s = 0;
+    bool need_min = false;
+    uint32_t s = 0, h = 0;
+    El v = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     if (live) {
-        const El v = ld_el(t, i);
-        s = el_hash(v) & mask;
+        v = ld_el(t, i);
+        h = el_hash(v);
+    }
+    const int leader = wave_value_leader(v, h, live);
+    if (live && leader == (int)(threadIdx.x & 63)) {          // one probe per distinct value of the wavefront, by its smallest index
+        s = h & mask;
         for (;;) {
             uint32_t cur = slots[s];
             if (cur == EMPTY) {
                 cur = atomicCAS(&slots[s], EMPTY, i);
                 if (cur == EMPTY) break;
             }
-            if (cur == i || el_eq(ld_el(t, cur), v)) {       // any index stored here carries this slot's value
-                atomicMin(&slots[s], i);
+            if (el_eq(ld_el(t, cur), v)) {       // any index stored here carries this slot's value
+                need_min = cur > i;
                 break;
             }
             s = (s + 1) & mask;
         }
-        slot_of[i] = s;
     }
-    count_add(cnt, s, live);
+    s = __shfl(s, leader, 64);
+    if (live) slot_of[i] = s;
+    wave_group_update(slots, s, i, need_min, false);
+    wave_group_update(cnt, s, i, live, true);
 }
 
 // f -> counts; err[0] = 1 when some f[i] is not in t (Error::ElementNotIndexed), err[1] = the smallest such i
@@ -94,23 +133,30 @@ __global__ void __launch_bounds__(256) ls_count_queries(const void* f, uint32_t 
                                                        uint32_t* cnt, uint32_t* err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < n_f;
-    uint32_t s = 0;
+    uint32_t s = EMPTY, h = 0;
+    El v = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     if (live) {
-        const El v = ld_el(f, i);
-        s = el_hash(v) & mask;
+        v = ld_el(f, i);
+        h = el_hash(v);
+    }
+    const int leader = wave_value_leader(v, h, live);
+    if (live && leader == (int)(threadIdx.x & 63)) {
+        s = h & mask;
         for (;;) {
             const uint32_t cur = slots[s];
             if (cur == EMPTY) {
                 atomicOr(&err[0], 1u);
                 atomicMin(&err[1], i);
-                live = false;
+                s = EMPTY;
                 break;
             }
             if (el_eq(ld_el(t, cur), v)) break;
             s = (s + 1) & mask;
         }
     }
-    count_add(cnt, s, live);
+    s = __shfl(s, leader, 64);
+    live = live && s != EMPTY;
+    wave_group_update(cnt, s, i, live, true);
 }
 
 // position i of t owns its bucket iff it is the first index of its value; odd[i] = owner with an odd count

@@ -51,9 +51,12 @@ def evaluate_batch(polys, points_mont, curve="bls12_381", ctx=None) -> np.ndarra
     ctx = ctx or default_context(polys[0].device.index)
     pts = np.ascontiguousarray(points_mont, dtype=np.uint64).reshape(len(polys), 4)
     out = np.zeros((len(polys), 4), dtype=np.uint64)
-    ptrs, lens = _ptrs(polys, ctx)
     ctx.use_torch_stream()
-    check(lib().zk_poly_evaluate_dev(ctx.handle, cv.curve_id, len(polys), ptrs, lens, ptr_of(pts), ptr_of(out)), "zk_poly_evaluate_dev")
+    for lo in range(0, len(polys), 32):                  # the entry point takes 32 pairs per call
+        part = polys[lo:lo + 32]
+        ptrs, lens = _ptrs(part, ctx)
+        check(lib().zk_poly_evaluate_dev(ctx.handle, cv.curve_id, len(part), ptrs, lens, ptr_of(pts[lo:lo + 32]), ptr_of(out[lo:lo + 32])),
+              "zk_poly_evaluate_dev")
     return out
 
 

@@ -1,0 +1,146 @@
+"""`Prover::prove_with_preprocessed` (proof_system/prover.rs:163-638) end to end on device-resident vectors: every O(n) step is
+one of the library's entry points, the transcript is the library's merlin, and the result is a `Proof` whose bytes are the
+reference's serialisation (proof.rs:41-103).  The circuit comes in as what the composer and `preprocess.rs` hand the prover:
+the four padded wire columns, the public inputs, and a prover key built from selector / sigma / table evaluation vectors.
+
+    round 1  4 iffts, 4 commitments                                              prover.rs:188-226
+    round 2  compressed table, query column, combine_split, 4 iffts, 3 commits   prover.rs:228-321   (lookup.py)
+    round 3  z and z_2 grand products, 2 iffts, 2 commitments, pi ifft           prover.rs:323-392   (permutation.py)
+    round 4  12 + 1 coset ffts, pointwise quotient, coset ifft, 4 commitments    prover.rs:394-481   (quotient.py)
+    round 5  23 evaluations, linearisation polynomial, 14 commits, 2 openings    prover.rs:483-618   (linearisation.py, msm.py)
+
+Nothing here is on the timed path of bench.py (its schedule replays the same calls on synthetic inputs); this module is the
+proof that the pieces compose into a proof the reference's verifier equations accept (tests/test_prover_gpu.py)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import linearisation, lookup, permutation, quotient
+from .curves import fr_from_mont, fr_to_mont, get_curve
+from .domain import Radix2EvaluationDomain
+from .transcript import (CUSTOM_EVAL_LABELS, EVAL_LABELS, PROOF_EVAL_FIELDS, ProverTranscript, Transcript, proof_serialize)
+
+SELECTORS = quotient.COLUMNS[12:]       # q_m q_l q_r q_o q_4 q_c q_arith q_range q_logic q_fixed_group_add q_variable_group_add q_lookup
+# transcript label of an evaluation -> field of ProofEvaluations (prover.rs:516-544)
+_EVAL_FIELD = {"a_eval": "a_eval", "b_eval": "b_eval", "c_eval": "c_eval", "d_eval": "d_eval", "left_sig_eval": "left_sigma_eval",
+               "right_sig_eval": "right_sigma_eval", "out_sig_eval": "out_sigma_eval", "perm_eval": "permutation_eval", "f_eval": "f_eval",
+               "q_lookup_eval": "q_lookup_eval", "lookup_perm_eval": "z2_next_eval", "h_1_eval": "h1_eval", "h_1_next_eval": "h1_next_eval",
+               "h_2_eval": "h2_eval"}
+_SEP = {"range separation challenge": "range_challenge", "logic separation challenge": "logic_challenge",
+        "fixed base separation challenge": "fixed_base_challenge", "variable base separation challenge": "var_base_challenge",
+        "lookup separation challenge": "lookup_challenge", "alpha": "alpha"}
+
+
+class ProverKey:
+    """What `preprocess.rs:138-212` leaves with the prover, device-resident: every selector and sigma polynomial in coefficient
+    form and as 4n coset evaluations, the sigma evaluations over the domain, the four table columns."""
+
+    def __init__(self, domain: Radix2EvaluationDomain, domain_4n: Radix2EvaluationDomain, selector_evals: dict, sigma_evals, table_cols):
+        if set(selector_evals) != set(SELECTORS) or len(sigma_evals) != 4 or len(table_cols) != 4:
+            raise ValueError("12 selector columns, 4 sigma columns and 4 table columns expected")
+        self.domain, self.domain_4n = domain, domain_4n
+        self.q_lookup_evals = selector_evals["q_lookup"]
+        self.polys = {name: domain.ifft(selector_evals[name]) for name in SELECTORS}
+        self.evals4n = {name: domain_4n.coset_fft(self.polys[name]) for name in SELECTORS}
+        self.sigma_evals = list(sigma_evals)
+        self.sigma_polys = [domain.ifft(s) for s in sigma_evals]
+        self.sigma4n = [domain_4n.coset_fft(p) for p in self.sigma_polys]
+        self.table_cols = list(table_cols)
+
+    def linearisation_key(self) -> dict:
+        k = dict(self.polys)
+        k.update(left_sigma=self.sigma_polys[0], right_sigma=self.sigma_polys[1], out_sigma=self.sigma_polys[2], fourth_sigma=self.sigma_polys[3])
+        return k
+
+
+@dataclass
+class Proof:
+    """`Proof<F, PC>` (proof.rs:41-103)."""
+    commitments: dict                       # PROOF_COMMITMENTS name -> G1Affine
+    aw_opening: object
+    saw_opening: object
+    evaluations: dict                       # ProofEvaluations field -> 4 Montgomery limbs (16 fixed + the custom ones)
+    challenges: dict = field(default_factory=dict)      # not part of the proof: what the transcript produced
+    polys: dict = field(default_factory=dict)           # not part of the proof: the device polynomial behind every commitment / opening
+    curve: str = "bls12_381"
+
+    def to_bytes(self) -> bytes:
+        from .transcript import PROOF_COMMITMENTS
+        return proof_serialize([self.commitments[k] for k in PROOF_COMMITMENTS], [self.aw_opening, self.saw_opening],
+                               [self.evaluations[k] for k in PROOF_EVAL_FIELDS], [(k, self.evaluations[k]) for k in CUSTOM_EVAL_LABELS], self.curve)
+
+
+def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcript, coeff_a_mont, coeff_d_mont) -> Proof:
+    """wires: the four wire columns padded to n (prover.rs:188-192), device tensors; public_inputs: position -> 4 Montgomery limbs
+    (pi.rs:28-36); preprocessed: the transcript after the verifier key was seeded into it; coeff_a / coeff_d: the embedded
+    curve's coefficients (`P::COEFF_A`, `P::COEFF_D`)."""
+    import torch
+    d, d4 = pk.domain, pk.domain_4n
+    cv = get_curve(d.curve)
+    n = d.size()
+    ctx = d._ctx_for(wires[0])
+    tr = ProverTranscript(preprocessed)
+    tr.public_inputs(public_inputs)                                                                       # :182
+    ch = {"coeff_a": np.asarray(coeff_a_mont, dtype=np.uint64), "coeff_d": np.asarray(coeff_d_mont, dtype=np.uint64)}
+    # -- round 1
+    w_polys = d.batch(1, list(wires))                                                                     # :196-203
+    w_commits = ck.commit_batch(w_polys)                                                                  # :213
+    ch.update(tr.round1(w_commits))                                                                       # :217-226
+    # -- round 2
+    t_ev = lookup.compress_table(pk.table_cols, ch["zeta"], cv, ctx)                                      # :229-237
+    table_poly = d.ifft(t_ev)                                                                             # :240-242
+    f_ev = lookup.compress_query(pk.q_lookup_evals, list(wires), ch["zeta"], t_ev, n=n, curve=cv, ctx=ctx)   # :244-276
+    f_poly = d.ifft(f_ev)                                                                                 # :279-283
+    f_commit = ck.commit_batch([f_poly])[0]                                                               # :289-291
+    h1_ev, h2_ev = lookup.combine_split(t_ev, f_ev, cv, ctx)                                              # :295-297
+    h1_poly, h2_poly = d.batch(1, [h1_ev, h2_ev])                                                         # :300-305
+    h1_commit = ck.commit_batch([h1_poly])[0]                                                             # :312-317
+    h2_commit = ck.commit_batch([h2_poly])[0]
+    ch.update(tr.round2(f_commit, h1_commit, h2_commit))                                                  # :294,320-337
+    for a, b in (("beta", "gamma"), ("beta", "delta"), ("beta", "epsilon"), ("gamma", "delta"), ("gamma", "epsilon"), ("delta", "epsilon")):
+        assert not np.array_equal(ch[a], ch[b]), "challenges must be different"                           # :340-345
+    # -- round 3
+    z_poly = d.ifft(permutation.permutation_evals(d, list(wires), pk.sigma_evals, ch["beta"], ch["gamma"]))     # :347-358
+    z_commit = ck.commit_batch([z_poly])[0]                                                               # :361-363
+    z2_poly = d.ifft(permutation.lookup_permutation_evals(ctx, cv, f_ev, t_ev, h1_ev, h2_ev, ch["delta"], ch["epsilon"]))   # :370-380
+    z2_commit = ck.commit_batch([z2_poly])[0]                                                             # :387-389
+    pi_ev = torch.zeros((n, 4), dtype=torch.int64, device=wires[0].device)                                # :392 into_dense_poly
+    for pos, v in public_inputs.items():
+        pi_ev[pos] = torch.from_numpy(np.asarray(v, dtype=np.uint64).reshape(4).view(np.int64)).to(pi_ev.device)
+    pi_poly = d.ifft(pi_ev)
+    r3 = tr.round3(z_commit)                                                                              # :366,398-426
+    ch.update({_SEP[k]: v for k, v in r3.items()})
+    # -- round 4
+    q_ch = {name: ch[name] for name in quotient.CHALLENGES}
+    t_poly = quotient.compute(d, d4, {"w_l": w_polys[0], "w_r": w_polys[1], "w_o": w_polys[2], "w_4": w_polys[3], "z": z_poly, "z2": z2_poly,
+                                      "f": f_poly, "table": table_poly, "h1": h1_poly, "h2": h2_poly, "pi": pi_poly},
+                              pk.evals4n, pk.sigma4n, q_ch)                                               # :428-453
+    t_parts = [t_poly[k * n:(k + 1) * n] for k in range(4)]                                               # :455-456 split_tx_poly
+    t_commits = ck.commit_batch(t_parts)                                                                  # :459-469
+    ch["z_challenge"] = tr.round4(t_commits)["z"]                                                         # :472-481
+    # -- round 5
+    lin_poly, ev = linearisation.compute(d, pk.linearisation_key(), {name: ch[name] for name in linearisation.CHALLENGES}, {
+        "w_l": w_polys[0], "w_r": w_polys[1], "w_o": w_polys[2], "w_4": w_polys[3], "t_1": t_parts[0], "t_2": t_parts[1], "t_3": t_parts[2],
+        "t_4": t_parts[3], "z": z_poly, "z2": z2_poly, "f": f_poly, "h1": h1_poly, "h2": h2_poly, "table": table_poly})   # :483-512
+    aw_ch, saw_ch = tr.round5({lb: ev[_EVAL_FIELD[lb]] for lb in EVAL_LABELS}, [(lb, ev[lb]) for lb in CUSTOM_EVAL_LABELS])  # :516-563,593-594
+    ch["aw_challenge"], ch["saw_challenge"] = aw_ch, saw_ch
+    aw_polys = [lin_poly, pk.sigma_polys[0], pk.sigma_polys[1], pk.sigma_polys[2], f_poly, h2_poly, table_poly]     # :569-577
+    ck.commit_batch(aw_polys)                                                                             # :579 (the verifier rebuilds these)
+    from .msm import kzg_witness
+    aw_witness = kzg_witness(aw_polys + list(w_polys), ch["z_challenge"], aw_ch, cv, ctx)                 # :582-591 PC::open =
+    aw_opening = ck.commit_batch([aw_witness], canonical=[True])[0]                                       #   witness polynomial + its commitment
+    saw_polys = [z_poly, w_polys[0], w_polys[1], w_polys[3], h1_poly, z2_poly, table_poly]                # :596-604
+    saw_commits = ck.commit_batch(saw_polys)                                                              # :606
+    zw = fr_to_mont(cv, [fr_from_mont(cv, ch["z_challenge"].reshape(1, 4))[0] * fr_from_mont(cv, np.asarray(d.group_gen()).reshape(1, 4))[0] % cv.r])[0]
+    saw_witness = kzg_witness(saw_polys, zw, saw_ch, cv, ctx)                                             # :609-618
+    saw_opening = ck.commit_batch([saw_witness], canonical=[True])[0]
+    commitments = {"a_comm": w_commits[0], "b_comm": w_commits[1], "c_comm": w_commits[2], "d_comm": w_commits[3], "z_comm": saw_commits[0],
+                   "f_comm": f_commit, "h_1_comm": h1_commit, "h_2_comm": h2_commit, "z_2_comm": z2_commit, "t_1_comm": t_commits[0],
+                   "t_2_comm": t_commits[1], "t_3_comm": t_commits[2], "t_4_comm": t_commits[3]}           # :620-637
+    assert saw_commits[0] == z_commit
+    polys = {"a_comm": w_polys[0], "b_comm": w_polys[1], "c_comm": w_polys[2], "d_comm": w_polys[3], "z_comm": z_poly, "f_comm": f_poly,
+             "h_1_comm": h1_poly, "h_2_comm": h2_poly, "z_2_comm": z2_poly, "t_1_comm": t_parts[0], "t_2_comm": t_parts[1],
+             "t_3_comm": t_parts[2], "t_4_comm": t_parts[3], "lin": lin_poly, "aw_witness": aw_witness, "saw_witness": saw_witness}
+    return Proof(commitments, aw_opening, saw_opening, ev, ch, polys, cv.name)

@@ -160,6 +160,8 @@ ROUND4_CHALLENGES = (("alpha", "alpha"),                                        
 QUOTIENT_COMMITS = ("t_1", "t_2", "t_3", "t_4")                                 # :472-475
 EVAL_LABELS = ("a_eval", "b_eval", "c_eval", "d_eval", "left_sig_eval", "right_sig_eval", "out_sig_eval", "perm_eval",
                "f_eval", "q_lookup_eval", "lookup_perm_eval", "h_1_eval", "h_1_next_eval", "h_2_eval")   # :516-544
+# labels of `CustomEvaluations.vals`, in push order (linearisation_poly.rs:243-253: `label_eval!` = the identifier's name)
+CUSTOM_EVAL_LABELS = ("q_arith_eval", "q_c_eval", "q_l_eval", "q_r_eval", "a_next_eval", "b_next_eval", "d_next_eval")
 # order of the 16 fixed evaluations inside the serialised Proof (linearisation_poly.rs:34-104)
 PROOF_EVAL_FIELDS = ("a_eval", "b_eval", "c_eval", "d_eval", "left_sigma_eval", "right_sigma_eval", "out_sigma_eval", "permutation_eval",
                      "q_lookup_eval", "z2_next_eval", "h1_eval", "h1_next_eval", "h2_eval", "f_eval", "table_eval", "table_next_eval")

@@ -1,0 +1,160 @@
+"""`Prover::prove_with_preprocessed` end to end on the device (ark_plonk_amd/prover.py: every O(n) step through the C ABI, the
+library's merlin transcript, the library's proof serialisation) against the reference VERIFIER restated on integers
+(oracle/verifier_oracle.py: proof.rs:110-611 with the pairing replaced by the same equation on discrete logarithms, which the test
+can do because it knows tau).
+
+The circuit is a real satisfied one: arithmetic gates with every selector in play, public inputs, copy constraints that move
+values between wires and rows (so z is not constant), lookup gates into a padded four-column table -- and all-zero range / logic /
+ECC selectors (their commitments are the point at infinity).  A proof for a witness with ONE wrong cell must fail."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ark_plonk_amd as zk  # noqa: E402
+from ark_plonk_amd import linearisation, prover, transcript  # noqa: E402
+from ark_plonk_amd.curves import fr_from_mont, fr_to_mont  # noqa: E402
+from oracle import bigint_oracle as bo  # noqa: E402
+from oracle import verifier_oracle as vo  # noqa: E402
+from oracle import wire_oracle as wo  # noqa: E402
+from tests.conftest import TAU, assert_is_scalar_times_g, srs_from_powers, tau_powers  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+K = (1, 7, 13, 17)
+
+
+def dev(cid, ints):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(fr_to_mont(cid, ints)).view(np.int64).reshape(-1, 4)).cuda()
+
+
+def build_circuit(cv, log_n, seed, break_cell=False):
+    """Selector / sigma / table / wire columns of a satisfied circuit as integer lists, and its public inputs."""
+    p, n = cv.r, 1 << log_n
+    rng = np.random.default_rng(seed)
+    rnd = lambda k, s: bo.seeded_scalars(cv, seed * 1000 + s, k)  # noqa: E731
+    used = n - 5                                                     # a few all-zero padding rows at the end
+    sel = {name: [0] * n for name in prover.SELECTORS}
+    a, b, c, d = ([0] * n for _ in range(4))
+    # the table: n/4 distinct rows, padded with its first row
+    rows = max(n // 4, 2)
+    tcols = [rnd(rows, 10 + k) for k in range(4)]
+    table = [[col[i] if i < rows else col[0] for i in range(n)] for col in tcols]
+    ra, rb, rd = rnd(n, 1), rnd(n, 2), rnd(n, 3)
+    qs = {name: rnd(n, 20 + k) for k, name in enumerate(("q_m", "q_l", "q_r", "q_4", "q_c"))}
+    is_lookup = [bool(rng.integers(0, 3) == 0) and 0 < i < used for i in range(n)]
+    pub = {1: rnd(1, 40)[0], 3: rnd(1, 41)[0]}
+    for i in range(used):
+        if is_lookup[i]:
+            j = int(rng.integers(0, rows))
+            a[i], b[i], c[i], d[i] = (tcols[k][j] for k in range(4))
+            sel["q_lookup"][i] = 1
+        else:
+            a[i], b[i], d[i] = ra[i], rb[i], rd[i]
+    # copy constraints before the outputs are computed: cell (wire, row) pairs that must hold one value
+    sigma = [[K[k] * pow(cv.root_of_unity(log_n), i, p) % p for i in range(n)] for k in range(4)]
+    free = [i for i in range(5, used) if not is_lookup[i]]
+    for t in range(0, min(len(free) - 1, 12), 2):
+        i, j = free[t], free[t + 1]
+        (w1, r1), (w2, r2) = ((0, i), (1, j)) if t % 4 == 0 else ((3, i), (0, j))      # a_i = b_j, then d_i = a_j
+        cols = (a, b, c, d)
+        cols[w2][r2] = cols[w1][r1]
+        sigma[w1][r1], sigma[w2][r2] = sigma[w2][r2], sigma[w1][r1]                    # a 2-cycle
+    for i in range(used):
+        if not is_lookup[i]:
+            for name in qs:
+                sel[name][i] = qs[name][i]
+            sel["q_o"][i] = p - 1
+            sel["q_arith"][i] = 1
+            c[i] = (sel["q_m"][i] * a[i] * b[i] + sel["q_l"][i] * a[i] + sel["q_r"][i] * b[i] + sel["q_4"][i] * d[i] + sel["q_c"][i]
+                    + pub.get(i, 0)) % p
+    pub = {i: v for i, v in pub.items() if not is_lookup[i]}
+    if break_cell:
+        c[free[3]] = (c[free[3]] + 1) % p
+    return sel, sigma, table, [a, b, c, d], pub
+
+
+def run_case(cid, log_n, ctx, oracle_cpu, break_cell=False):
+    cv = bo.CURVES[cid]
+    n = 1 << log_n
+    sel, sigma, table, wires, pub = build_circuit(cv, log_n, 7 + log_n + cid, break_cell)
+    dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
+    dom4 = zk.Radix2EvaluationDomain.new(4 * n, cid, ctx)
+    pk = prover.ProverKey(dom, dom4, {k: dev(cid, v) for k, v in sel.items()}, [dev(cid, s) for s in sigma], [dev(cid, t) for t in table])
+    pw_canon, _ = tau_powers(oracle_cpu, cid, n + 8)
+    ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
+    pre = transcript.Transcript(b"end to end", cid)
+    pre.circuit_domain_sep(n)
+    ca, cd = bo.seeded_scalars(cv, 0x51, 2)                                  # any coefficients: the ECC selectors are zero
+    proof = prover.prove(pk, ck, [dev(cid, w) for w in wires], {i: fr_to_mont(cid, [v])[0] for i, v in pub.items()}, pre,
+                         fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
+    return cv, pk, ck, proof, pub, (ca, cd), wires
+
+
+KEY = {"q_m": "q_m", "q_l": "q_l", "q_r": "q_r", "q_o": "q_o", "q_4": "q_4", "q_c": "q_c", "q_arith": "q_arith", "q_range": "q_range",
+       "q_logic": "q_logic", "q_fixed": "q_fixed_group_add", "q_var": "q_variable_group_add", "q_lookup": "q_lookup"}
+
+
+def dlogs(cid, ctx, pk, proof):
+    """polynomial(tau) for every commitment of the verifier key and of the proof, from the device-resident polynomials
+    (zk_poly_evaluate_dev).  The opening witnesses are canonical scalars: read as Montgomery values they are off by the factor R."""
+    cv = bo.CURVES[cid]
+    polys = {k: pk.polys[v] for k, v in KEY.items()}
+    polys.update({f"sigma{k}": pk.sigma_polys[k] for k in range(4)})
+    polys.update({f"table_{k + 1}": pk.domain.ifft(pk.table_cols[k]) for k in range(4)})
+    polys.update(proof.polys)
+    names = list(polys)
+    tau_m = fr_to_mont(cid, [TAU])
+    vals = fr_from_mont(cid, linearisation.evaluate_batch([polys[k] for k in names], np.repeat(tau_m, len(names), axis=0), cid, ctx))
+    d = dict(zip(names, vals))
+    for k in ("aw", "saw"):
+        d[f"{k}_opening"] = d.pop(f"{k}_witness") * (1 << 256) % cv.r
+    return d
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 5), (0, 10), (0, 14), (1, 7)])
+def test_device_prover_satisfies_the_reference_verifier(cid, log_n, ctx, oracle_cpu):
+    import torch
+    cv, pk, ck, proof, pub, (ca, cd), wires = run_case(cid, log_n, ctx, oracle_cpu)
+    n = 1 << log_n
+    data = proof.to_bytes()
+    # -- the logarithm of every commitment: its polynomial at tau, bound to the proof's points by scalar multiplication
+    ch = proof.challenges
+    dlog = dlogs(cid, ctx, pk, proof)
+    for k in vo.COMMITMENTS:
+        assert_is_scalar_times_g(proof.commitments[k], dlog[k], cid)
+    assert_is_scalar_times_g(proof.aw_opening, dlog["aw_opening"], cid)
+    assert_is_scalar_times_g(proof.saw_opening, dlog["saw_opening"], cid)
+    # -- the verifier
+    t = wo.PlonkTranscript(b"end to end", cv)
+    t.circuit_domain_sep(n)
+    ok, vch, det = vo.verify_with_trapdoor(cv, log_n, data, t, pub, dlog, TAU, ca, cd)
+    assert ok, det
+    # the library's transcript and the independent one agree on every challenge
+    mine = {k: fr_from_mont(cid, np.asarray(v).reshape(1, 4))[0] for k, v in ch.items()}
+    for a, b in (("zeta", "zeta"), ("beta", "beta"), ("gamma", "gamma"), ("delta", "delta"), ("epsilon", "epsilon"), ("alpha", "alpha"),
+                 ("range", "range_challenge"), ("logic", "logic_challenge"), ("fixed", "fixed_base_challenge"), ("var", "var_base_challenge"),
+                 ("lookup", "lookup_challenge"), ("z", "z_challenge"), ("aw", "aw_challenge"), ("saw", "saw_challenge")):
+        assert vch[a] == mine[b], a
+    # the bytes are the reference layout: the independent serialiser rebuilds them from the parsed proof
+    pr = det["proof"]
+    assert wo.proof_bytes(cv, [pr["commitments"][k] for k in vo.COMMITMENTS], [pr["aw_opening"], pr["saw_opening"]],
+                          [pr["evals"][k] for k in vo.EVALS], pr["custom"]) == data
+    # all-zero selectors commit to the point at infinity and z is not the constant 1
+    assert pr["commitments"]["z_comm"] != (cv.gx, cv.gy)
+    assert torch.count_nonzero(pk.polys["q_range"]).item() == 0
+
+
+def test_wrong_witness_does_not_verify(ctx, oracle_cpu):
+    """One output cell off by one: the prover still runs (the quotient is no longer a polynomial of degree < 4n, its coset iFFT is
+    just some vector) and the aggregate opening at z fails the verifier's equation."""
+    cid, log_n = 0, 6
+    cv, pk, ck, proof, pub, (ca, cd), wires = run_case(cid, log_n, ctx, oracle_cpu, break_cell=True)
+    dlog = dlogs(cid, ctx, pk, proof)
+    t = wo.PlonkTranscript(b"end to end", cv)
+    t.circuit_domain_sep(1 << log_n)
+    ok, _, det = vo.verify_with_trapdoor(cv, log_n, proof.to_bytes(), t, pub, dlog, TAU, ca, cd)
+    assert not ok and not det["aw"]

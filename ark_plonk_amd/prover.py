@@ -144,3 +144,105 @@ def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcrip
              "h_1_comm": h1_poly, "h_2_comm": h2_poly, "z_2_comm": z2_poly, "t_1_comm": t_parts[0], "t_2_comm": t_parts[1],
              "t_3_comm": t_parts[2], "t_4_comm": t_parts[3], "lin": lin_poly, "aw_witness": aw_witness, "saw_witness": saw_witness}
     return Proof(commitments, aw_opening, saw_opening, ev, ch, polys, cv.name)
+
+
+def check_identity(pk: ProverKey, proof: Proof, public_inputs: dict) -> bool:
+    """The equation the verifier's first opening rests on, checked on the polynomials themselves: lin(z) = -r_0 with r_0 as
+    `Proof::compute_r0` builds it from the evaluations (proof.rs:427-486).  It holds iff the quotient really is
+    (gates + permutation + lookup) / Z_H at z, i.e. (with overwhelming probability over z) iff the witness satisfies the circuit."""
+    d = pk.domain
+    cv = get_curve(d.curve)
+    p, n = cv.r, d.size()
+    ctx = d._ctx_for(proof.polys["lin"])
+    ch = {k: fr_from_mont(cv, np.asarray(v, dtype=np.uint64).reshape(1, 4))[0] for k, v in proof.challenges.items()}
+    ev = {k: fr_from_mont(cv, np.asarray(v, dtype=np.uint64).reshape(1, 4))[0] for k, v in proof.evaluations.items()}
+    z = ch["z_challenge"]
+    lin_z = fr_from_mont(cv, linearisation.evaluate_batch([proof.polys["lin"]], proof.challenges["z_challenge"].reshape(1, 4), cv, ctx))[0]
+    zh = (pow(z, n, p) - 1) % p
+    l1 = zh * pow(n * (z - 1) % p, -1, p) % p
+    w = fr_from_mont(cv, np.asarray(d.group_gen(), dtype=np.uint64).reshape(1, 4))[0]
+    pi_z = 0
+    for i, v in public_inputs.items():                                                                    # proof.rs:635-680
+        wi = pow(w, i, p)
+        pi_z += fr_from_mont(cv, np.asarray(v, dtype=np.uint64).reshape(1, 4))[0] * wi % p * zh % p * pow(n * (z - wi) % p, -1, p)
+    al, be, ga, de, ep, ls = ch["alpha"], ch["beta"], ch["gamma"], ch["delta"], ch["epsilon"], ch["lookup_challenge"]
+    b = (ev["a_eval"] + be * ev["left_sigma_eval"] + ga) * (ev["b_eval"] + be * ev["right_sigma_eval"] + ga) \
+        * (ev["c_eval"] + be * ev["out_sigma_eval"] + ga) * (ev["d_eval"] + ga) * ev["permutation_eval"] * al
+    e1d = ep * (1 + de)
+    dd = ls * ls * ev["z2_next_eval"] * (e1d + de * ev["h2_eval"]) * (e1d + ev["h2_eval"] + de * ev["h1_next_eval"])
+    r0 = (pi_z - b - l1 * al * al - dd - ls ** 3 * l1) % p
+    return (lin_z + r0) % p == 0
+
+
+def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99):
+    """A satisfied circuit of n = 2^log_n rows built ON the device: arithmetic gates with random selectors on about two thirds of
+    the rows (q_o = -1, the output wire computed from the others), public inputs on rows 1 and 3, six copy constraints that tie
+    cells of different wires and rows (2-cycles in sigma), lookup gates into a four-column table of n/4 distinct rows padded
+    with its first row on the remaining third, five all-zero padding rows, and all-zero range / logic / ECC selectors.
+    Returns (ProverKey, [w_l, w_r, w_o, w_4], public inputs {row: 4 Montgomery limbs})."""
+    import torch
+    from ._lib import check, lib
+    from .context import default_context
+    cv = get_curve(curve)
+    cid, p, n = cv.curve_id, cv.r, 1 << log_n
+    if n < 32:
+        raise ValueError("example_circuit needs at least 32 rows")
+    ctx = ctx or default_context(0)
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    dom = Radix2EvaluationDomain.new(n, cv, ctx)
+    dom4 = Radix2EvaluationDomain.new(4 * n, cv, ctx)
+
+    def rnd(rows):
+        t = torch.randint(0, 1 << 62, (rows, 4), dtype=torch.int64, device=dev, generator=g)
+        t[:, 3] &= (1 << 60) - 1                     # < 2^252: a reduced element of either curve's scalar field
+        return t
+
+    def mul(x, y):
+        o = torch.empty_like(x)
+        ctx.use_torch_stream()
+        check(lib().zk_fr_mul_dev(ctx.handle, cid, x.data_ptr(), y.data_ptr(), n, o.data_ptr()), "zk_fr_mul_dev")
+        return o
+
+    def const(v):
+        return torch.from_numpy(fr_to_mont(cv, [v])[0].view(np.int64)).to(dev)
+
+    zero = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    used = n - 5
+    row = torch.arange(n, device=dev)
+    rows = n // 4
+    tsrc = [rnd(n) for _ in range(4)]
+    rep = torch.where(row < rows, row, torch.zeros_like(row))
+    table = [c[rep].contiguous() for c in tsrc]
+    is_lookup = (torch.randint(0, 3, (n,), device=dev, generator=g) == 0) & (row > 4) & (row < used)
+    live = (~is_lookup) & (row < used)
+    pick = torch.randint(0, rows, (n,), device=dev, generator=g)
+    lk, lv = is_lookup.unsqueeze(1), live.unsqueeze(1)
+    a, b, d = (torch.where(lk, table[k][pick], torch.where(lv, rnd(n), zero)).contiguous() for k in (0, 1, 3))
+    x_poly = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    x_poly[1] = const(1)
+    omega_i = dom.fft(x_poly)                        # the evaluations of X over the domain: omega^i
+    ks = (1, linearisation.K1, linearisation.K2, linearisation.K3)
+    sigma = [linearisation.lincomb([omega_i], fr_to_mont(cv, [ks[k]]), curve=cv, ctx=ctx).clone() for k in range(4)]
+    free = torch.nonzero(live & (row >= 5)).flatten()[:12].tolist()
+    cols = {0: a, 1: b, 3: d}
+    for t in range(0, len(free) - 1, 2):
+        i, j = free[t], free[t + 1]
+        (w1, r1), (w2, r2) = ((0, i), (1, j)) if t % 4 == 0 else ((3, i), (0, j))      # a_i = b_j, then d_i = a_j
+        cols[w2][r2] = cols[w1][r1]
+        s1, s2 = sigma[w1][r1].clone(), sigma[w2][r2].clone()
+        sigma[w1][r1], sigma[w2][r2] = s2, s1
+    sel = {name: zero.clone() for name in SELECTORS}
+    for name in ("q_m", "q_l", "q_r", "q_4", "q_c"):
+        sel[name] = torch.where(lv, rnd(n), zero).contiguous()
+    sel["q_o"] = torch.where(lv, const(p - 1).expand(n, 4), zero).contiguous()
+    sel["q_arith"] = torch.where(lv, const(1).expand(n, 4), zero).contiguous()
+    sel["q_lookup"] = torch.where(lk, const(1).expand(n, 4), zero).contiguous()
+    pub = {1: rnd(1)[0].cpu().numpy().view(np.uint64), 3: rnd(1)[0].cpu().numpy().view(np.uint64)}
+    pi = zero.clone()
+    for i, v in pub.items():
+        pi[i] = torch.from_numpy(v.view(np.int64)).to(dev)
+    c_arith = linearisation.lincomb([mul(sel["q_m"], mul(a, b)), mul(sel["q_l"], a), mul(sel["q_r"], b), mul(sel["q_4"], d), sel["q_c"], pi],
+                                    fr_to_mont(cv, [1] * 6), curve=cv, ctx=ctx)
+    c = torch.where(lk, table[2][pick], c_arith).contiguous()
+    return ProverKey(dom, dom4, sel, sigma, table), [a, b, c, d], pub

@@ -158,3 +158,40 @@ def test_wrong_witness_does_not_verify(ctx, oracle_cpu):
     t.circuit_domain_sep(1 << log_n)
     ok, _, det = vo.verify_with_trapdoor(cv, log_n, proof.to_bytes(), t, pub, dlog, TAU, ca, cd)
     assert not ok and not det["aw"]
+
+
+def test_full_size_proof_verifies(ctx, oracle_cpu):
+    """n = 2^20 (BASELINE config 2): a satisfied circuit built on the device (prover.example_circuit), proved on the device, its
+    proof bytes checked by the restated verifier.  Prints the prover's wall time (all five rounds, every O(n) step on the device)."""
+    import time
+    import torch
+    cid, log_n = 0, 20
+    n = 1 << log_n
+    cv = bo.CURVES[cid]
+    pk, wires, pub_m = prover.example_circuit(log_n, cid, ctx)
+    pub = {i: fr_from_mont(cid, v.reshape(1, 4))[0] for i, v in pub_m.items()}
+    pw_canon, _ = tau_powers(oracle_cpu, cid, n)
+    ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
+    ck.precompute()
+    pre = transcript.Transcript(b"end to end", cid)
+    pre.circuit_domain_sep(n)
+    ca, cd = bo.seeded_scalars(cv, 0x51, 2)
+    args = (pk, ck, wires, pub_m, pre, fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
+    prover.prove(*args)                                           # warm-up (twiddle tables, buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    proof = prover.prove(*args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    data = proof.to_bytes()
+    print(f"\nfull proof at n = 2^{log_n}: {dt * 1e3:.1f} ms, {len(data)} bytes")
+    dlog = dlogs(cid, ctx, pk, proof)
+    for k in ("a_comm", "z_comm", "z_2_comm", "t_3_comm"):
+        assert_is_scalar_times_g(proof.commitments[k], dlog[k], cid)
+    assert_is_scalar_times_g(proof.aw_opening, dlog["aw_opening"], cid)
+    t = wo.PlonkTranscript(b"end to end", cv)
+    t.circuit_domain_sep(n)
+    ok, _, det = vo.verify_with_trapdoor(cv, log_n, data, t, pub, dlog, TAU, ca, cd)
+    assert ok, (det["aw"], det["saw"])
+    assert prover.check_identity(pk, proof, pub_m)              # the product-side self check agrees
+    assert dt < 1.0

@@ -27,3 +27,7 @@ def test_stress_msm_short(ctx, oracle_cpu):
 
 def test_stress_kzg_short(ctx, oracle_cpu):
     assert _load("stress_kzg").run(budget=12.0, seed=30, ctx=ctx, max_len=1 << 16) >= 10
+
+
+def test_stress_rounds_short(ctx, oracle_cpu):
+    assert _load("stress_rounds").run(budget=12.0, seed=40, ctx=ctx, max_len=1 << 15) >= 20

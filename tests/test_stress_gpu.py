@@ -31,3 +31,7 @@ def test_stress_kzg_short(ctx, oracle_cpu):
 
 def test_stress_rounds_short(ctx, oracle_cpu):
     assert _load("stress_rounds").run(budget=12.0, seed=40, ctx=ctx, max_len=1 << 15) >= 20
+
+
+def test_stress_prover_short(ctx, oracle_cpu):
+    assert _load("stress_prover").run(budget=12.0, seed=50, ctx=ctx, max_log_n=9) >= 5

@@ -9,7 +9,7 @@ from ark_plonk_amd import _lib
 ctx = zk.Context(0)
 ctx.use_torch_stream()
 cv = zk.get_curve(0)
-nmax = 1 << 20
+nmax = 1 << int(os.environ.get('LOG_NMAX', '20'))
 g = torch.Generator(device="cuda").manual_seed(1)
 ks = torch.randint(1, 1 << 62, (nmax, 4), dtype=torch.int64, device="cuda", generator=g)
 ks[:, 1:] = 0

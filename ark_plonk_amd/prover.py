@@ -77,7 +77,7 @@ def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcrip
     (pi.rs:28-36); preprocessed: the transcript after the verifier key was seeded into it; coeff_a / coeff_d: the embedded
     curve's coefficients (`P::COEFF_A`, `P::COEFF_D`).
     lean=False issues the reference's 29 MSMs in the reference's 11 calls.  lean=True produces the SAME proof with 15 MSMs in 5
-    calls: the 14 commitments of prover.rs:579,606 are never used (KZG10's `open` ignores the commitments it is handed, the
+    calls: the 14 commitments of prover.rs:579,606 are never used (ark-poly-commit 0.3's SonicKZG10 `open` does not read its `commitments` argument (published source; the crate is not in this container), the
     `Proof` holds none of them except z's, which round 3 already has, and the verifier rebuilds them -- proof.rs:343-395), f / h_1 /
     h_2 and z / z_2 have no transcript challenge between them, and the two opening witnesses are known together."""
     import torch

@@ -596,7 +596,7 @@ def main():
             ckp.close()
             return {"proofs_per_s": k2 / dtp, "ms_per_proof": dtp / k2 * 1e3, "proof_bytes": nbytes, "verifier_identity_holds": bool(ok),
                     "lean": {"proofs_per_s": k2 / dtl, "ms_per_proof": dtl / k2 * 1e3, "msms": 15, "same_proof_bytes": bool(same),
-                             "how": "the 14 commitments of prover.rs:579,606 are used by nobody (KZG10 open ignores them, the Proof holds none but z's, "
+                             "how": "the 14 commitments of prover.rs:579,606 are used by nobody (SonicKZG10's open does not read them, the Proof holds none but z's, "
                                     "the verifier rebuilds them): 15 MSMs in 5 calls instead of 29 in 11, identical bytes"},
                     "what": "a satisfied circuit of 2^%d rows proved end to end on the device (31 NTTs, 29 MSMs, round-2 lookup multisets, both grand "
                             "products, the pointwise quotient, 23 evaluations, the linearisation polynomial, merlin transcript, proof bytes); "

@@ -1692,7 +1692,7 @@ constexpr uint32_t PRE_C = 16;        // default window of the precomputed table
 constexpr uint32_t PRE_C_MAX = 21;    // 2^20 shared buckets: 4096 per partition in the second sort pass (144 KiB of LDS)
 constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
 constexpr uint32_t PRE_Q_OFF = 1024;  // words of part_key in front of the combine queues (partition starts, totals, counter)
-constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket reduction: 128 chains x 4 lanes per workgroup
+constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket reduction: 512 buckets = 64 chains x 4 lanes per workgroup
                                       // (256 registers per lane; with 32 windows the 1024-lane workgroup spilled at 128)
 
 template <class Cv>
@@ -1757,7 +1757,20 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     pl.gv.W = pl.wide ? pl.g.B / WIDE_VB : PRE_VW;
     pl.gv.B = pl.g.B / pl.gv.W;
     pl.gv.nb = pl.g.B;
-    pl.gv.logG = 2;
+    pl.gv.logG = pl.wide ? 2 : 3;     // 8 buckets per segment: 64 chains (one wavefront per SIMD) per virtual window; measured against 4 / 16
+    if (!pl.wide) {                                       // tuning hooks (profiles/r02_notes.md)
+        if (const char* e = getenv("ZK_PRE_VW")) {
+            const uint32_t v = (uint32_t)atoi(e);
+            if (v >= 8 && v <= 512 && (v & (v - 1)) == 0 && pl.g.B % v == 0) {
+                pl.gv.W = v;
+                pl.gv.B = pl.g.B / v;
+            }
+        }
+        if (const char* e = getenv("ZK_PRE_LOGG")) {
+            const uint32_t v = (uint32_t)atoi(e);
+            if (v <= 5 && (pl.gv.B >> v) >= 1) pl.gv.logG = v;
+        }
+    }
     pl.gv.ns = pl.gv.B >> pl.gv.logG;
     pl.gv.logq = 0;
     while ((256u << pl.gv.logq) < pl.gv.ns) ++pl.gv.logq;

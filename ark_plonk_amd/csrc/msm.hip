@@ -800,11 +800,8 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
 // PRE: references carry a window number and `bases` is the window-multiples table [W][n_srs]
 // (row w holds 2^(c w) P_i); tab_stride = n_srs, tab_off = base_offset.
 template <class F, bool PRE>
-__global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
-                                                       void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes, uint64_t tab_stride,
-                                                       uint64_t tab_off) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_lanes) return;
+ZK_D void accumulate_chunk(const uint32_t t, const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases, void* buckets,
+                           void* part_pt, uint32_t L, uint64_t tab_stride, uint64_t tab_off) {
     const uint32_t E = offsets[nb];
     const uint64_t e0 = (uint64_t)t * L;
     if (e0 >= E) return;
@@ -858,6 +855,15 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
         if (tail_complete) st_xyzz<F>(buckets, b, acc);
         else st_xyzz<F>(part_pt, 2ull * t + 1, acc);
     }
+}
+
+template <class F, bool PRE>
+__global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
+                                                       void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes, uint64_t tab_stride,
+                                                       uint64_t tab_off) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lanes) return;
+    accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, tab_stride, tab_off);
 }
 
 // The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by

@@ -49,6 +49,14 @@ class ProverKey:
         self.sigma4n = [domain_4n.coset_fft(p) for p in self.sigma_polys]
         self.table_cols = list(table_cols)
 
+    def with_ctx(self, ctx) -> "ProverKey":
+        """The same device-resident key driven from another Context (its own stream / thread) of the same GPU."""
+        other = object.__new__(ProverKey)
+        other.__dict__.update(self.__dict__)
+        other.domain = Radix2EvaluationDomain.new(self.domain.size(), self.domain.curve, ctx)
+        other.domain_4n = Radix2EvaluationDomain.new(self.domain_4n.size(), self.domain.curve, ctx)
+        return other
+
     def linearisation_key(self) -> dict:
         k = dict(self.polys)
         k.update(left_sigma=self.sigma_polys[0], right_sigma=self.sigma_polys[1], out_sigma=self.sigma_polys[2], fourth_sigma=self.sigma_polys[3])

@@ -593,9 +593,49 @@ def main():
             torch.cuda.synchronize()
             dtl = time.perf_counter() - t0
             same = lean.to_bytes() == data
+            # the same lean proofs, three in flight (a thread + zk_ctx + HIP stream each over ONE prover key, SRS and window table)
+            import threading
+            S3 = 3
+            lanes3 = []
+            for i in range(S3):
+                cx = ctx if i == 0 else zk.Context(dev)
+                st3 = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+                lanes3.append((cx, st3, (pk if i == 0 else pk.with_ctx(cx), ckp if i == 0 else ckp.with_ctx(cx)) + a[2:]))
+            for cx, st3, a3 in lanes3[1:]:
+                with torch.cuda.stream(st3):
+                    prover.prove(*a3, lean=True)
+            torch.cuda.synchronize()
+            gate, errs3, outs3 = threading.Barrier(S3 + 1), [], [None] * S3
+
+            def lane3(i):
+                cx, st3, a3 = lanes3[i]
+                try:
+                    with torch.cuda.stream(st3):
+                        gate.wait()
+                        for _ in range(k2):
+                            outs3[i] = prover.prove(*a3, lean=True)
+                        st3.synchronize()
+                except Exception as e:
+                    errs3.append(e)
+                    gate.abort()
+            th3 = [threading.Thread(target=lane3, args=(i,)) for i in range(S3)]
+            for t in th3:
+                t.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for t in th3:
+                t.join()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            if errs3:
+                raise errs3[0]
+            same3 = all(o.to_bytes() == data for o in outs3)
+            for cx, _, _ in lanes3[1:]:
+                cx.close()
             ckp.close()
             return {"proofs_per_s": k2 / dtp, "ms_per_proof": dtp / k2 * 1e3, "proof_bytes": nbytes, "verifier_identity_holds": bool(ok),
                     "lean": {"proofs_per_s": k2 / dtl, "ms_per_proof": dtl / k2 * 1e3, "msms": 15, "same_proof_bytes": bool(same),
+                             "three_in_flight": {"proofs_per_s": S3 * k2 / dt3, "ms_per_proof_aggregate": dt3 / (S3 * k2) * 1e3, "same_proof_bytes": bool(same3)},
                              "how": "the 14 commitments of prover.rs:579,606 are used by nobody (SonicKZG10's open does not read them, the Proof holds none but z's, "
                                     "the verifier rebuilds them): 15 MSMs in 5 calls instead of 29 in 11, identical bytes"},
                     "what": "a satisfied circuit of 2^%d rows proved end to end on the device (31 NTTs, 29 MSMs, round-2 lookup multisets, both grand "

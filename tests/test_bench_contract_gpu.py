@@ -39,7 +39,7 @@ def test_bench_json_contract():
     assert d["no_precompute"]["commitments_match"] is True
     # a real proof of a satisfied circuit, end to end on the device, and the rounds' O(n) glue inside the synthetic step
     assert d["full_proof"]["verifier_identity_holds"] is True and d["full_proof"]["proof_bytes"] == 1591 and d["full_proof"]["proofs_per_s"] > 0
-    assert d["full_proof"]["lean"]["same_proof_bytes"] is True
+    assert d["full_proof"]["lean"]["same_proof_bytes"] is True and d["full_proof"]["lean"]["three_in_flight"]["same_proof_bytes"] is True
     assert d["with_device_glue"]["proofs_per_s"] > 0 and d["with_device_glue"]["lookup_round2_ms_per_proof"] > 0
     assert rf["valu"]["mixed_adds_per_scalar"] == 16 and "traffic_source" in rf
 

@@ -45,7 +45,8 @@ def run(budget: float = 120.0, seed: int = 7, ctx=None, max_log_n: int = 11):
         n = 1 << log_n
         cv = bo.CURVES[cid]
         broken = bool(rng.random() < 0.3)
-        sel, sigma, table, wires, pub = H.build_circuit(cv, log_n, int(rng.integers(1, 1 << 30)), break_cell=broken)
+        ca, cd = bo.seeded_scalars(cv, int(rng.integers(1, 1 << 20)), 2)
+        sel, sigma, table, wires, pub = H.build_circuit(cv, log_n, int(rng.integers(1, 1 << 30)), break_cell=broken, coeffs=(ca, cd))
         dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
         dom4 = zk.Radix2EvaluationDomain.new(4 * n, cid, ctx)
         pk = prover.ProverKey(dom, dom4, {k: H.dev(cid, v) for k, v in sel.items()}, [H.dev(cid, s) for s in sigma], [H.dev(cid, t) for t in table])
@@ -56,7 +57,6 @@ def run(budget: float = 120.0, seed: int = 7, ctx=None, max_log_n: int = 11):
         label = b"stress %d" % int(rng.integers(0, 1000))
         pre = transcript.Transcript(label, cid)
         pre.circuit_domain_sep(n)
-        ca, cd = bo.seeded_scalars(cv, int(rng.integers(1, 1 << 20)), 2)
         args = (pk, ck, [H.dev(cid, w) for w in wires], {i: fr_to_mont(cid, [v])[0] for i, v in pub.items()}, pre, fr_to_mont(cid, [ca])[0],
                 fr_to_mont(cid, [cd])[0])
         lean = bool(rng.integers(0, 2))

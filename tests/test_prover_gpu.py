@@ -4,8 +4,10 @@ library's merlin transcript, the library's proof serialisation) against the refe
 can do because it knows tau).
 
 The circuit is a real satisfied one: arithmetic gates with every selector in play, public inputs, copy constraints that move
-values between wires and rows (so z is not constant), lookup gates into a padded four-column table -- and all-zero range / logic /
-ECC selectors (their commitments are the point at infinity).  A proof for a witness with ONE wrong cell must fail."""
+values between wires and rows (so z is not constant), lookup gates into a padded four-column table and -- from 128 rows up -- runs of
+every other gate the reference has: range (base-4 accumulator chains, widget/range.rs), logic (AND and XOR quads, widget/logic.rs),
+curve addition and fixed-base scalar multiplication steps over a twisted Edwards curve with random coefficients (widget/ecc/*.rs).
+At 32 rows those four selectors are all-zero (their commitments are the point at infinity).  A witness with ONE wrong cell must fail."""
 import os
 import sys
 
@@ -31,7 +33,80 @@ def dev(cid, ints):
     return torch.from_numpy(np.ascontiguousarray(fr_to_mont(cid, ints)).view(np.int64).reshape(-1, 4)).cuda()
 
 
-def build_circuit(cv, log_n, seed, break_cell=False):
+def add_gadgets(cv, base, sel, a, b, c, d, rnd, ca, cd):
+    """Runs of range / logic / curve-addition / fixed-base rows starting at row `base`, each followed by an ordinary arithmetic row
+    that absorbs the run's "next row" values in its a, b, d wires (its c is computed later).  Returns the rows that are NOT free
+    arithmetic rows (the gadget rows) and the terminal rows."""
+    p = cv.r
+    inv = lambda x: pow(x % p, -1, p)  # noqa: E731
+    quads = [int(v % 4) for v in rnd(64, 90)]
+    gadget, terminal = [], []
+    r = base
+    # -- range (widget/range.rs:47-63): c - 4d, b - 4c, a - 4b, d_next - 4a in {0,1,2,3}
+    acc = rnd(1, 91)[0]
+    for k in range(6):
+        d[r] = acc
+        c[r] = (4 * d[r] + quads[4 * k]) % p
+        b[r] = (4 * c[r] + quads[4 * k + 1]) % p
+        a[r] = (4 * b[r] + quads[4 * k + 2]) % p
+        acc = (4 * a[r] + quads[4 * k + 3]) % p
+        sel["q_range"][r] = 1
+        gadget.append(r)
+        r += 1
+    d[r] = acc
+    terminal.append(r)
+    r += 1
+    # -- logic (widget/logic.rs:65-133): q_c = 1 is AND, q_c = -1 is XOR on base-4 digits; c holds the product of the two digits
+    xa, xb, xd = rnd(3, 92)
+    for k in range(6):
+        qa, qb = quads[24 + 2 * k], quads[25 + 2 * k]
+        is_and = k % 2 == 0
+        a[r], b[r], d[r] = xa, xb, xd
+        c[r] = qa * qb
+        xa, xb = (4 * xa + qa) % p, (4 * xb + qb) % p
+        xd = (4 * xd + ((qa & qb) if is_and else (qa ^ qb))) % p
+        sel["q_logic"][r] = 1
+        sel["q_c"][r] = 1 if is_and else p - 1
+        gadget.append(r)
+        r += 1
+    a[r], b[r], d[r] = xa, xb, xd
+    terminal.append(r)
+    r += 1
+    # -- curve addition (widget/ecc/curve_addition.rs:62-97): (x1, y1) + (x2, y2) by the twisted Edwards formulas with coefficients ca, cd;
+    #    the row after it holds the sum in a, b and x1 * y2 in d
+    for k in range(4):
+        x1, y1, x2, y2 = rnd(4, 94 + k)
+        a[r], b[r], c[r], d[r] = x1, y1, x2, y2
+        x1y2, y1x2 = x1 * y2 % p, y1 * x2 % p
+        x3 = (x1y2 + y1x2) * inv(1 + cd * x1y2 % p * y1x2) % p
+        y3 = (y1 * y2 - ca * x1 * x2) * inv(1 - cd * x1y2 % p * y1x2) % p
+        sel["q_variable_group_add"][r] = 1
+        gadget.append(r)
+        r += 1
+        a[r], b[r], d[r] = x3, y3, x1y2
+        terminal.append(r)
+        r += 1
+    # -- fixed-base scalar multiplication step (widget/ecc/fixed_base_scalar_mul.rs:88-156): bit = d_next - 2d in {-1, 0, 1}
+    ax, ay, ad = rnd(3, 110)
+    for k, bit in enumerate((1, 0, p - 1, 1, p - 1)):
+        xb, yb, xyb = rnd(3, 111 + k)
+        sel["q_l"][r], sel["q_r"][r], sel["q_c"][r] = xb, yb, xyb
+        sel["q_fixed_group_add"][r] = 1
+        a[r], b[r], d[r] = ax, ay, ad
+        c[r] = bit * xyb % p                                       # xy_alpha
+        x_alpha, y_alpha = xb * bit % p, (bit * bit * (yb - 1) + 1) % p
+        t = cd * c[r] % p * ax % p * ay % p
+        ax, ay = (x_alpha * ay + y_alpha * ax) * inv(1 + t) % p, (y_alpha * ay - ca * x_alpha * ax) * inv(1 - t) % p
+        ad = (2 * ad + bit) % p
+        gadget.append(r)
+        r += 1
+    a[r], b[r], d[r] = ax, ay, ad
+    terminal.append(r)
+    r += 1
+    return gadget, terminal, r
+
+
+def build_circuit(cv, log_n, seed, break_cell=False, coeffs=(0, 0)):
     """Selector / sigma / table / wire columns of a satisfied circuit as integer lists, and its public inputs."""
     p, n = cv.r, 1 << log_n
     rng = np.random.default_rng(seed)
@@ -39,13 +114,16 @@ def build_circuit(cv, log_n, seed, break_cell=False):
     used = n - 5                                                     # a few all-zero padding rows at the end
     sel = {name: [0] * n for name in prover.SELECTORS}
     a, b, c, d = ([0] * n for _ in range(4))
+    gadget_rows, terminal_rows = set(), set()
+    g_base = used - 48
     # the table: n/4 distinct rows, padded with its first row
     rows = max(n // 4, 2)
     tcols = [rnd(rows, 10 + k) for k in range(4)]
     table = [[col[i] if i < rows else col[0] for i in range(n)] for col in tcols]
     ra, rb, rd = rnd(n, 1), rnd(n, 2), rnd(n, 3)
     qs = {name: rnd(n, 20 + k) for k, name in enumerate(("q_m", "q_l", "q_r", "q_4", "q_c"))}
-    is_lookup = [bool(rng.integers(0, 3) == 0) and 0 < i < used for i in range(n)]
+    reserved = set(range(g_base, used)) if n >= 128 else set()       # rows of the gadget runs: neither lookups nor random arithmetic
+    is_lookup = [bool(rng.integers(0, 3) == 0) and 0 < i < used and i not in reserved for i in range(n)]
     pub = {1: rnd(1, 40)[0], 3: rnd(1, 41)[0]}
     for i in range(used):
         if is_lookup[i]:
@@ -63,7 +141,13 @@ def build_circuit(cv, log_n, seed, break_cell=False):
         cols = (a, b, c, d)
         cols[w2][r2] = cols[w1][r1]
         sigma[w1][r1], sigma[w2][r2] = sigma[w2][r2], sigma[w1][r1]                    # a 2-cycle
+    if n >= 128:
+        g, t, end = add_gadgets(cv, g_base, sel, a, b, c, d, rnd, coeffs[0], coeffs[1])
+        assert end <= used
+        gadget_rows, terminal_rows = set(g), set(t)
     for i in range(used):
+        if i in gadget_rows:
+            continue
         if not is_lookup[i]:
             for name in qs:
                 sel[name][i] = qs[name][i]
@@ -80,7 +164,8 @@ def build_circuit(cv, log_n, seed, break_cell=False):
 def run_case(cid, log_n, ctx, oracle_cpu, break_cell=False):
     cv = bo.CURVES[cid]
     n = 1 << log_n
-    sel, sigma, table, wires, pub = build_circuit(cv, log_n, 7 + log_n + cid, break_cell)
+    ca, cd = bo.seeded_scalars(cv, 0x51, 2)                                  # the embedded curve's coefficients: any two field elements
+    sel, sigma, table, wires, pub = build_circuit(cv, log_n, 7 + log_n + cid, break_cell, (ca, cd))
     dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
     dom4 = zk.Radix2EvaluationDomain.new(4 * n, cid, ctx)
     pk = prover.ProverKey(dom, dom4, {k: dev(cid, v) for k, v in sel.items()}, [dev(cid, s) for s in sigma], [dev(cid, t) for t in table])
@@ -88,7 +173,6 @@ def run_case(cid, log_n, ctx, oracle_cpu, break_cell=False):
     ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
     pre = transcript.Transcript(b"end to end", cid)
     pre.circuit_domain_sep(n)
-    ca, cd = bo.seeded_scalars(cv, 0x51, 2)                                  # any coefficients: the ECC selectors are zero
     proof = prover.prove(pk, ck, [dev(cid, w) for w in wires], {i: fr_to_mont(cid, [v])[0] for i, v in pub.items()}, pre,
                          fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
     return cv, pk, ck, proof, pub, (ca, cd), wires
@@ -145,7 +229,11 @@ def test_device_prover_satisfies_the_reference_verifier(cid, log_n, ctx, oracle_
                           [pr["evals"][k] for k in vo.EVALS], pr["custom"]) == data
     # all-zero selectors commit to the point at infinity and z is not the constant 1
     assert pr["commitments"]["z_comm"] != (cv.gx, cv.gy)
-    assert torch.count_nonzero(pk.polys["q_range"]).item() == 0
+    if n < 128:                                       # no gadget runs: the four selectors are zero polynomials
+        assert torch.count_nonzero(pk.polys["q_range"]).item() == 0 and pr["commitments"]["z_comm"] is not None
+    else:                                             # every widget contributes to this proof
+        for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add", "q_lookup", "q_arith"):
+            assert torch.count_nonzero(pk.polys[name]).item() > 0, name
 
 
 def test_wrong_witness_does_not_verify(ctx, oracle_cpu):

@@ -22,7 +22,7 @@ def _strip(poly):
 def prove(cv: bo.Curve, log_n: int, sel: dict, sigma_evals, table_cols, wires, pub: dict, t: wo.PlonkTranscript, commit, ca: int, cd: int):
     """sel: selector evaluation vectors keyed by KEYS; sigma_evals / table_cols / wires: 4 lists of n; pub: {row: value};
     t: the transcript after the verifier key was seeded; commit(coefficients) -> affine point or None (KZG10 over the test's SRS).
-    Returns (proof bytes, challenges)."""
+    Returns (proof bytes, challenges, the polynomial behind every commitment and opening -- for a verifier that checks logarithms)."""
     p, n = cv.r, 1 << log_n
     ifft = lambda ev: bo.ntt(cv, 1, log_n, ev)                  # noqa: E731  domain.ifft
     coset4 = lambda poly: bo.ntt(cv, 2, log_n + 2, poly)        # noqa: E731  domain_4n.coset_fft
@@ -92,22 +92,29 @@ def prove(cv: bo.Curve, log_n: int, sel: dict, sigma_evals, table_cols, wires, p
     ch["saw"] = t.challenge_scalar(b"aggregate_witness")                                                  # :593-594
     saw_polys = [z_poly, w_polys[0], w_polys[1], w_polys[3], h1_poly, z2_poly, table_poly]                # :596-604
 
-    def open_(polys, point, chi):                                                                         # PC::open (kzg.hip header)
+    def witness(polys, point, chi):                                                                       # PC::open (kzg.hip header)
         m = max(len(q) for q in polys)
         comb, pw = [0] * m, 1
         for q in polys:
             for i, v in enumerate(q):
                 comb[i] = (comb[i] + pw * v) % p
             pw = pw * chi % p
-        return commit(bo.kzg_witness_poly(cv, comb, point))
+        return bo.kzg_witness_poly(cv, comb, point)
 
-    aw_open = open_(aw_polys, ch["z"], ch["aw"])                                                          # :582-591
-    saw_open = open_(saw_polys, ch["z"] * cv.root_of_unity(log_n) % p, ch["saw"])                         # :609-618
+    aw_w = witness(aw_polys, ch["z"], ch["aw"])                                                           # :582-591
+    saw_w = witness(saw_polys, ch["z"] * cv.root_of_unity(log_n) % p, ch["saw"])                          # :609-618
+    aw_open, saw_open = commit(aw_w), commit(saw_w)
     evals16 = [ev[k] for k in ("a_eval", "b_eval", "c_eval", "d_eval", "left_sigma_eval", "right_sigma_eval", "out_sigma_eval",
                                "permutation_eval", "q_lookup_eval", "z2_next_eval", "h1_eval", "h1_next_eval", "h2_eval", "f_eval",
                                "table_eval", "table_next_eval")]
     data = wo.proof_bytes(cv, w_comm + [z_comm, f_comm, h1_comm, h2_comm, z2_comm] + t_comm, [aw_open, saw_open], evals16, custom)
-    return data, ch
+    polys = {"a_comm": w_polys[0], "b_comm": w_polys[1], "c_comm": w_polys[2], "d_comm": w_polys[3], "z_comm": z_poly, "f_comm": f_poly,
+             "h_1_comm": h1_poly, "h_2_comm": h2_poly, "z_2_comm": z2_poly, "t_1_comm": t_parts[0], "t_2_comm": t_parts[1], "t_3_comm": t_parts[2],
+             "t_4_comm": t_parts[3], "aw_opening": aw_w, "saw_opening": saw_w}
+    polys.update(key_polys)
+    polys.update({f"sigma{k}": sigma_polys[k] for k in range(4)})
+    polys.update({f"table_{k + 1}": ifft(table_cols[k]) for k in range(4)})
+    return data, ch, polys
 
 
 def cpp_committer(cpu, cid: int, cv: bo.Curve, srs_mont_xy: np.ndarray):

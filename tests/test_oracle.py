@@ -218,3 +218,44 @@ def test_combine_split_oracle_on_the_reference_vector():
     assert h1 == [2, 2, 1, 3] and h2 == [2, 4, 3, 3]
     with pytest.raises(KeyError):
         bo.combine_split([1, 2, 3], [4])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_oracle_prover_and_oracle_verifier_agree(cid):
+    """No GPU: `Prover::prove_with_preprocessed` restated on integers (oracle/prover_oracle.py) produces a proof of a satisfied
+    128-row circuit with every gate type (tests/test_prover_gpu.py's builder) that `Proof::verify` restated on integers
+    (oracle/verifier_oracle.py, pairing -> known tau) accepts; one wrong witness cell and it does not.  The two restatements share
+    the widget formulas of bigint_oracle but nothing else: prover side = quotient by coset evaluations and a coset iFFT, verifier
+    side = r_0 and the linearisation scalars from the evaluations."""
+    import importlib.util
+    from oracle import cpu, prover_oracle as po, verifier_oracle as vo, wire_oracle as wo
+    cpu.build()
+    src = open(os.path.join(ROOT, "tests", "test_prover_gpu.py")).read()
+    ns = {"np": np, "bo": bo, "K": (1, 7, 13, 17),
+          "prover": type("P", (), {"SELECTORS": ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+                                                 "q_variable_group_add", "q_lookup")})}
+    exec(src[src.index("def add_gadgets"):src.index("def run_case")], ns)          # the circuit builder only (the module itself needs a GPU)
+    assert importlib.util.find_spec("oracle.prover_oracle") is not None
+    cv = bo.CURVES[cid]
+    log_n, tau = 7, 0x7A5C0DE
+    n = 1 << log_n
+    ca, cd = bo.seeded_scalars(cv, 0x51, 2)
+    key_map = {"q_fixed": "q_fixed_group_add", "q_var": "q_variable_group_add"}
+    srs = cpu.srs_powers(cid, tau, n + 8)
+    for broken in (False, True):
+        sel, sigma, table, wires, pub = ns["build_circuit"](cv, log_n, 31 + cid, broken, (ca, cd))
+        osel = {k: sel[key_map.get(k, k)] for k in po.KEYS}
+        t = wo.PlonkTranscript(b"cpu only", cv)
+        t.circuit_domain_sep(n)
+        data, ch, polys = po.prove(cv, log_n, osel, sigma, table, wires, pub, t, po.cpp_committer(cpu, cid, cv, srs), ca, cd)
+        dlog = {k: bo.horner(v, tau, cv.r) for k, v in polys.items()}
+        t2 = wo.PlonkTranscript(b"cpu only", cv)
+        t2.circuit_domain_sep(n)
+        ok, vch, det = vo.verify_with_trapdoor(cv, log_n, data, t2, pub, dlog, tau, ca, cd)
+        assert ok == (not broken), (broken, det["aw"], det["saw"])
+        assert vch["z"] == ch["z"] and vch["saw"] == ch["saw"]
+        if not broken:      # the commitments in the bytes are the polynomials at tau times G
+            pr = det["proof"]
+            for k in ("a_comm", "z_2_comm", "t_4_comm"):
+                assert pr["commitments"][k] == bo.ec_mul(cv, dlog[k], (cv.gx, cv.gy))
+            assert pr["aw_opening"] == bo.ec_mul(cv, dlog["aw_opening"], (cv.gx, cv.gy))

@@ -306,7 +306,7 @@ def test_proof_bytes_equal_the_cpu_restatement(cid, log_n, ctx, oracle_cpu):
     t = wo.PlonkTranscript(b"end to end", cv)
     t.circuit_domain_sep(n)
     osel = {k: sel[v] for k, v in KEY.items()}
-    data, och = po.prove(cv, log_n, osel, sigma, table, wires, pub, t, po.cpp_committer(oracle_cpu, cid, cv, srs), ca, cd)
+    data, och, _ = po.prove(cv, log_n, osel, sigma, table, wires, pub, t, po.cpp_committer(oracle_cpu, cid, cv, srs), ca, cd)
     mine = {k: fr_from_mont(cid, np.asarray(v).reshape(1, 4))[0] for k, v in proof.challenges.items()}
     for a, b in (("zeta", "zeta"), ("beta", "beta"), ("epsilon", "epsilon"), ("alpha", "alpha"), ("lookup", "lookup_challenge"),
                  ("z", "z_challenge"), ("aw", "aw_challenge"), ("saw", "saw_challenge")):

@@ -199,11 +199,83 @@ def check_identity(pk: ProverKey, proof: Proof, public_inputs: dict) -> bool:
     return (lin_z + r0) % p == 0
 
 
-def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99):
+def _gadget_runs(p: int, base: int, rng, ca: int, cd: int):
+    """Short runs of the reference's other gates on host integers, starting at row `base`: six range rows (widget/range.rs:47-63:
+    base-4 accumulator chains), six logic rows (widget/logic.rs:65-133: q_c = 1 AND, q_c = -1 XOR on base-4 digits), four
+    curve-addition rows (widget/ecc/curve_addition.rs:62-97) and five fixed-base steps (widget/ecc/fixed_base_scalar_mul.rs:88-156)
+    over a twisted Edwards curve with coefficients (ca, cd).  Every run ends in an ordinary arithmetic row that takes the run's
+    "next row" values in its a, b, d wires.  Returns (cells {(wire, row): value}, selectors {(name, row): value}, gadget rows, end)."""
+    inv = lambda x: pow(x % p, -1, p)  # noqa: E731
+    fe = lambda: int.from_bytes(rng.bytes(40), "little") % p  # noqa: E731
+    cells, sels, gadget = {}, {}, []
+    r = base
+
+    def put(row, a=None, b=None, c=None, d=None):
+        for w, v in enumerate((a, b, c, d)):
+            if v is not None:
+                cells[(w, row)] = v % p
+    acc = fe()
+    for _ in range(6):                                   # range: c - 4d, b - 4c, a - 4b, d_next - 4a are base-4 digits
+        q = [int(v) for v in rng.integers(0, 4, 4)]
+        d_ = acc
+        c_ = 4 * d_ + q[0]
+        b_ = 4 * c_ + q[1]
+        a_ = 4 * b_ + q[2]
+        acc = (4 * a_ + q[3]) % p
+        put(r, a_, b_, c_, d_)
+        sels[("q_range", r)] = 1
+        gadget.append(r)
+        r += 1
+    put(r, d=acc)
+    r += 1
+    xa, xb, xd = fe(), fe(), fe()
+    for k in range(6):                                   # logic: c holds the product of the two digits
+        qa, qb = (int(v) for v in rng.integers(0, 4, 2))
+        is_and = k % 2 == 0
+        put(r, xa, xb, qa * qb, xd)
+        xa, xb = (4 * xa + qa) % p, (4 * xb + qb) % p
+        xd = (4 * xd + ((qa & qb) if is_and else (qa ^ qb))) % p
+        sels[("q_logic", r)] = 1
+        sels[("q_c", r)] = 1 if is_and else p - 1
+        gadget.append(r)
+        r += 1
+    put(r, xa, xb, None, xd)
+    r += 1
+    for _ in range(4):                                   # curve addition; the next row holds the sum and x1 * y2
+        x1, y1, x2, y2 = fe(), fe(), fe(), fe()
+        put(r, x1, y1, x2, y2)
+        x1y2, y1x2 = x1 * y2 % p, y1 * x2 % p
+        x3 = (x1y2 + y1x2) * inv(1 + cd * x1y2 * y1x2) % p
+        y3 = (y1 * y2 - ca * x1 * x2) * inv(1 - cd * x1y2 * y1x2) % p
+        sels[("q_variable_group_add", r)] = 1
+        gadget.append(r)
+        r += 1
+        put(r, x3, y3, None, x1y2)
+        r += 1
+    ax, ay, ad = fe(), fe(), fe()
+    for bit in (1, 0, p - 1, 1, p - 1):                  # fixed-base step: bit = d_next - 2d in {-1, 0, 1}, c = bit * xy_beta
+        xb_, yb_, xyb = fe(), fe(), fe()
+        sels[("q_l", r)], sels[("q_r", r)], sels[("q_c", r)], sels[("q_fixed_group_add", r)] = xb_, yb_, xyb, 1
+        xy_alpha = bit * xyb % p
+        put(r, ax, ay, xy_alpha, ad)
+        x_alpha, y_alpha = xb_ * bit % p, (bit * bit * (yb_ - 1) + 1) % p
+        t = cd * xy_alpha % p * ax % p * ay % p
+        ax, ay = (x_alpha * ay + y_alpha * ax) * inv(1 + t) % p, (y_alpha * ay - ca * x_alpha * ax) * inv(1 - t) % p
+        ad = (2 * ad + bit) % p
+        gadget.append(r)
+        r += 1
+    put(r, ax, ay, None, ad)
+    r += 1
+    return cells, sels, gadget, r
+
+
+def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99, coeffs=(1, 1)):
     """A satisfied circuit of n = 2^log_n rows built ON the device: arithmetic gates with random selectors on about two thirds of
     the rows (q_o = -1, the output wire computed from the others), public inputs on rows 1 and 3, six copy constraints that tie
     cells of different wires and rows (2-cycles in sigma), lookup gates into a four-column table of n/4 distinct rows padded
-    with its first row on the remaining third, five all-zero padding rows, and all-zero range / logic / ECC selectors.
+    with its first row on the remaining third, five all-zero padding rows and -- from 128 rows up -- short runs of range, logic,
+    curve-addition and fixed-base gates (`_gadget_runs`; coeffs = the embedded curve's (COEFF_A, COEFF_D) as integers, to be
+    passed to `prove` in Montgomery form).  Below 128 rows those four selectors are zero.
     Returns (ProverKey, [w_l, w_r, w_o, w_4], public inputs {row: 4 Montgomery limbs})."""
     import torch
     from ._lib import check, lib
@@ -239,7 +311,9 @@ def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99):
     tsrc = [rnd(n) for _ in range(4)]
     rep = torch.where(row < rows, row, torch.zeros_like(row))
     table = [c[rep].contiguous() for c in tsrc]
-    is_lookup = (torch.randint(0, 3, (n,), device=dev, generator=g) == 0) & (row > 4) & (row < used)
+    g_base = used - 48
+    reserved = (row >= g_base) & (row < used) if n >= 128 else torch.zeros_like(row, dtype=torch.bool)
+    is_lookup = (torch.randint(0, 3, (n,), device=dev, generator=g) == 0) & (row > 4) & (row < used) & ~reserved
     live = (~is_lookup) & (row < used)
     pick = torch.randint(0, rows, (n,), device=dev, generator=g)
     lk, lv = is_lookup.unsqueeze(1), live.unsqueeze(1)
@@ -258,10 +332,26 @@ def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99):
         s1, s2 = sigma[w1][r1].clone(), sigma[w2][r2].clone()
         sigma[w1][r1], sigma[w2][r2] = s2, s1
     sel = {name: zero.clone() for name in SELECTORS}
+    c_fixed = {}
+    if n >= 128:                                     # the other gates: cells and selectors computed on host integers, written row by row
+        cells, gsel, gadget, end = _gadget_runs(p, g_base, np.random.default_rng(seed), int(coeffs[0]) % p, int(coeffs[1]) % p)
+        assert end <= used
+        wires_abd = {0: a, 1: b, 3: d}
+        for (w, r_), v in cells.items():
+            if w == 2:
+                c_fixed[r_] = v
+            else:
+                wires_abd[w][r_] = const(v)
+        grows = torch.tensor(gadget, device=dev)
+        live[grows] = False                          # gadget rows carry no arithmetic gate
+        lv = live.unsqueeze(1)
     for name in ("q_m", "q_l", "q_r", "q_4", "q_c"):
         sel[name] = torch.where(lv, rnd(n), zero).contiguous()
     sel["q_o"] = torch.where(lv, const(p - 1).expand(n, 4), zero).contiguous()
     sel["q_arith"] = torch.where(lv, const(1).expand(n, 4), zero).contiguous()
+    if n >= 128:
+        for (name, r_), v in gsel.items():
+            sel[name][r_] = const(v)
     sel["q_lookup"] = torch.where(lk, const(1).expand(n, 4), zero).contiguous()
     pub = {1: rnd(1)[0].cpu().numpy().view(np.uint64), 3: rnd(1)[0].cpu().numpy().view(np.uint64)}
     pi = zero.clone()
@@ -270,4 +360,6 @@ def example_circuit(log_n: int, curve="bls12_381", ctx=None, seed: int = 99):
     c_arith = linearisation.lincomb([mul(sel["q_m"], mul(a, b)), mul(sel["q_l"], a), mul(sel["q_r"], b), mul(sel["q_4"], d), sel["q_c"], pi],
                                     fr_to_mont(cv, [1] * 6), curve=cv, ctx=ctx)
     c = torch.where(lk, table[2][pick], c_arith).contiguous()
+    for r_, v in c_fixed.items():
+        c[r_] = const(v)
     return ProverKey(dom, dom4, sel, sigma, table), [a, b, c, d], pub

@@ -562,7 +562,7 @@ def main():
                             "(zk_poly_lincomb_dev; linearisation_poly.rs:164-350) -- instead of synthetic inputs / a stand-in polynomial"}
         leg("with_device_glue", glue_leg)
         def full_proof_leg():
-            # a REAL proof: a satisfied circuit (arithmetic gates, public inputs, copy constraints, lookups) built on the device, proved by
+            # a REAL proof: a satisfied circuit (arithmetic, range, logic, ECC and lookup gates, public inputs, copy constraints) built on the device, proved by
             # ark_plonk_amd/prover.py -- Prover::prove_with_preprocessed's five rounds with every O(n) step through the C ABI, challenges from
             # the library's merlin transcript -- and serialised; self-check: the verifier's identity lin(z) = -r_0 on the result
             from ark_plonk_amd import prover, transcript

@@ -256,14 +256,16 @@ def test_full_size_proof_verifies(ctx, oracle_cpu):
     cid, log_n = 0, 20
     n = 1 << log_n
     cv = bo.CURVES[cid]
-    pk, wires, pub_m = prover.example_circuit(log_n, cid, ctx)
+    ca, cd = bo.seeded_scalars(cv, 0x51, 2)
+    pk, wires, pub_m = prover.example_circuit(log_n, cid, ctx, coeffs=(ca, cd))
     pub = {i: fr_from_mont(cid, v.reshape(1, 4))[0] for i, v in pub_m.items()}
+    for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add", "q_lookup", "q_arith"):
+        assert torch.count_nonzero(pk.polys[name]).item() > 0, name          # every widget is in this circuit
     pw_canon, _ = tau_powers(oracle_cpu, cid, n)
     ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
     ck.precompute()
     pre = transcript.Transcript(b"end to end", cid)
     pre.circuit_domain_sep(n)
-    ca, cd = bo.seeded_scalars(cv, 0x51, 2)
     args = (pk, ck, wires, pub_m, pre, fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
     prover.prove(*args)                                           # warm-up (twiddle tables, buffers)
     torch.cuda.synchronize()

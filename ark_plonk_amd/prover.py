@@ -57,6 +57,16 @@ class ProverKey:
         other.domain_4n = Radix2EvaluationDomain.new(self.domain_4n.size(), self.domain.curve, ctx)
         return other
 
+    def verifier_key(self, ck) -> dict:
+        """The commitments of `preprocess.rs:351-374` + `lookup/preprocess.rs:63-64`: 12 selectors, 4 sigmas, 4 table columns
+        (name -> G1Affine; `transcript.seed_transcript` appends 15 of them).  Two batches of commitments over the prover's SRS."""
+        names = list(SELECTORS) + ["left_sigma", "right_sigma", "out_sigma", "fourth_sigma"]
+        polys = [self.polys[k] for k in SELECTORS] + list(self.sigma_polys)
+        out = dict(zip(names, ck.commit_batch(polys)))
+        tables = ck.commit_batch([self.domain.ifft(t) for t in self.table_cols])
+        out.update({f"table_{k + 1}": tables[k] for k in range(4)})
+        return out
+
     def linearisation_key(self) -> dict:
         k = dict(self.polys)
         k.update(left_sigma=self.sigma_polys[0], right_sigma=self.sigma_polys[1], out_sigma=self.sigma_polys[2], fourth_sigma=self.sigma_polys[3])

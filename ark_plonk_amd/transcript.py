@@ -146,6 +146,20 @@ class Transcript:
         check(lib().zk_transcript_circuit_domain_sep(self._h, int(n)), "zk_transcript_circuit_domain_sep")
 
 
+# `VerifierKey::seed_transcript` (proof_system/widget/mod.rs:252-278): the 15 commitments appended under these labels, in this order
+# (q_lookup and the four table commitments are part of the key but are NOT appended), then circuit_domain_sep(n).
+VK_SEED_LABELS = ("q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_logic", "q_variable_group_add", "q_fixed_group_add",
+                  "left_sigma", "right_sigma", "out_sigma", "fourth_sigma")
+
+
+def seed_transcript(t: "Transcript", vk: dict, n: int) -> "Transcript":
+    """vk: name -> G1Affine for every name in VK_SEED_LABELS.  Returns t (the `preprocessed_transcript` of prover.rs:179)."""
+    for lb in VK_SEED_LABELS:
+        t.append(lb, vk[lb])
+    t.circuit_domain_sep(n)
+    return t
+
+
 # The prover's feed order (proof_system/prover.rs line numbers).  Challenges are drawn under `draw` and appended back
 # under `put` -- the reference spells two of the put-labels "seperation" (prover.rs:403,407).
 ROUND1_COMMITS = ("w_l", "w_r", "w_o", "w_4")                                   # :217-220

@@ -570,8 +570,7 @@ def main():
             pk, wires, pub = prover.example_circuit(log_n, cv, ctx)
             ckp = zk.CommitterKey(build_srs(ctx, cv, n, 0, n, torch), cv, ctx)
             ckp.precompute(args.table_window)
-            pre = transcript.Transcript(b"bench", cv)
-            pre.circuit_domain_sep(n)
+            pre = transcript.seed_transcript(transcript.Transcript(b"bench", cv), pk.verifier_key(ckp), n)   # Circuit::compile's part of the transcript
             one = zk.curves.fr_to_mont(cv, [1])[0]
             a = (pk, ckp, wires, pub, pre, one, one)
             prover.prove(*a)

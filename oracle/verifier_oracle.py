@@ -52,6 +52,19 @@ def parse_proof(cv: bo.Curve, data: bytes) -> dict:
     return out
 
 
+VK_SEED = (("q_m", "q_m"), ("q_l", "q_l"), ("q_r", "q_r"), ("q_o", "q_o"), ("q_c", "q_c"), ("q_4", "q_4"), ("q_arith", "q_arith"),
+           ("q_range", "q_range"), ("q_logic", "q_logic"), ("q_variable_group_add", "q_var"), ("q_fixed_group_add", "q_fixed"),
+           ("left_sigma", "sigma0"), ("right_sigma", "sigma1"), ("out_sigma", "sigma2"), ("fourth_sigma", "sigma3"))
+
+
+def seed_transcript(cv: bo.Curve, t: wo.PlonkTranscript, vk_points: dict, n: int):
+    """`VerifierKey::seed_transcript` (widget/mod.rs:252-278).  vk_points: this module's key names -> affine point or None."""
+    for label, name in VK_SEED:
+        t.append_g1(label.encode(), vk_points[name])
+    t.circuit_domain_sep(n)
+    return t
+
+
 def replay_transcript(cv: bo.Curve, t: wo.PlonkTranscript, proof: dict, pub_inputs: dict) -> dict:
     """proof.rs:128-300, 343-378: the verifier's transcript traffic.  t: the transcript after the verifier key was seeded."""
     cm, ev = proof["commitments"], proof["evals"]

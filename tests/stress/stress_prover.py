@@ -55,15 +55,14 @@ def run(budget: float = 120.0, seed: int = 7, ctx=None, max_log_n: int = 11):
             cks[(cid, log_n)] = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
         ck = cks[(cid, log_n)]
         label = b"stress %d" % int(rng.integers(0, 1000))
-        pre = transcript.Transcript(label, cid)
-        pre.circuit_domain_sep(n)
+        vk = pk.verifier_key(ck)
+        pre = transcript.seed_transcript(transcript.Transcript(label, cid), vk, n)
         args = (pk, ck, [H.dev(cid, w) for w in wires], {i: fr_to_mont(cid, [v])[0] for i, v in pub.items()}, pre, fr_to_mont(cid, [ca])[0],
                 fr_to_mont(cid, [cd])[0])
         lean = bool(rng.integers(0, 2))
         proof = prover.prove(*args, lean=lean)
         data = proof.to_bytes()
-        t = wo.PlonkTranscript(label, cv)
-        t.circuit_domain_sep(n)
+        t = vo.seed_transcript(cv, wo.PlonkTranscript(label, cv), H.oracle_points(cid, vk), n)
         ok, _, det = vo.verify_with_trapdoor(cv, log_n, data, t, pub, H.dlogs(cid, ctx, pk, proof), TAU, ca, cd)
         assert ok == (not broken), (cid, log_n, broken, lean, det["aw"], det["saw"])
         assert prover.check_identity(pk, proof, args[3]) == (not broken)

@@ -171,11 +171,24 @@ def run_case(cid, log_n, ctx, oracle_cpu, break_cell=False):
     pk = prover.ProverKey(dom, dom4, {k: dev(cid, v) for k, v in sel.items()}, [dev(cid, s) for s in sigma], [dev(cid, t) for t in table])
     pw_canon, _ = tau_powers(oracle_cpu, cid, n + 8)
     ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
-    pre = transcript.Transcript(b"end to end", cid)
-    pre.circuit_domain_sep(n)
+    vk = pk.verifier_key(ck)                                                 # preprocess.rs:351-374: the 20 commitments of the key
+    pre = transcript.seed_transcript(transcript.Transcript(b"end to end", cid), vk, n)      # widget/mod.rs:252-278
     proof = prover.prove(pk, ck, [dev(cid, w) for w in wires], {i: fr_to_mont(cid, [v])[0] for i, v in pub.items()}, pre,
                          fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
+    proof.vk = vk
     return cv, pk, ck, proof, pub, (ca, cd), wires
+
+
+def oracle_points(cid, vk):
+    """The verifier key's commitments as the oracle's affine integer points, under the oracle's names."""
+    from ark_plonk_amd.curves import fq_from_mont
+    names = dict(KEY, sigma0="left_sigma", sigma1="right_sigma", sigma2="out_sigma", sigma3="fourth_sigma",
+                 table_1="table_1", table_2="table_2", table_3="table_3", table_4="table_4")
+    out = {}
+    for k, v in names.items():
+        pt = vk[v]
+        out[k] = None if pt.infinity else (fq_from_mont(cid, pt.x.reshape(1, -1))[0], fq_from_mont(cid, pt.y.reshape(1, -1))[0])
+    return out
 
 
 KEY = {"q_m": "q_m", "q_l": "q_l", "q_r": "q_r", "q_o": "q_o", "q_4": "q_4", "q_c": "q_c", "q_arith": "q_arith", "q_range": "q_range",
@@ -213,8 +226,10 @@ def test_device_prover_satisfies_the_reference_verifier(cid, log_n, ctx, oracle_
     assert_is_scalar_times_g(proof.aw_opening, dlog["aw_opening"], cid)
     assert_is_scalar_times_g(proof.saw_opening, dlog["saw_opening"], cid)
     # -- the verifier
-    t = wo.PlonkTranscript(b"end to end", cv)
-    t.circuit_domain_sep(n)
+    vk_pts = oracle_points(cid, proof.vk)
+    for k, pt in vk_pts.items():                       # the key's commitments are its polynomials at tau times G
+        assert pt == bo.ec_mul(cv, dlog[k], (cv.gx, cv.gy)), k
+    t = vo.seed_transcript(cv, wo.PlonkTranscript(b"end to end", cv), vk_pts, n)
     ok, vch, det = vo.verify_with_trapdoor(cv, log_n, data, t, pub, dlog, TAU, ca, cd)
     assert ok, det
     # the library's transcript and the independent one agree on every challenge
@@ -242,8 +257,7 @@ def test_wrong_witness_does_not_verify(ctx, oracle_cpu):
     cid, log_n = 0, 6
     cv, pk, ck, proof, pub, (ca, cd), wires = run_case(cid, log_n, ctx, oracle_cpu, break_cell=True)
     dlog = dlogs(cid, ctx, pk, proof)
-    t = wo.PlonkTranscript(b"end to end", cv)
-    t.circuit_domain_sep(1 << log_n)
+    t = vo.seed_transcript(cv, wo.PlonkTranscript(b"end to end", cv), oracle_points(cid, proof.vk), 1 << log_n)
     ok, _, det = vo.verify_with_trapdoor(cv, log_n, proof.to_bytes(), t, pub, dlog, TAU, ca, cd)
     assert not ok and not det["aw"]
 
@@ -264,8 +278,8 @@ def test_full_size_proof_verifies(ctx, oracle_cpu):
     pw_canon, _ = tau_powers(oracle_cpu, cid, n)
     ck = zk.CommitterKey(srs_from_powers(ctx, cid, pw_canon), cid, ctx)
     ck.precompute()
-    pre = transcript.Transcript(b"end to end", cid)
-    pre.circuit_domain_sep(n)
+    vk = pk.verifier_key(ck)
+    pre = transcript.seed_transcript(transcript.Transcript(b"end to end", cid), vk, n)
     args = (pk, ck, wires, pub_m, pre, fr_to_mont(cid, [ca])[0], fr_to_mont(cid, [cd])[0])
     prover.prove(*args)                                           # warm-up (twiddle tables, buffers)
     torch.cuda.synchronize()
@@ -279,8 +293,7 @@ def test_full_size_proof_verifies(ctx, oracle_cpu):
     for k in ("a_comm", "z_comm", "z_2_comm", "t_3_comm"):
         assert_is_scalar_times_g(proof.commitments[k], dlog[k], cid)
     assert_is_scalar_times_g(proof.aw_opening, dlog["aw_opening"], cid)
-    t = wo.PlonkTranscript(b"end to end", cv)
-    t.circuit_domain_sep(n)
+    t = vo.seed_transcript(cv, wo.PlonkTranscript(b"end to end", cv), oracle_points(cid, vk), n)
     ok, _, det = vo.verify_with_trapdoor(cv, log_n, data, t, pub, dlog, TAU, ca, cd)
     assert ok, (det["aw"], det["saw"])
     assert prover.check_identity(pk, proof, pub_m)              # the product-side self check agrees
@@ -305,8 +318,7 @@ def test_proof_bytes_equal_the_cpu_restatement(cid, log_n, ctx, oracle_cpu):
     assert wires2 == wires and pub2 == pub
     pw_canon, _ = tau_powers(oracle_cpu, cid, n + 8)
     srs = srs_from_powers(ctx, cid, pw_canon).cpu().numpy().view(np.uint64)
-    t = wo.PlonkTranscript(b"end to end", cv)
-    t.circuit_domain_sep(n)
+    t = vo.seed_transcript(cv, wo.PlonkTranscript(b"end to end", cv), oracle_points(cid, proof.vk), n)
     osel = {k: sel[v] for k, v in KEY.items()}
     data, och, _ = po.prove(cv, log_n, osel, sigma, table, wires, pub, t, po.cpp_committer(oracle_cpu, cid, cv, srs), ca, cd)
     mine = {k: fr_from_mont(cid, np.asarray(v).reshape(1, 4))[0] for k, v in proof.challenges.items()}

@@ -48,6 +48,7 @@ class ProverKey:
         self.sigma_polys = [domain.ifft(s) for s in sigma_evals]
         self.sigma4n = [domain_4n.coset_fft(p) for p in self.sigma_polys]
         self.table_cols = list(table_cols)
+        self.l1_4n = quotient.l1_coset_evals(domain, domain_4n, selector_evals["q_m"].device)     # depends on n only (the reference rebuilds it per proof, quotient_poly.rs:292-294)
 
     def with_ctx(self, ctx) -> "ProverKey":
         """The same device-resident key driven from another Context (its own stream / thread) of the same GPU."""
@@ -146,7 +147,7 @@ def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcrip
     q_ch = {name: ch[name] for name in quotient.CHALLENGES}
     t_poly = quotient.compute(d, d4, {"w_l": w_polys[0], "w_r": w_polys[1], "w_o": w_polys[2], "w_4": w_polys[3], "z": z_poly, "z2": z2_poly,
                                       "f": f_poly, "table": table_poly, "h1": h1_poly, "h2": h2_poly, "pi": pi_poly},
-                              pk.evals4n, pk.sigma4n, q_ch)                                               # :428-453
+                              pk.evals4n, pk.sigma4n, q_ch, l1_4n=pk.l1_4n)                               # :428-453
     t_parts = [t_poly[k * n:(k + 1) * n] for k in range(4)]                                               # :455-456 split_tx_poly
     t_commits = ck.commit_batch(t_parts)                                                                  # :459-469
     ch["z_challenge"] = tr.round4(t_commits)["z"]                                                         # :472-481

@@ -57,16 +57,24 @@ def compute_quotient_evals(domain: Radix2EvaluationDomain, columns: dict, sigmas
     return out
 
 
-def compute(domain: Radix2EvaluationDomain, domain_4n: Radix2EvaluationDomain, polys: dict, key_evals: dict, sigmas, challenges: dict):
-    """quotient_poly.rs:34-178: polys = coefficient vectors of w_l, w_r, w_o, w_4, z, z2, f, table, h1, h2, pi
-    (l1 is built here as the reference does, quotient_poly.rs:68-69,313-326); key_evals = the prover key's 4n coset
-    evaluations.  Returns the 4n coefficients of the quotient polynomial."""
+def l1_coset_evals(domain: Radix2EvaluationDomain, domain_4n: Radix2EvaluationDomain, device):
+    """coset_fft of the first Lagrange polynomial over the 4n domain (quotient_poly.rs:68-69,313-326): depends on n only, so a
+    prover key may hold it."""
     import torch
-    n = domain.size()
     from .curves import fr_to_mont
-    l1_evals = torch.zeros((n, 4), dtype=torch.int64, device=polys["w_l"].device)
-    l1_evals[0] = torch.from_numpy(fr_to_mont(domain.curve, [1])[0].view(np.int64)).to(l1_evals.device)
-    cols = {name: domain_4n.coset_fft(polys[name]) for name in ("w_l", "w_r", "w_o", "w_4", "z", "z2", "f", "table", "h1", "h2", "pi")}
-    cols["l1"] = domain_4n.coset_fft(domain.ifft(l1_evals))
+    l1_evals = torch.zeros((domain.size(), 4), dtype=torch.int64, device=device)
+    l1_evals[0] = torch.from_numpy(fr_to_mont(domain.curve, [1])[0].view(np.int64)).to(device)
+    return domain_4n.coset_fft(domain.ifft(l1_evals))
+
+
+def compute(domain: Radix2EvaluationDomain, domain_4n: Radix2EvaluationDomain, polys: dict, key_evals: dict, sigmas, challenges: dict,
+            l1_4n=None):
+    """quotient_poly.rs:34-178: polys = coefficient vectors of w_l, w_r, w_o, w_4, z, z2, f, table, h1, h2, pi
+    (l1 is built here as the reference does, quotient_poly.rs:68-69,313-326, unless the caller holds it: l1_4n); key_evals = the
+    prover key's 4n coset evaluations.  The eleven coset FFTs go out as one batch (one launch per pass).
+    Returns the 4n coefficients of the quotient polynomial."""
+    names = ("w_l", "w_r", "w_o", "w_4", "z", "z2", "f", "table", "h1", "h2", "pi")
+    cols = dict(zip(names, domain_4n.batch(2, [polys[name] for name in names])))
+    cols["l1"] = l1_4n if l1_4n is not None else l1_coset_evals(domain, domain_4n, polys["w_l"].device)
     cols.update(key_evals)
     return domain_4n.coset_ifft(compute_quotient_evals(domain, cols, sigmas, challenges))

@@ -19,6 +19,8 @@ ZK_ERR_NO_DEVICE = -5
 ZK_ERR_UNSUPPORTED = -6
 ZK_ERR_NOT_INVERTIBLE = -7
 ZK_ERR_NOT_INDEXED = -8
+ZK_ERR_PENDING = -9
+ZK_TABLE_EVERY_BIT = 0x100     # zk_srs_precompute_ex: | 17 = a table row for every bit position, width-17 NAF digits
 
 c_void_p = ctypes.c_void_p
 c_size_t = ctypes.c_size_t
@@ -91,6 +93,7 @@ SYMBOLS = {
     "zk_srs_precompute": (c_int, [c_void_p, c_void_p]),
     "zk_srs_precompute_ex": (c_int, [c_void_p, c_void_p, c_u32]),
     "zk_srs_table_info": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
+    "zk_srs_retain": (c_int, [c_void_p]),
     "zk_srs_free": (None, [c_void_p]),
     "zk_srs_len": (c_size_t, [c_void_p]),
     "zk_msm_g1_srs": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -107,6 +110,12 @@ SYMBOLS = {
     "zk_kzg_commit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_kzg_round_begin_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
+    "zk_kzg_open_begin_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_kzg_round_end": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
+    "zk_kzg_round_end_partial": (c_int, [c_void_p, c_u32, c_void_p]),
+    "zk_kzg_round_pending": (c_int, [c_void_p, ctypes.POINTER(c_u32)]),
+    "zk_kzg_round_abort": (c_int, [c_void_p]),
     "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
     "zk_kzg_round_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),

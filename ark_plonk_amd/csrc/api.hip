@@ -112,6 +112,9 @@ static int domain_new(uint64_t num_coeffs, zk_domain_info* out) {
     return ZK_OK;
 }
 
+// a deferred round (zk_kzg_round_begin_dev ...) holds the ctx's MSM buffer sets until zk_kzg_round_end
+inline bool round_open(const zk_ctx* c) { return c->pend_n != 0; }
+
 int ensure_pinned_small(zk_ctx* c) {
     if (c->pinned_small) return ZK_OK;
     if (hipHostMalloc(&c->pinned_small, 4096, hipHostMallocDefault) != hipSuccess) return ZK_ERR_OOM;
@@ -133,6 +136,7 @@ const char* zk_strerror(int code) {
     case ZK_ERR_UNSUPPORTED: return "size not supported";
     case ZK_ERR_NOT_INVERTIBLE: return "zero denominator in a grand product";
     case ZK_ERR_NOT_INDEXED: return "lookup query value not in the table";
+    case ZK_ERR_PENDING: return "a deferred commitment round is open on this ctx (zk_kzg_round_end closes it)";
     default: return "unknown error";
     }
 }
@@ -158,6 +162,8 @@ int zk_ctx_create(int device, zk_ctx** out) {
     }
     c->stream = c->own_stream;
     c->pool.reset(new HostPool(7));
+    zk_process_key(c->digest_key);
+    c->digest_key[0] ^= (uint64_t)(uintptr_t)c * 0x9E3779B97F4A7C15ull;      // caches are per ctx: so are their keys
     for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
@@ -215,6 +221,7 @@ int zk_ctx_sync(zk_ctx* c) {
 int zk_ctx_set_msm_window(zk_ctx* c, int w) {
     if (!c || w < 0 || w > 16 || w == 1) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     c->msm_window = w;
     return ZK_OK;
 }
@@ -343,7 +350,7 @@ static size_t g_srs_idle_limit = (size_t)32 << 30;   // bytes of UNREFERENCED ca
 static uint64_t g_srs_hits = 0, g_srs_misses = 0;
 
 typedef std::shared_lock<std::shared_mutex> SrsReadLock;
-static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_W ? s->pre_W : 1); }
+static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_naf ? s->pre_rows : s->pre_W ? s->pre_W : 1); }
 
 static void srs_destroy(zk_srs* s) {
     if (s->d_xy) {
@@ -467,11 +474,18 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
 
 int zk_srs_precompute_ex(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     if (!c || !s || s->device != c->device) return ZK_ERR_BAD_ARG;
-    if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) return ZK_ERR_BAD_ARG;
+    if (window_bits & ZK_TABLE_EVERY_BIT) {
+        if (window_bits != (ZK_TABLE_EVERY_BIT | 17u)) return ZK_ERR_BAD_ARG;
+    } else if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) {
+        return ZK_ERR_BAD_ARG;
+    }
     Guard g(c);
     std::unique_lock<std::shared_mutex> wl(s->mu);   // no MSM of any ctx is reading or enqueueing on this SRS
     if (s->n == 0) return ZK_OK;
-    if (s->pre_W) return (window_bits == 0 || window_bits == s->pre_c) ? ZK_OK : ZK_ERR_UNSUPPORTED;   // one table per SRS
+    if (s->pre_W) {                                    // one table per SRS: the first precompute wins
+        const uint32_t have = s->pre_c | (s->pre_naf ? (uint32_t)ZK_TABLE_EVERY_BIT : 0u);
+        return (window_bits == 0 || window_bits == have) ? ZK_OK : ZK_ERR_UNSUPPORTED;
+    }
     ZK_HIP_TRY(hipDeviceSynchronize());               // ... and none it enqueued earlier is still running
     return msm_precompute_dev(c, s, window_bits);
 }
@@ -481,8 +495,16 @@ int zk_srs_precompute(zk_ctx* c, zk_srs* s) { return zk_srs_precompute_ex(c, s, 
 int zk_srs_table_info(zk_srs* s, uint32_t* window_bits, uint32_t* windows) {
     if (!s) return ZK_ERR_BAD_ARG;
     SrsReadLock rl(s->mu);
-    if (window_bits) *window_bits = s->pre_c;
+    if (window_bits) *window_bits = s->pre_c | (s->pre_naf ? (uint32_t)ZK_TABLE_EVERY_BIT : 0u);
     if (windows) *windows = s->pre_W;
+    return ZK_OK;
+}
+
+int zk_srs_retain(zk_srs* s) {
+    if (!s) return ZK_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> reg(g_srs_mu);
+    if (s->refs.load() <= 0) return ZK_ERR_BAD_ARG;     // only a live handle can be shared
+    s->refs.fetch_add(1);
     return ZK_OK;
 }
 
@@ -541,6 +563,7 @@ static int msm_partial_locked(zk_ctx* c, zk_srs* s, size_t base_offset, const vo
 int zk_msm_g1_srs_partial_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     if (!c || !s || s->device != c->device || !out_xyz || (n && !d_scalars)) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     return msm_partial_locked(c, s, base_offset, d_scalars, n, out_xyz);
 }
@@ -556,6 +579,7 @@ int zk_msm_g1_srs_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_sc
 int zk_msm_g1_srs(zk_ctx* c, zk_srs* s, size_t base_offset, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!c || !s || s->device != c->device || !out_xy || (n && !scalars)) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     {
         int rc = c->mb[0].scalars.ensure((n ? n : 1) * 32);
         if (rc) return rc;
@@ -651,7 +675,7 @@ static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
     int rc;
     if ((rc = c->digest_dev.ensure(16 * 32))) return rc;
     if ((rc = ensure_pinned_small(c))) return rc;
-    if ((rc = dev_digest256(d_inputs, lens, n_jobs, (uint64_t*)c->digest_dev.p, c->stream))) return rc;
+    if ((rc = dev_digest256(d_inputs, lens, n_jobs, (uint64_t*)c->digest_dev.p, c->stream, c->digest_key))) return rc;
     ZK_HIP_TRY(hipMemcpyAsync(c->pinned_small, c->digest_dev.p, (size_t)n_jobs * 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t* dig = (const uint64_t*)c->pinned_small;
@@ -723,6 +747,7 @@ static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
 int zk_ctx_set_commit_cache(zk_ctx* c, int enable, uint32_t capacity) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     c->commit_cache_on = enable != 0;
     if (capacity) c->commit_cache_cap = capacity;
     if (!enable) c->commit_cache.clear();
@@ -742,6 +767,7 @@ int zk_commit_cache_stats(zk_ctx* c, uint64_t* hits, uint64_t* misses, uint64_t*
 int zk_kzg_commit_dev(zk_ctx* c, zk_srs* s, const void* d_coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!c || !s || s->device != c->device || !out_xy || (n && !d_coeffs_mont)) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     if (n > s->n) return ZK_ERR_BAD_ARG;
     if (c->commit_cache_on && n) return batch_cached_locked(c, s, 1, &d_coeffs_mont, &n, nullptr, out_xy, out_inf);
@@ -761,6 +787,7 @@ int zk_kzg_round_batch_partial_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const 
     if (!c || !s || s->device != c->device || (n_jobs && (!d_inputs || !lens || !out_xyz))) return ZK_ERR_BAD_ARG;
     if (n_jobs > 16) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     return batch_locked(c, s, n_jobs, d_inputs, lens, kinds, out_xyz, nullptr, nullptr, nullptr);
 }
@@ -775,8 +802,164 @@ int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* c
     if (!c || !s || s->device != c->device || (n_polys && (!d_coeffs_mont || !lens || !out_xy))) return ZK_ERR_BAD_ARG;
     if (n_polys > 16) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     return batch_cached_locked(c, s, n_polys, d_coeffs_mont, lens, kinds, out_xy, out_inf);
+}
+
+// ---------------------------------------------------------------------- deferred rounds (begin ... end)
+// ctx lock held.  Entry points that would reuse the buffer sets of queued jobs refuse while a round is open (ZK_ERR_PENDING).
+
+static void round_clear(zk_ctx* c) {
+    c->pend_n = 0;
+    c->pend_srs = nullptr;
+}
+
+// jobs [0, n_jobs) appended to the open round; inputs on the device
+static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds) {
+    if (c->pend_n && c->pend_srs != s) return ZK_ERR_BAD_ARG;
+    if (c->pend_n + n_jobs > 16) return ZK_ERR_UNSUPPORTED;
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
+    const uint32_t slot0 = c->pend_n;
+    int rc;
+    if (c->commit_cache_on) {
+        // the cache answers (or computes) at once; no job of such a round is ever queued, so the buffer sets are free
+        uint64_t xy[16 * 12];
+        uint8_t inf[16];
+        const int L = fq_limbs64(s->curve);
+        if ((rc = batch_cached_locked(c, s, n_jobs, d_inputs, lens, kinds, xy, inf))) return rc;
+        for (uint32_t k = 0; k < n_jobs; ++k) {
+            zk_ctx::PendingJob& pj = c->pend[slot0 + k];
+            pj = zk_ctx::PendingJob();
+            pj.n = lens[k];
+            memcpy(pj.xy, xy + (size_t)k * 2 * L, sizeof(uint64_t) * 2 * L);
+            pj.inf = inf[k];
+        }
+        c->pend_n += n_jobs;
+        c->pend_srs = s;
+        return ZK_OK;
+    }
+    const bool table = s->pre_W != 0 && c->msm_window == 0;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        const uint32_t slot = slot0 + k;
+        zk_ctx::PendingJob& pj = c->pend[slot];
+        pj = zk_ctx::PendingJob();
+        pj.n = lens[k];
+        if (table && lens[k] >= ZK_PRE_MIN_N) {
+            const uint8_t kind = kinds ? kinds[k] : 0;
+            if ((rc = msm_batch_pre_begin_dev(c, s, slot, 1, d_inputs + k, lens + k, &kind, nullptr))) return rc;
+            pj.queued = true;
+        } else {
+            // short vector / no table: computed now, in this job's own buffer set (set 0 may belong to a queued job)
+            if (slot) std::swap(c->mb[0], c->mb[slot]);
+            rc = commit_one_locked(c, s, d_inputs[k], lens[k], kinds && kinds[k], pj.xyz);
+            if (slot) std::swap(c->mb[0], c->mb[slot]);
+            if (rc) return rc;
+            pj.have_xyz = true;
+        }
+        c->pend_n = slot + 1;      // a failure further on leaves the jobs queued so far open: zk_kzg_round_end / _abort settles them
+        c->pend_srs = s;
+    }
+    return ZK_OK;
+}
+
+int zk_kzg_round_begin_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds) {
+    if (!c || !s || s->device != c->device || (n_jobs && (!d_inputs || !lens))) return ZK_ERR_BAD_ARG;
+    if (n_jobs > 16) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    return round_append_locked(c, s, n_jobs, d_inputs, lens, kinds);
+}
+
+int zk_kzg_open_begin_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
+                          const uint64_t* challenge_mont) {
+    if (!c || !s || s->device != c->device || !z_mont || !challenge_mont || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    if (c->pend_n >= 16) return ZK_ERR_UNSUPPORTED;
+    void* d_w = nullptr;
+    size_t wlen = 0;
+    int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen, c->pend_n);
+    if (rc) return rc;
+    if (wlen > s->n) return ZK_ERR_BAD_ARG;
+    const void* in = d_w;
+    const uint8_t kind = 1;
+    return round_append_locked(c, s, 1, &in, &wlen, &kind);
+}
+
+// closes the round: one reduction launch per kernel for every queued job, one wait, results in submission order
+static int round_end_locked(zk_ctx* c, uint32_t n_expected, uint64_t* out_xyz, uint64_t* out_xy, uint8_t* out_inf) {
+    const uint32_t n = c->pend_n;
+    zk_srs* s = c->pend_srs;
+    if (n != n_expected) return ZK_ERR_BAD_ARG;          // the round stays open
+    if (n == 0) return ZK_OK;
+    const int L = fq_limbs64(s->curve);
+    uint32_t slots[16], nq = 0;
+    size_t qlens[16];
+    for (uint32_t k = 0; k < n; ++k)
+        if (c->pend[k].queued) {
+            slots[nq] = k;
+            qlens[nq] = c->pend[k].n;
+            ++nq;
+        }
+    uint64_t q_xyz[16 * 18], q_xy[16 * 12];
+    uint8_t q_inf[16];
+    int rc = ZK_OK;
+    if (nq) {
+        SrsRead rl(s->mu);
+        rc = msm_batch_pre_end_dev(c, s, nq, slots, qlens, q_xyz, out_xy ? q_xy : nullptr, q_inf);
+    }
+    uint32_t q = 0;
+    for (uint32_t k = 0; k < n && !rc; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (pj.queued) {
+            if (out_xyz) memcpy(out_xyz + (size_t)k * 3 * L, q_xyz + (size_t)q * 3 * L, sizeof(uint64_t) * 3 * L);
+            if (out_xy) {
+                memcpy(out_xy + (size_t)k * 2 * L, q_xy + (size_t)q * 2 * L, sizeof(uint64_t) * 2 * L);
+                if (out_inf) out_inf[k] = q_inf[q];
+            }
+            ++q;
+        } else if (pj.have_xyz) {
+            if (out_xyz) memcpy(out_xyz + (size_t)k * 3 * L, pj.xyz, sizeof(uint64_t) * 3 * L);
+            if (out_xy) rc = finish_point(s->curve, pj.xyz, out_xy + (size_t)k * 2 * L, out_inf ? out_inf + k : nullptr);
+        } else {
+            if (out_xyz) rc = ZK_ERR_UNSUPPORTED;         // the commitment cache holds affine points only
+            if (out_xy) {
+                memcpy(out_xy + (size_t)k * 2 * L, pj.xy, sizeof(uint64_t) * 2 * L);
+                if (out_inf) out_inf[k] = pj.inf;
+            }
+        }
+    }
+    round_clear(c);
+    return rc;
+}
+
+int zk_kzg_round_end(zk_ctx* c, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!c || (n_jobs && !out_xy)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return round_end_locked(c, n_jobs, nullptr, out_xy, out_inf);
+}
+
+int zk_kzg_round_end_partial(zk_ctx* c, uint32_t n_jobs, uint64_t* out_xyz) {
+    if (!c || (n_jobs && !out_xyz)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    return round_end_locked(c, n_jobs, out_xyz, nullptr, nullptr);
+}
+
+int zk_kzg_round_pending(zk_ctx* c, uint32_t* n_jobs) {
+    if (!c || !n_jobs) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    *n_jobs = c->pend_n;
+    return ZK_OK;
+}
+
+int zk_kzg_round_abort(zk_ctx* c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (c->pend_n) (void)hipStreamSynchronize(c->stream);     // the queued kernels still read the caller's inputs
+    round_clear(c);
+    return ZK_OK;
 }
 
 static int ensure_copy_stream(zk_ctx* c) {
@@ -795,6 +978,7 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
     for (uint32_t k = 0; k < n_polys; ++k)
         if (lens[k] && !coeffs_mont[k]) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     int rc = ensure_copy_stream(c);
     if (rc) return rc;
@@ -829,6 +1013,7 @@ int zk_kzg_open_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d
     void* d_w = nullptr;
     size_t wlen = 0;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     SrsRead rl(s->mu);
     {
         int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
@@ -847,6 +1032,7 @@ int zk_kzg_open(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* p
     if (!c || !s || s->device != c->device || !out_xy || !z_mont || !challenge_mont || (n_polys && (!polys_mont || !lens))) return ZK_ERR_BAD_ARG;
     if (n_polys > 16) return ZK_ERR_BAD_ARG;
     Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
     const void* d_in[16];
     for (uint32_t k = 0; k < n_polys; ++k) {
         if (lens[k] && !polys_mont[k]) return ZK_ERR_BAD_ARG;

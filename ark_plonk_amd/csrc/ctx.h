@@ -250,6 +250,21 @@ struct zk_ctx {
     std::list<CommitEntry> commit_cache;      // most recently used first
     uint64_t cache_hits = 0, cache_misses = 0;
     DevBuf digest_dev;                        // 16 jobs x 4 u64
+    uint64_t digest_key[4] = {0, 0, 0, 0};    // zk_process_key mixed with the ctx's address: keys the device digests of this cache
+
+    // open round (zk_kzg_round_begin_dev / zk_kzg_open_begin_dev ... zk_kzg_round_end): jobs whose sort + accumulate are queued
+    // on the stream and whose reduction waits for the round to close, in submission order.  Job k lives in buffer set mb[k].
+    struct PendingJob {
+        size_t n = 0;
+        bool queued = false;        // false: computed at begin (no table / short vector / commitment cache) -- result below
+        bool have_xyz = false;
+        uint64_t xyz[18] = {};
+        uint64_t xy[12] = {};
+        uint8_t inf = 0;
+    };
+    uint32_t pend_n = 0;
+    zk_srs* pend_srs = nullptr;
+    PendingJob pend[16];
 };
 
 // An SRS belongs to a DEVICE, not to a ctx: every zk_ctx of that device may use it (several proof streams share one
@@ -272,6 +287,12 @@ struct zk_srs {
     // with it all windows of an MSM share ONE bucket set (no per-window reduction, no host doublings)
     void* d_pre = nullptr;
     uint32_t pre_c = 0, pre_W = 0;
+    // "every bit position" form of the table (zk_srs_precompute_ex with ZK_TABLE_EVERY_BIT): row p holds 2^p * P_i for EVERY bit
+    // position p = 0 .. pre_rows-1 (scalar bits + 1 rows), so a scalar can be recoded in width-pre_c non-adjacent form -- odd digits
+    // at arbitrary positions, at least pre_c apart: ~14.7 instead of 16 mixed additions per 255-bit scalar at pre_c = 17, into 2^(pre_c-2)
+    // shared buckets.  pre_W is then the number of digit slots per scalar (16).
+    bool pre_naf = false;
+    uint32_t pre_rows = 0;
 };
 
 // profiling helpers (ctx mutex held by caller)
@@ -308,6 +329,12 @@ int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scal
 int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
                       const uint8_t* kinds = nullptr, uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr,
                       const std::function<int(uint32_t)>* before_job = nullptr);
+// the two halves of msm_batch_pre_dev: queue sort + accumulate of n_polys jobs into the buffer sets c->mb[slot0 ..] / reduce the
+// jobs in slots[0 .. n_jobs) with one launch per reduction kernel, wait once, combine on the host
+int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
+                            const uint8_t* kinds = nullptr, const std::function<int(uint32_t)>* before_job = nullptr);
+int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
+                          uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
@@ -329,8 +356,9 @@ int poly_evaluate_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const*
                       uint64_t* out_mont);
 int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,
                      void* d_out, size_t out_len);
+// the witness lands in c->mb[slot].scalars (slot: the buffer set of the MSM that will consume it)
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
-                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);
+                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen, uint32_t slot = 0);
 
 // hostio.hip: staged host<->device copies and digests
 // Copies run on `st`; h2d returns once the host buffer has been read (the device copy may still be in flight on st),
@@ -341,4 +369,7 @@ void zk_io_release(zk_ctx* c);
 // 256-bit digest of a host buffer (4 lanes; block-parallel on the ctx-less pool)
 void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]);
 // 256-bit multiset digests of n_jobs device vectors of 32-byte elements -> d_out[job][4] (async on st)
-int dev_digest256(const void* const* d_ptrs, const size_t* lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st);
+// keyed with `key` (the ctx's digest_key): see hostio.hip
+int dev_digest256(const void* const* d_ptrs, const size_t* lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st, const uint64_t key[4]);
+// 256 random bits per process (operating-system entropy), the key of every cache digest
+void zk_process_key(uint64_t out[4]);

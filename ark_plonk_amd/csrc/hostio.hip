@@ -11,6 +11,10 @@
 // Pinned or hipHostRegister-ed caller buffers are detected and always sent directly.
 #include "ctx.h"
 
+#include <chrono>
+#include <cstdio>
+#include <mutex>
+
 namespace {
 
 bool is_pinned(const void* p) {
@@ -74,9 +78,10 @@ ZK_HD uint64_t fmix64(uint64_t x) {
 }
 
 // one block: four xxhash-style lanes over 32-byte stripes, cross-mixed at the end so that every output word depends
-// on every input byte
-void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, uint64_t out[4]) {
-    uint64_t a[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+// on every input byte.  The lanes start from the 256-bit process key (zk_process_key): the digests address caches, and a
+// fixed, public mixing function would let a client who picks the cached bytes search for two inputs with one digest offline.
+void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, const uint64_t key[4], uint64_t out[4]) {
+    uint64_t a[4] = {key[0] ^ (seed + P1 + P2), key[1] ^ (seed + P2), key[2] ^ seed, key[3] ^ (seed - P1)};
     size_t i = 0;
     for (; i + 32 <= bytes; i += 32) {
         uint64_t w[4];
@@ -99,6 +104,7 @@ void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, uint64_t out[4]
 struct DigJobs {
     const void* p[16];
     uint64_t n[16];
+    uint64_t key[4];      // the ctx's secret: the per-element mixes are keyed, so equal sums cannot be searched for without it
 };
 __global__ void __launch_bounds__(256) digest_kernel(DigJobs jobs, uint64_t* out) {
     const uint32_t job = blockIdx.y;
@@ -110,10 +116,10 @@ __global__ void __launch_bounds__(256) digest_kernel(DigJobs jobs, uint64_t* out
         const uint64_t w[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint64_t h = fmix64(i * 0x9E3779B97F4A7C15ull + 0xD6E8FEB86659FD93ull * (uint64_t)(k + 1));
+            uint64_t h = fmix64((i * 0x9E3779B97F4A7C15ull + 0xD6E8FEB86659FD93ull * (uint64_t)(k + 1)) ^ jobs.key[k]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) h = fmix64(h ^ (w[(j + k) & 3] + 0x9E3779B185EBCA87ull * (uint64_t)(j + 1)));
-            acc[k] += h;
+            acc[k] += fmix64(h + jobs.key[(k + 1) & 3]);
         }
     }
 #pragma unroll
@@ -127,26 +133,48 @@ __global__ void __launch_bounds__(256) digest_kernel(DigJobs jobs, uint64_t* out
 
 }  // namespace
 
+// 256 bits drawn once per process from the operating system (getrandom / /dev/urandom).  Digests are only ever compared inside
+// the process that computed them, so the key never leaves it.
+void zk_process_key(uint64_t out[4]) {
+    static uint64_t key[4];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        bool ok = false;
+        if (FILE* f = fopen("/dev/urandom", "rb")) {
+            ok = fread(key, 1, sizeof key, f) == sizeof key;
+            fclose(f);
+        }
+        if (!ok) {      // no entropy source: address-space layout + clock (still unknown to a remote client, but weaker)
+            uint64_t x = (uint64_t)(uintptr_t)&key ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+            for (int k = 0; k < 4; ++k) key[k] = x = fmix64(x + P1 * (uint64_t)(k + 1));
+        }
+    });
+    memcpy(out, key, sizeof key);
+}
+
 void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]) {
     constexpr size_t BLOCK = (size_t)1 << 20;
     const uint32_t nblk = (uint32_t)((bytes + BLOCK - 1) / BLOCK);
+    uint64_t key[4];
+    zk_process_key(key);
     if (nblk <= 1) {
-        block_digest((const uint8_t*)p, bytes, seed, out);
+        block_digest((const uint8_t*)p, bytes, seed, key, out);
         return;
     }
     std::vector<uint64_t> parts((size_t)nblk * 4);
     host_parallel_for(nblk, [&](uint32_t k) {
         const size_t off = (size_t)k * BLOCK;
         const size_t len = bytes - off < BLOCK ? bytes - off : BLOCK;
-        block_digest((const uint8_t*)p + off, len, seed ^ (P4 * (uint64_t)(k + 1)), &parts[(size_t)k * 4]);
+        block_digest((const uint8_t*)p + off, len, seed ^ (P4 * (uint64_t)(k + 1)), key, &parts[(size_t)k * 4]);
     });
-    block_digest((const uint8_t*)parts.data(), parts.size() * 8, seed ^ (uint64_t)bytes, out);
+    block_digest((const uint8_t*)parts.data(), parts.size() * 8, seed ^ (uint64_t)bytes, key, out);
 }
 
-int dev_digest256(const void* const* d_ptrs, const size_t* d_lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st) {
+int dev_digest256(const void* const* d_ptrs, const size_t* d_lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st, const uint64_t key[4]) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > 16) return ZK_ERR_BAD_ARG;
     DigJobs jobs;
+    memcpy(jobs.key, key, sizeof jobs.key);
     for (uint32_t k = 0; k < 16; ++k) {
         jobs.p[k] = k < n_jobs ? d_ptrs[k] : nullptr;
         jobs.n[k] = k < n_jobs ? d_lens[k] : 0;

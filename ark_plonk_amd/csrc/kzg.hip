@@ -253,10 +253,10 @@ int poly_lincomb(zk_ctx* c, uint32_t n_terms, const void* const* d_polys, const 
 
 template <class C>
 int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
-                 const uint64_t* chal_mont, void** d_w, size_t* wlen) {
+                 const uint64_t* chal_mont, void** d_w, size_t* wlen, uint32_t slot) {
     typedef typename C::Fr Fr;
     typedef typename C::FrU FU;
-    if (n_polys > (uint32_t)MAX_POLYS) return ZK_ERR_UNSUPPORTED;
+    if (n_polys > (uint32_t)MAX_POLYS || slot >= 16) return ZK_ERR_UNSUPPORTED;
     uint64_t m = 0;
     for (uint32_t k = 0; k < n_polys; ++k) m = lens[k] > m ? lens[k] : m;
     *wlen = m > 0 ? m - 1 : 0;
@@ -288,7 +288,7 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     int rc;
     if ((rc = c->io_a.ensure(m * 32))) return rc;                       // comb
     if ((rc = c->io_b.ensure(n_chunks * 48 * 2))) return rc;            // H | A  (limb vectors)
-    if ((rc = c->mb[0].scalars.ensure(m * 32))) return rc;                // witness, canonical
+    if ((rc = c->mb[slot].scalars.ensure(m * 32))) return rc;             // witness, canonical
     void* comb = c->io_a.p;
     void* H = c->io_b.p;
     void* A = (char*)c->io_b.p + n_chunks * 48;
@@ -301,9 +301,9 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     size_t shmem = (size_t)SCAN_T * 2 * 48;
     ZK_HIP_TRY(hipFuncSetAttribute((const void*)kzg_chunk_scan<FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kzg_chunk_scan<FU>, dim3(1), dim3(SCAN_T), shmem, st, H, n_chunks, zkp, A);
-    hipLaunchKernelGGL(kzg_witness<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, A, c->mb[0].scalars.p, n_chunks);
+    hipLaunchKernelGGL(kzg_witness<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, A, c->mb[slot].scalars.p, n_chunks);
     ZK_HIP_TRY(hipGetLastError());
-    *d_w = c->mb[0].scalars.p;
+    *d_w = c->mb[slot].scalars.p;
     return ZK_OK;
 }
 
@@ -324,8 +324,8 @@ int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* 
 }
 
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
-                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen) {
-    if (curve == ZK_CURVE_BLS12_381) return open_prepare<CurveBls>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen);
-    if (curve == ZK_CURVE_BN254) return open_prepare<CurveBn>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen);
+                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen, uint32_t slot) {
+    if (curve == ZK_CURVE_BLS12_381) return open_prepare<CurveBls>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen, slot);
+    if (curve == ZK_CURVE_BN254) return open_prepare<CurveBn>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen, slot);
     return ZK_ERR_BAD_ARG;
 }

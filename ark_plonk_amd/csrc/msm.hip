@@ -625,6 +625,77 @@ __global__ void __launch_bounds__(256) psortw_digits_hist(const uint32_t* scalar
     hist[(uint64_t)threadIdx.x * PS_SLABS + blockIdx.x] = lc[threadIdx.x];
 }
 
+
+// ---- width-w NAF digits for the every-bit-position table (zk_srs::pre_naf) -------------------------------------------------------
+// k = sum_j d_j 2^(p_j) with d_j odd, |d_j| < 2^(w-1) and p_(j+1) >= p_j + w: on average (bits + 1) / (w + 1) + ~0.5 digits instead of
+// bits / c, and only the odd magnitudes occur, so 2^(w-2) buckets take what a c = w - 1 window table needs 2^(w-2) for with more digits.
+// The scalar is never modified: a borrow into the bits above a negative digit is a carry flag, and "the next set bit of k + 2^p"
+// is the end of the run of ones at p.  Record of slot j of scalar i (rec[j*n + i], at most 16 slots):
+//   bucket (|d| - 1) / 2 in bits 0..15 | position << 16 | negative << 24 | 1 << 31;  0 = empty slot.
+constexpr uint32_t NAF_SLOTS = 16;
+template <class Fr, bool MONT>
+__global__ void __launch_bounds__(256) psortn_digits_hist(const uint32_t* scalars, uint64_t n, uint32_t sp, uint32_t w, uint32_t lob, uint32_t* rec,
+                                                          uint32_t* hist /* [256][PS_SLABS] */, uint32_t* scan_counter, uint32_t* combine_q) {
+    __shared__ uint32_t lc[256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scan_counter[0] = 0;
+        combine_q[0] = 0;
+        combine_q[1] = 0;
+    }
+    lc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * sp < n ? (uint64_t)blockIdx.x * sp : n;
+    const uint64_t hi = lo + sp < n ? lo + sp : n;
+    const uint32_t wmask = (1u << w) - 1u, half = 1u << (w - 1);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * i;
+        uint4 a = q[0], b = q[1];
+        Fr x;
+        x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+        x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+        if (MONT) x = Fr::from_mont(x);
+        // 64 bits of the scalar starting at bit p (zero beyond bit 255); register-resident limbs: select, do not index
+        auto bits64 = [&](uint32_t p) -> uint64_t {
+            const uint32_t limb = p >> 5, off = p & 31;
+            uint32_t l0 = 0, l1 = 0, l2 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((uint32_t)k == limb) l0 = x.v[k];
+                if ((uint32_t)k == limb + 1) l1 = x.v[k];
+                if ((uint32_t)k == limb + 2) l2 = x.v[k];
+            }
+            const uint64_t lo64 = ((uint64_t)l1 << 32) | l0;
+            return off ? (lo64 >> off) | ((uint64_t)l2 << (64 - off)) : lo64;
+        };
+        // state: the part of the scalar not yet recoded is floor(k / 2^p) + carry
+        uint32_t p = 0, carry = 0, slot = 0;
+        while (slot < NAF_SLOTS) {
+            uint64_t v = bits64(p);
+            if (carry) v = ~v;                       // k + 2^p: the carry runs through the ones at p and lands on the first zero
+            if (v == 0) {                            // 64 zeros (or, with a carry, 64 ones: only below bit 192, bit 255 of k is 0)
+                if (p >= 192) break;                 // no carry and nothing set above p: done
+                p += 64;
+                continue;
+            }
+            p += (uint32_t)__builtin_ctzll(v);       // <= 255: a negative digit needs bit p + w - 1 <= 254 set, so its carry lands at <= 255
+            uint32_t win = (uint32_t)bits64(p) & wmask;
+            win |= carry;                            // the zero that stopped the carry becomes the digit's low bit
+            carry = win >= half ? 1u : 0u;           // digit win - 2^w: borrow from the bits above the window
+            const uint32_t mag = carry ? (1u << w) - win : win;      // odd, < 2^(w-1)
+            const uint32_t bkt = (mag - 1u) >> 1;
+            rec[(uint64_t)slot * n + i] = bkt | (p << 16) | (carry << 24) | 0x80000000u;
+            atomicAdd(&lc[bkt >> lob], 1u);
+            ++slot;
+            p += w;
+        }
+        for (; slot < NAF_SLOTS; ++slot) rec[(uint64_t)slot * n + i] = 0u;
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * PS_SLABS + blockIdx.x] = lc[threadIdx.x];
+}
+
+// NAF: `dig` holds the records of psortn_digits_hist and a reference is negative << 31 | position << 23 | index
+template <bool NAF>
 __global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t lob, const uint32_t* cursors,
                                                        const uint32_t* part_start, uint32_t* stage_ref, uint16_t* stage_lo) {
     constexpr uint32_t PER = PS_STILE / PS_T;
@@ -654,8 +725,8 @@ __global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint6
                 const uint32_t q = base + i, w = q / len, ii = q - w * len;
                 const int32_t d = dig[(uint64_t)w * n + lo + ii];
                 if (d != 0) {
-                    const uint32_t neg = d < 0 ? 1u : 0u;
-                    const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
+                    const uint32_t neg = NAF ? ((uint32_t)d >> 24) & 1u : (d < 0 ? 1u : 0u);
+                    const uint32_t b = NAF ? (uint32_t)d & 0xffffu : (uint32_t)((neg ? -d : d) - 1);
                     pk[k] = i | (neg << 14) | ((b >> lob) << 15);
                     pl[k] = (uint16_t)(b & LOM);
                     atomicAdd(&cnt[b >> lob], 1u);
@@ -688,7 +759,9 @@ __global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint6
                 const uint32_t r = rec[qq];
                 const uint32_t pp = r >> 15;
                 const uint32_t q = base + (r & 0x3fffu), w = q / len, ii = q - w * len;
-                const uint32_t ref = (w << 26) | (uint32_t)(lo + ii) | (((r >> 14) & 1u) << 31);
+                uint32_t ref = (uint32_t)(lo + ii) | (((r >> 14) & 1u) << 31);
+                if (NAF) ref |= (((uint32_t)dig[(uint64_t)w * n + lo + ii] >> 16) & 0xffu) << 23;     // the digit's bit position (L2 hit)
+                else ref |= w << 26;
                 const uint32_t dst = gcur[pp] + (qq - toff[pp]);
                 stage_ref[dst] = ref;
                 stage_lo[dst] = rlo[qq];
@@ -801,7 +874,7 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
 // (row w holds 2^(c w) P_i); tab_stride = n_srs, tab_off = base_offset.
 template <class F, bool PRE>
 ZK_D void accumulate_chunk(const uint32_t t, const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases, void* buckets,
-                           void* part_pt, uint32_t L, uint64_t tab_stride, uint64_t tab_off) {
+                           void* part_pt, uint32_t L, uint64_t tab_stride, uint64_t tab_off, uint32_t row_shift, uint32_t row_mask) {
     const uint32_t E = offsets[nb];
     const uint64_t e0 = (uint64_t)t * L;
     if (e0 >= E) return;
@@ -820,7 +893,8 @@ ZK_D void accumulate_chunk(const uint32_t t, const uint32_t* entries, const uint
     // software pipeline: the reference and the 128-byte point of iteration e+1 are requested before the
     // mixed addition of iteration e (two dependent HBM/L2 round trips otherwise sit in front of every add)
     auto point_index = [&](uint32_t ref) -> uint64_t {
-        return PRE ? (uint64_t)((ref >> 26) & 31u) * tab_stride + tab_off + (ref & 0x3ffffffu) : (uint64_t)(ref & 0x7fffffffu);
+        // PRE: row (window, or bit position of a NAF digit) in bits [row_shift, 31), index below it
+        return PRE ? (uint64_t)((ref >> row_shift) & row_mask) * tab_stride + tab_off + (ref & ((1u << row_shift) - 1u)) : (uint64_t)(ref & 0x7fffffffu);
     };
     uint32_t ref_n = entries[(uint32_t)e0];
     AffineU<F> p_n = ld_affine<F>(bases, point_index(ref_n));
@@ -860,10 +934,10 @@ ZK_D void accumulate_chunk(const uint32_t t, const uint32_t* entries, const uint
 template <class F, bool PRE>
 __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases,
                                                        void* buckets, void* part_pt, uint32_t L, uint32_t n_lanes, uint64_t tab_stride,
-                                                       uint64_t tab_off) {
+                                                       uint64_t tab_off, uint32_t row_shift, uint32_t row_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
-    accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, tab_stride, tab_off);
+    accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, tab_stride, tab_off, row_shift, row_mask);
 }
 
 // The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by
@@ -1626,7 +1700,7 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         const int T = 128;
         unsigned blocks = (n_lanes + T - 1) / T;
         hipLaunchKernelGGL((msm_accumulate<F, false>), dim3(blocks), dim3(T), 0, st, entries, offsets, g.nb, d_bases, mb.buckets.p,
-                           mb.part_pt.p, CHUNK_L, n_lanes, (uint64_t)0, (uint64_t)0);
+                           mb.part_pt.p, CHUNK_L, n_lanes, (uint64_t)0, (uint64_t)0, 31u, 0u);
         ZK_HIP_TRY(hipGetLastError());
     }
     {
@@ -1694,6 +1768,57 @@ __global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, u
     }
 }
 
+// table[r][i] = 2^r * P_i for EVERY r = 1 .. R-1 (the every-bit-position table of zk_srs::pre_naf), affine internal form.
+// One inversion per row and point (msm_precompute with c = 1) would be 255 Fermat inversions per point; instead the rows are
+// produced RB at a time: RB doublings in XYZZ (X, Y parked in the table row itself; ZZ, ZZZ and the running product of the ZZZ
+// in `scratch`, RB x n x 3 field elements), ONE inversion of the product, and a backward sweep that peels off every 1/ZZZ_j
+// (Montgomery's trick along the chain): ~16 products per row + 1/RB of an inversion instead of ~580.
+constexpr uint32_t CHAIN_RB = 32;
+template <class F>
+__global__ void __launch_bounds__(128) msm_precompute_chain(void* table, uint64_t n, uint32_t R, void* scratch) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int U4 = Store<F>::U4;
+    uint4* base = reinterpret_cast<uint4*>(table);
+    uint4* scr = reinterpret_cast<uint4*>(scratch);
+    auto row = [&](uint32_t r) { return base + ((uint64_t)r * n + i) * (2 * U4); };
+    auto sc = [&](uint32_t j, uint32_t which) { return scr + (((uint64_t)j * n + i) * 3 + which) * U4; };     // 0 ZZ, 1 ZZZ, 2 prefix product
+    AffineU<F> p = ld_affine<F>(table, i);
+    if (p.is_null()) {
+        for (uint32_t r = 1; r < R; ++r) {
+            st_fu<F>(row(r), F::zero());
+            st_fu<F>(row(r) + U4, F::zero());
+        }
+        return;
+    }
+    XYZZu<F> acc = XYZZu<F>::from_affine(p);
+    for (uint32_t r0 = 1; r0 < R; r0 += CHAIN_RB) {
+        const uint32_t m = R - r0 < CHAIN_RB ? R - r0 : CHAIN_RB;
+        F prefix = F::one();
+        for (uint32_t j = 0; j < m; ++j) {
+            acc = XYZZu<F>::dbl(acc);           // a point of odd prime order never doubles to infinity
+            st_fu<F>(row(r0 + j), acc.x);
+            st_fu<F>(row(r0 + j) + U4, acc.y);
+            st_fu<F>(sc(j, 0), acc.zz);
+            st_fu<F>(sc(j, 1), acc.zzz);
+            prefix = F::mul(prefix, acc.zzz);
+            st_fu<F>(sc(j, 2), prefix);
+        }
+        F inv = F::inverse(prefix);             // 1 / (ZZZ_0 ... ZZZ_(m-1))
+        for (uint32_t j = m; j-- > 0;) {
+            const F zzz = ld_fu<F>(sc(j, 1));
+            const F i3 = j ? F::mul(inv, ld_fu<F>(sc(j - 1, 2))) : inv;     // 1 / ZZZ_j
+            inv = F::mul(inv, zzz);
+            const F zi = F::mul(ld_fu<F>(sc(j, 0)), i3);                    // ZZ / ZZZ = 1 / Z
+            const F zi2 = F::sqr(zi);
+            const F x = F::canonical_lt2p(F::mul(ld_fu<F>(row(r0 + j)), zi2));
+            const F y = F::canonical_lt2p(F::mul(ld_fu<F>(row(r0 + j) + U4), i3));
+            st_fu<F>(row(r0 + j), x);
+            st_fu<F>(row(r0 + j) + U4, y);
+        }
+    }
+}
+
 constexpr uint32_t PRE_C = 16;        // default window of the precomputed table
 constexpr uint32_t PRE_C_MAX = 21;    // 2^20 shared buckets: 4096 per partition in the second sort pass (144 KiB of LDS)
 constexpr uint32_t PRE_CHUNK_L = 128; // references per lane on the shared-bucket path (buckets hold ~W*n/2^15 each)
@@ -1704,6 +1829,45 @@ constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket re
 template <class Cv>
 int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     typedef typename Cv::FqU F;
+    if (window_bits & ZK_TABLE_EVERY_BIT) {
+        // every-bit-position table for width-w NAF digits: (scalar bits + 1) rows, 2^(w-2) shared buckets
+        const uint32_t w = window_bits & 0xffu;
+        if (w != 17) return ZK_ERR_BAD_ARG;
+        const uint32_t R = (uint32_t)Cv::FrP::BITS + 1;
+        if (R > 256 || s->n >= (1ull << 23)) return ZK_ERR_UNSUPPORTED;      // a reference holds 8 bits of position and 23 of index
+        const size_t pb = s->point_bytes;
+        void* tab = nullptr;
+        void* scratch = nullptr;
+        if (hipMalloc(&tab, (size_t)R * s->n * pb) != hipSuccess) {
+            (void)hipGetLastError();
+            return ZK_ERR_OOM;
+        }
+        if (hipMalloc(&scratch, (size_t)CHAIN_RB * s->n * 3 * (pb / 2)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(tab);
+            return ZK_ERR_OOM;
+        }
+        hipError_t e = hipMemcpyAsync(tab, s->d_xy, s->n * pb, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) {
+            const int T = 128;
+            hipLaunchKernelGGL(msm_precompute_chain<F>, dim3((unsigned)((s->n + T - 1) / T)), dim3(T), 0, c->stream, tab, (uint64_t)s->n, R, scratch);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(scratch);
+        if (e != hipSuccess) {
+            (void)hipFree(tab);
+            zk_note_hip_error(e, "msm_precompute_chain", __FILE__, __LINE__);
+            return ZK_ERR_HIP;
+        }
+        (void)hipFree(s->d_xy);
+        s->d_xy = tab;
+        s->pre_c = w;
+        s->pre_W = NAF_SLOTS;
+        s->pre_naf = true;
+        s->pre_rows = R;
+        return ZK_OK;
+    }
     if (window_bits == 0) window_bits = PRE_C;
     if (window_bits < PRE_C || window_bits > PRE_C_MAX) return ZK_ERR_BAD_ARG;
     MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)window_bits, PRE_C_MAX);
@@ -1742,6 +1906,8 @@ struct PrePlan {
     uint32_t chunk_l, n_lanes, S;
     size_t win_bytes;
     bool wide;          // c > 16: int32 digits, 2^(c-9) buckets per sort partition, three-level device reduction
+    bool naf;           // every-bit-position table: width-c NAF digits (odd, <= 16 per scalar), 2^(c-2) shared buckets; the
+                        // digits take the wide sort (32-bit records), the buckets the ordinary reduction
 };
 
 template <class Cv>
@@ -1751,9 +1917,21 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     typedef XYZZ<Fq> PH;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
-    pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
-    if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
-    pl.wide = pl.g.c > 16;
+    pl.naf = s->pre_naf;
+    if (pl.naf) {
+        pl.g.c = s->pre_c;
+        pl.g.W = NAF_SLOTS;                               // digit slots per scalar; the digits present are counted by the sort
+        pl.g.B = 1u << (s->pre_c - 2);                     // odd magnitudes below 2^(c-1)
+        pl.g.nb = pl.g.B;
+        pl.g.logG = 4;
+        pl.g.ns = pl.g.B >> pl.g.logG;
+        pl.g.logq = 0;
+        if (n >= (1ull << 23) || pl.g.B != (1u << 15)) return ZK_ERR_UNSUPPORTED;
+    } else {
+        pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
+        if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
+    }
+    pl.wide = !pl.naf && pl.g.c > 16;
     pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
     if (pl.nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
     pl.g1 = pl.g;                                       // the sort sees ONE window of nf digits
@@ -1797,7 +1975,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     int rc;
     if (!pl.wide && (rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
     if ((rc = mb.offsets.ensure((size_t)(pl.g.B + 1) * 4))) return rc;
-    if ((rc = mb.tmp.ensure((size_t)pl.nf * (pl.wide ? 4 : 2)))) return rc;
+    if ((rc = mb.tmp.ensure((size_t)pl.nf * (pl.wide || pl.naf ? 4 : 2)))) return rc;
     if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
     if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
@@ -1826,8 +2004,8 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
     const int T = 256;
     unsigned blocks = (unsigned)((n + T - 1) / T);
     typedef typename Cv::Fr FrS;
-    if (pl.wide) {
-        const uint32_t lob = pl.g.c - 9, P = 256;
+    if (pl.wide || pl.naf) {
+        const uint32_t lob = pl.naf ? pl.g.c - 10 : pl.g.c - 9, P = 256;     // 2^lob buckets per partition, 256 partitions
         const uint32_t sp = psort_slab_len(n);
         uint32_t* part_start = (uint32_t*)mb.part_key.p;
         uint32_t* part_total = part_start + P + 1;
@@ -1838,15 +2016,25 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
         hist = (uint32_t*)mb.counts.p;
         int32_t* dig32 = (int32_t*)mb.tmp.p;
-        if (mont) hipLaunchKernelGGL((psortw_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
-                                     lob, dig32, hist, scan_counter, combine_q);
-        else hipLaunchKernelGGL((psortw_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
-                                lob, dig32, hist, scan_counter, combine_q);
+        if (pl.naf) {
+            if (mont) hipLaunchKernelGGL((psortn_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp,
+                                         pl.g.c, lob, (uint32_t*)dig32, hist, scan_counter, combine_q);
+            else hipLaunchKernelGGL((psortn_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp,
+                                    pl.g.c, lob, (uint32_t*)dig32, hist, scan_counter, combine_q);
+        } else if (mont) {
+            hipLaunchKernelGGL((psortw_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
+                               lob, dig32, hist, scan_counter, combine_q);
+        } else {
+            hipLaunchKernelGGL((psortw_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
+                               lob, dig32, hist, scan_counter, combine_q);
+        }
         hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
         uint32_t* stage_ref = (uint32_t*)mb.stage.p;
         uint16_t* stage_lo = (uint16_t*)((char*)mb.stage.p + (size_t)pl.nf * 4);
-        hipLaunchKernelGGL(psortw_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, (const int32_t*)dig32, (uint64_t)n, pl.g.W, sp, lob, hist, part_start,
-                           stage_ref, stage_lo);
+        if (pl.naf) hipLaunchKernelGGL(psortw_scatter<true>, dim3(PS_SLABS), dim3(PS_T), 0, st, (const int32_t*)dig32, (uint64_t)n, pl.g.W, sp, lob, hist,
+                                       part_start, stage_ref, stage_lo);
+        else hipLaunchKernelGGL(psortw_scatter<false>, dim3(PS_SLABS), dim3(PS_T), 0, st, (const int32_t*)dig32, (uint64_t)n, pl.g.W, sp, lob, hist,
+                                part_start, stage_ref, stage_lo);
         const uint32_t NB = 1u << lob;
         const size_t lds = ((size_t)3 * NB + 1 + 16 + PS_TILE) * 4 + (size_t)PS_TILE * 2;
         ZK_HIP_TRY(hipFuncSetAttribute((const void*)psortw_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1926,7 +2114,8 @@ int pre_queue_accumulate(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, s
     const int T = 128;
     unsigned blocks = (pl.n_lanes + T - 1) / T;
     hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, (const uint32_t*)mb.entries.p, (const uint32_t*)mb.offsets.p,
-                       pl.g1.nb, s->d_xy, mb.buckets.p, mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
+                       pl.g1.nb, s->d_xy, mb.buckets.p, mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset,
+                       pl.naf ? 23u : 26u, pl.naf ? 255u : 31u);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
@@ -1934,14 +2123,14 @@ int pre_queue_accumulate(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, s
 // fused reduction of the jobs mbs[0..n_jobs) (same geometry) + read-back of their virtual-window sums
 // into h_win (n_jobs x win_bytes)
 template <class Cv>
-int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_jobs, void* h_win, hipStream_t st) {
+int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_t n_jobs, void* h_win, hipStream_t st) {
     typedef typename Cv::FqU F;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     RJobs jobs;
     memset(&jobs, 0, sizeof jobs);
     const PrePlan& p0 = pls[0];
     for (uint32_t k = 0; k < n_jobs; ++k) {
-        MsmBufs& mb = mbs[k];
+        MsmBufs& mb = *mbs[k];
         jobs.part_pt[k] = mb.part_pt.p;
         jobs.offsets[k] = (const uint32_t*)mb.offsets.p;
         jobs.buckets[k] = mb.buckets.p;
@@ -1960,9 +2149,9 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* mbs, uint32_t n_job
         void* d_seg3[MAX_JOBS];
         void* d_seg2[MAX_JOBS];
         for (uint32_t k = 0; k < n_jobs; ++k) {
-            d_vw[k] = mbs[k].win.p;
-            d_seg3[k] = mbs[k].seg3.p;
-            d_seg2[k] = mbs[k].seg2.p;
+            d_vw[k] = mbs[k]->win.p;
+            d_seg3[k] = mbs[k]->seg3.p;
+            d_seg2[k] = mbs[k]->seg2.p;
         }
         return queue_reduce_wide<F>(c, jobs, n_jobs, p0.g1.nb, d_vw, d_seg3, d_seg2, (char*)h_win, p0.win_bytes, st);
     }
@@ -2015,8 +2204,10 @@ void pre_host_partial(const void* h_win, uint32_t VW, uint32_t lo, uint32_t hi, 
     out.t = PH::add(run, win[VW + lo]);
     out.w = w;
 }
+// odd: bucket j (0-based) holds the digits of magnitude 2j + 1 (the NAF table) instead of j + 1:
+//   sum_j (2j + 1) B_j = 2 * sum_j (j + 1) B_j - sum_j B_j
 template <class Cv>
-void pre_host_final(const HostPartial<typename Cv::Fq>* part, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
+void pre_host_final(const HostPartial<typename Cv::Fq>* part, uint32_t VW, uint32_t VB, uint64_t* out_xyz, bool odd = false) {
     typedef typename Cv::Fq Fq;
     typedef XYZZ<Fq> PH;
     constexpr int L64 = Fq::N / 2;
@@ -2034,6 +2225,11 @@ void pre_host_final(const HostPartial<typename Cv::Fq>* part, uint32_t VW, uint3
     wsum = PH::add(wsum, ct);
     for (uint32_t k = 0; (1u << k) < VB; ++k) wsum = PH::dbl(wsum);
     total = PH::add(total, wsum);
+    if (odd) {
+        PH plain = PH::infinity();
+        for (uint32_t c = 0; c < HOST_CHUNKS; ++c) plain = PH::add(plain, part[c].t);
+        total = PH::add(PH::dbl(total), PH::neg(plain));
+    }
     Fq X = Fq::one(), Y = Fq::one(), Z = Fq::zero();
     if (!total.is_inf()) {
         X = Fq::mul(total.x, total.zz);
@@ -2045,10 +2241,10 @@ void pre_host_final(const HostPartial<typename Cv::Fq>* part, uint32_t VW, uint3
     memcpy(out_xyz + 2 * L64, Z.v, sizeof(uint64_t) * L64);
 }
 template <class Cv>
-void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out_xyz) {
+void pre_host_combine(const void* h_win, uint32_t VW, uint32_t VB, uint64_t* out_xyz, bool odd = false) {
     HostPartial<typename Cv::Fq> part[HOST_CHUNKS];
     for (uint32_t c = 0; c < HOST_CHUNKS; ++c) pre_host_partial<Cv>(h_win, VW, c * (VW / HOST_CHUNKS), (c + 1) * (VW / HOST_CHUNKS), part[c]);
-    pre_host_final<Cv>(part, VW, VB, out_xyz);
+    pre_host_final<Cv>(part, VW, VB, out_xyz, odd);
 }
 
 int ensure_pinned(zk_ctx* c, size_t bytes) {
@@ -2071,10 +2267,11 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     if ((rc = ensure_pinned(c, pl.win_bytes * MAX_JOBS))) return rc;
     if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_scalars, n, c->stream))) return rc;
     if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, base_offset, c->stream))) return rc;
-    if ((rc = pre_queue_reduce<Cv>(c, &pl, &mb, 1, c->pinned, c->stream))) return rc;
+    MsmBufs* one = &mb;
+    if ((rc = pre_queue_reduce<Cv>(c, &pl, &one, 1, c->pinned, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     if (pl.wide) pre_host_wide<Cv>(c->pinned, ilog2_floor(pl.gv.B), out_xyz);
-    else pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
+    else pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz, pl.naf);
     return ZK_OK;
 }
 
@@ -2087,63 +2284,94 @@ int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 // launch per kernel (job = blockIdx.y), so the dependent-addition chains of the reduction are paid
 // once per round instead of once per MSM.  Everything stays on the ctx stream: overlapping
 // neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md).
+//
+// The batch comes in two halves so that a round may be OPENED by several calls and closed by one
+// (zk_kzg_round_begin_dev / zk_kzg_round_end): `begin` queues sort + accumulate of its jobs into the buffer
+// sets c->mb[slot0 ..], `end` reduces every open job in one launch per kernel, waits once and finishes on the host.
 template <class Cv>
-int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
-                  const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
-                  uint64_t* out_xy /* optional: n_polys x 2L affine */, uint8_t* out_inf /* optional flags */,
-                  const std::function<int(uint32_t)>* before_job /* optional: runs before job k is queued */) {
+int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
+                        const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
+                        const std::function<int(uint32_t)>* before_job /* optional: runs before job k is queued */) {
+    if (n_polys == 0) return ZK_OK;
+    if (slot0 + n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    int rc;
+    hipStream_t st = c->stream;
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        MsmBufs& mb = c->mb[slot0 + k];
+        PrePlan pl;
+        if ((rc = pre_plan<Cv>(c, s, lens[k], mb, pl))) return rc;
+        const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
+        if (before_job && (rc = (*before_job)(k))) return rc;
+        if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_coeffs[k], lens[k], st, mont))) return rc;
+        if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, 0, st))) return rc;
+    }
+    return ZK_OK;
+}
+
+// slots[k]: the buffer set job k was queued into; lens[k]: its length (the plan is a pure function of the SRS and the length)
+template <class Cv>
+int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz /* n_jobs x 3L */,
+                      uint64_t* out_xy /* optional: n_jobs x 2L affine */, uint8_t* out_inf /* optional flags */) {
     typedef typename Cv::Fq Fq;
     constexpr int L64 = Fq::N / 2;
-    if (n_polys == 0) return ZK_OK;
-    if (n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
     PrePlan pl[MAX_JOBS];
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[k], pl[k]))) return rc;
+    MsmBufs* mbs[MAX_JOBS];
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        if (slots[k] >= (uint32_t)MAX_JOBS) return ZK_ERR_BAD_ARG;
+        mbs[k] = &c->mb[slots[k]];
+        if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k]))) return rc;    // buffers already large enough: no allocation
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
     }
     const size_t wb = pl[0].win_bytes;
     if ((rc = ensure_pinned(c, wb * MAX_JOBS))) return rc;
     hipStream_t st = c->stream;
-    for (uint32_t k = 0; k < n_polys; ++k) {
-        MsmBufs& mb = c->mb[k];
-        const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
-        if (before_job && (rc = (*before_job)(k))) return rc;
-        if ((rc = pre_queue_sort<Cv>(c, pl[k], mb, d_coeffs[k], lens[k], st, mont))) return rc;
-        if ((rc = pre_queue_accumulate<Cv>(c, pl[k], mb, s, 0, st))) return rc;
-    }
-    if ((rc = pre_queue_reduce<Cv>(c, pl, c->mb, n_polys, c->pinned, st))) return rc;
+    if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(st));
     const char* h_win = (const char*)c->pinned;
     int rcs[MAX_JOBS] = {0};
     if (pl[0].wide) {
-        c->pool->run(n_polys, [&](uint32_t k) {
+        c->pool->run(n_jobs, [&](uint32_t k) {
             uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
             pre_host_wide<Cv>(h_win + (size_t)k * wb, ilog2_floor(pl[k].gv.B), xyz);
             if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
         });
-    } else if (n_polys <= 2) {
+    } else if (n_jobs <= 2) {
         // few jobs: the window ranges of a job go to different pool threads as well
         HostPartial<Fq> part[2 * HOST_CHUNKS];
-        c->pool->run(n_polys * HOST_CHUNKS, [&](uint32_t i) {
+        c->pool->run(n_jobs * HOST_CHUNKS, [&](uint32_t i) {
             const uint32_t k = i / HOST_CHUNKS, ch = i % HOST_CHUNKS, VW = pl[k].gv.W;
             pre_host_partial<Cv>(h_win + (size_t)k * wb, VW, ch * (VW / HOST_CHUNKS), (ch + 1) * (VW / HOST_CHUNKS), part[i]);
         });
-        for (uint32_t k = 0; k < n_polys; ++k) {
+        for (uint32_t k = 0; k < n_jobs; ++k) {
             uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
-            pre_host_final<Cv>(part + k * HOST_CHUNKS, pl[k].gv.W, pl[k].gv.B, xyz);
+            pre_host_final<Cv>(part + k * HOST_CHUNKS, pl[k].gv.W, pl[k].gv.B, xyz, pl[k].naf);
             if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
         }
     } else {
-        c->pool->run(n_polys, [&](uint32_t k) {
+        c->pool->run(n_jobs, [&](uint32_t k) {
             uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
-            pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, xyz);
+            pre_host_combine<Cv>(h_win + (size_t)k * wb, pl[k].gv.W, pl[k].gv.B, xyz, pl[k].naf);
             if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
         });
     }
-    for (uint32_t k = 0; k < n_polys; ++k)
+    for (uint32_t k = 0; k < n_jobs; ++k)
         if (rcs[k]) return rcs[k];
     return ZK_OK;
+}
+
+template <class Cv>
+int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
+                  const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job) {
+    if (n_polys == 0) return ZK_OK;
+    if (n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    int rc = msm_batch_pre_begin<Cv>(c, s, 0, n_polys, d_coeffs, lens, kinds, before_job);
+    if (rc) return rc;
+    uint32_t slots[MAX_JOBS];
+    for (uint32_t k = 0; k < n_polys; ++k) slots[k] = k;
+    return msm_batch_pre_end<Cv>(c, s, n_polys, slots, lens, out_xyz, out_xy, out_inf);
 }
 
 template <class Fq>
@@ -2248,6 +2476,15 @@ int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void
 int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz,
                               const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job) {
     return msm_batch_pre<CurveSel>(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf, before_job);
+}
+
+int ZK_SYM(msm_batch_pre_begin_dev)(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
+                                    const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
+    return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+}
+int ZK_SYM(msm_batch_pre_end_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
+                                  uint64_t* out_xy, uint8_t* out_inf) {
+    return msm_batch_pre_end<CurveSel>(c, s, n_jobs, slots, lens, out_xyz, out_xy, out_inf);
 }
 
 size_t ZK_SYM(msm_point_bytes)() { return (size_t)2 * Store<CurveSel::FqU>::WORDS * 4; }

@@ -11,7 +11,11 @@
     int msm_precompute_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t window_bits);                                                                 \
     int msm_run_pre_dev##sfx(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);  \
     int msm_batch_pre_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz, \
-                               const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job);
+                               const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job); \
+    int msm_batch_pre_begin_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, \
+                                     const uint8_t* kinds, const std::function<int(uint32_t)>* before_job);                \
+    int msm_batch_pre_end_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz, \
+                                   uint64_t* out_xy, uint8_t* out_inf);
 DECLS(_c0)
 DECLS(_c1)
 
@@ -59,5 +63,17 @@ int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const*
                       const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job) {
     if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_dev_c0(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf, before_job);
     if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_dev_c1(c, s, n_polys, d_coeffs, lens, out_xyz, kinds, out_xy, out_inf, before_job);
+    return ZK_ERR_BAD_ARG;
+}
+int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
+                            const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_begin_dev_c0(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+    if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_begin_dev_c1(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+    return ZK_ERR_BAD_ARG;
+}
+int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz, uint64_t* out_xy,
+                          uint8_t* out_inf) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_end_dev_c0(c, s, n_jobs, slots, lens, out_xyz, out_xy, out_inf);
+    if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_end_dev_c1(c, s, n_jobs, slots, lens, out_xyz, out_xy, out_inf);
     return ZK_ERR_BAD_ARG;
 }

@@ -257,6 +257,7 @@ struct Wire {
         uint8_t buf[FQ_BYTES];
         memcpy(buf, in + FQ_BYTES, FQ_BYTES);
         const uint8_t flags = buf[FQ_BYTES - 1] & 0xC0;
+        if (flags == 0xC0) return ZK_ERR_BAD_ARG;           // SWFlags::from_u8: both bits set is invalid (as g1_de_c)
         buf[FQ_BYTES - 1] &= 0x3F;
         Fq x, y;
         if (!fp_from_le_bytes<Fq, FqP>(in, FQ_BYTES, x) || !fp_from_le_bytes<Fq, FqP>(buf, FQ_BYTES, y)) return ZK_ERR_BAD_ARG;
@@ -383,7 +384,9 @@ int zk_transcript_challenge_scalar(zk_transcript* t, int curve_id, const uint8_t
     WIRE_DISPATCH(curve_id, Wire<CurveBls>::challenge(t->st, label, label_len, fr_mont), Wire<CurveBn>::challenge(t->st, label, label_len, fr_mont));
 }
 // `PublicInputs { values: BTreeMap<usize, F> }` (pi.rs:28-36) under `label` (prover.rs:182 uses b"pi"):
-// u64 count, then (u64 position, Fr) in ascending position order
+// u64 count, then (u64 position, Fr) in ascending position order.  `PublicInputs::insert` (pi.rs:56-65) drops zero values
+// ("zeros are the implicit value of empty positions"), so the reference's map never holds one -- neither on the prover's nor on
+// the verifier's side: a zero entry handed in here is skipped the same way, it is not part of the message.
 int zk_transcript_append_public_inputs(zk_transcript* t, int curve_id, const uint8_t* label, size_t label_len, const uint64_t* positions,
                                        const uint64_t* values_mont, size_t n) {
     if (!t || (n && (!positions || !values_mont))) return ZK_ERR_BAD_ARG;
@@ -391,10 +394,14 @@ int zk_transcript_append_public_inputs(zk_transcript* t, int curve_id, const uin
     if (!f) return ZK_ERR_BAD_ARG;
     for (size_t i = 1; i < n; ++i)
         if (positions[i] <= positions[i - 1]) return ZK_ERR_BAD_ARG;     // a BTreeMap iterates in strictly ascending key order
-    std::vector<uint8_t> buf(8 + n * (8 + f));
+    auto is_zero = [&](size_t i) { return (values_mont[4 * i] | values_mont[4 * i + 1] | values_mont[4 * i + 2] | values_mont[4 * i + 3]) == 0; };
+    size_t kept = 0;
+    for (size_t i = 0; i < n; ++i) kept += is_zero(i) ? 0 : 1;
+    std::vector<uint8_t> buf(8 + kept * (8 + f));
     uint8_t* w = buf.data();
-    for (int b = 0; b < 8; ++b) *w++ = (uint8_t)((uint64_t)n >> (8 * b));
+    for (int b = 0; b < 8; ++b) *w++ = (uint8_t)((uint64_t)kept >> (8 * b));
     for (size_t i = 0; i < n; ++i) {
+        if (is_zero(i)) continue;
         for (int b = 0; b < 8; ++b) *w++ = (uint8_t)(positions[i] >> (8 * b));
         int rc = zk_fr_serialize(curve_id, values_mont + 4 * i, w);
         if (rc) return rc;

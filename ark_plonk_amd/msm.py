@@ -92,7 +92,9 @@ class CommitterKey:
 
     def precompute(self, window_bits: int = 0):
         """Build the window-multiples table (16x the SRS in HBM at the default window c = 16); later MSMs share one
-        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets)."""
+        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets), or
+        TABLE_EVERY_BIT | 17: a row for every bit position (256x the SRS) and width-17 NAF digits -- 14.7 instead of 16
+        additions per 255-bit scalar into the same 2^15 buckets."""
         self.ctx.use_torch_stream() if _has_torch_cuda() else None
         check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
         return self
@@ -164,8 +166,9 @@ class CommitterKey:
         """The same device-resident SRS (and window table) driven from another Context of the same GPU."""
         if ctx.device != self.ctx.device:
             raise ValueError("an SRS handle belongs to one device")
+        check(lib().zk_srs_retain(self._h), "zk_srs_retain")     # the copy owns a reference: it may outlive `self`
         other = object.__new__(CommitterKey)
-        other.curve, other.ctx, other.n, other._h, other._borrowed = self.curve, ctx, self.n, self._h, True
+        other.curve, other.ctx, other.n, other._h, other._borrowed = self.curve, ctx, self.n, self._h, False
         return other
 
     def commit_batch(self, polys, canonical=None) -> list:
@@ -218,6 +221,63 @@ class CommitterKey:
         check(lib().zk_kzg_round_batch_partial_dev(self.ctx.handle, self._h, k, ptrs, lens, None if kinds is None else ptr_of(kinds),
                                                    ptr_of(out)), "zk_kzg_round_batch_partial_dev")
         return out
+
+    # -- deferred rounds (zk_kzg_round_begin_dev ... zk_kzg_round_end): commitments whose inputs do not depend on each
+    #    other's results -- f | h_1 | h_2, z | z_2, the four calls of the last round -- queued by several calls, collected by one
+    def commit_begin(self, polys, canonical=None) -> int:
+        """Queue the MSMs of `polys` (device tensors) in the ctx's open round; returns the number of jobs now pending."""
+        k = len(polys)
+        kinds = None
+        if canonical is not None:
+            kinds = np.ascontiguousarray([1 if f else 0 for f in canonical], dtype=np.uint8)
+        ptrs = (ctypes.c_void_p * k)()
+        lens = (ctypes.c_size_t * k)()
+        for i, p in enumerate(polys):
+            lens[i] = check_dev_tensor(p, 4, self.ctx.device)
+            ptrs[i] = p.data_ptr()
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_round_begin_dev(self.ctx.handle, self._h, k, ptrs, lens, None if kinds is None else ptr_of(kinds)),
+              "zk_kzg_round_begin_dev")
+        return self.round_pending()
+
+    def open_begin(self, polys, point_mont, challenge_mont) -> int:
+        """PC::open as a job of the open round: the witness polynomial is built now, its MSM is deferred."""
+        k = len(polys)
+        ptrs = (ctypes.c_void_p * k)()
+        lens = (ctypes.c_size_t * k)()
+        for i, p in enumerate(polys):
+            lens[i] = check_dev_tensor(p, 4, self.ctx.device)
+            ptrs[i] = p.data_ptr()
+        z = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
+        ch = np.ascontiguousarray(challenge_mont, dtype=np.uint64).reshape(4)
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_open_begin_dev(self.ctx.handle, self._h, k, ptrs, lens, ptr_of(z), ptr_of(ch)), "zk_kzg_open_begin_dev")
+        return self.round_pending()
+
+    def round_pending(self) -> int:
+        n = ctypes.c_uint32()
+        check(lib().zk_kzg_round_pending(self.ctx.handle, ctypes.byref(n)), "zk_kzg_round_pending")
+        return n.value
+
+    def round_end(self, n_jobs: int | None = None) -> list:
+        """Close the round: one G1Affine per job, in submission order."""
+        L = self.curve.fq_limbs
+        k = self.round_pending() if n_jobs is None else n_jobs
+        out = np.zeros((max(k, 1), 2 * L), dtype=np.uint64)
+        inf = np.zeros(max(k, 1), dtype=np.uint8)
+        check(lib().zk_kzg_round_end(self.ctx.handle, k, ptr_of(out), ptr_of(inf)), "zk_kzg_round_end")
+        return [_point(out[i], inf[i:i + 1], self.curve) for i in range(k)]
+
+    def round_end_partial(self, n_jobs: int | None = None) -> np.ndarray:
+        """Close the round on a sharded SRS: this rank's Jacobian partials (jobs, 3L)."""
+        L = self.curve.fq_limbs
+        k = self.round_pending() if n_jobs is None else n_jobs
+        out = np.zeros((max(k, 1), 3 * L), dtype=np.uint64)
+        check(lib().zk_kzg_round_end_partial(self.ctx.handle, k, ptr_of(out)), "zk_kzg_round_end_partial")
+        return out[:k]
+
+    def round_abort(self):
+        check(lib().zk_kzg_round_abort(self.ctx.handle), "zk_kzg_round_abort")
 
     # -- PC::open(ck, polys, comms, point, opening_challenge, rands, None)
     def open(self, polys, point_mont, challenge_mont) -> G1Affine:

@@ -4,8 +4,12 @@ prover.rs:163-638), replayed through the C ABI on device-resident data.
 Only the transforms and commitments are reproduced -- the same kinds, sizes and order the reference
 issues them: 13 ifft(n) + 4 fft(n) + 13 coset_fft(4n) + 1 coset_ifft(4n) and 29 MSMs
 of ~n points, in the reference's eleven PC::commit / PC::open calls (4 | 1 | 1 | 1 | 1 | 1 | 4 | 7 | 1 | 7 | 1
-polynomials, prover.rs:213,289,312,315,361,387,459,579,582,606,609): a batch never crosses a call
-boundary, because a drop-in PC implementation could not do that either.  The serial CPU glue between
+polynomials, prover.rs:213,289,312,315,361,387,459,579,582,606,609).  Calls whose inputs do not depend on each
+other's results -- f | h_1 | h_2 (no challenge is drawn between them, prover.rs:289-317), z | z_2 (prover.rs:361-389)
+and the four calls of the last round (prover.rs:579-618) -- are issued through the deferred form of the ABI
+(zk_kzg_round_begin_dev / zk_kzg_open_begin_dev ... zk_kzg_round_end): still eleven calls and 29 MSMs with identical
+results, but the host blocks five times per proof instead of eleven and the bucket reductions of a group run as one
+launch per kernel (`defer_calls=False` blocks in every call, as an unchanged `Prover::prove` does).  The serial CPU glue between
 the calls (transcript, linearisation) is out of scope, so polynomial *values* are synthetic unless the
 optional device builders of SURVEY.md 8f are switched on (grand_products: z / z2; quotient: the 4n
 quotient evaluations); what is preserved is which buffers feed which call and their lengths, e.g. the
@@ -29,7 +33,7 @@ class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
-                 ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False):
+                 ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -52,6 +56,9 @@ class ProofSchedule:
         # known before the first call (both opening challenges are drawn with no transcript append in between), so
         # a prover that merges the four calls can run them as ONE batch: fuse_round5=True (needs that caller change).
         self.fuse_round5 = fuse_round5
+        # eleven PC calls, five host waits: see the module docstring.  False = every call blocks (the drop-in shape).
+        self.defer_calls = defer_calls
+        self._pending = []          # per open call: ("q", n_jobs) queued in the ABI's round | ("r", [points]) already computed
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
         self.grand_products = grand_products
@@ -152,11 +159,97 @@ class ProofSchedule:
     # -- the commitments of one prover round: submitted back to back, collected together (the
     #    transcript needs them only at the end of the round)
     def _commit_round(self, polys, canonical=None, labels=None):
+        self._round_begin(polys, canonical, labels)
+        return self._round_end()
+
+    def _immediate(self):
+        # the label cache and the ABI's commitment cache answer at once; so does a schedule asked to block in every call
+        return self.dedup or self.dedup_abi or not self.defer_calls
+
+    def _round_begin(self, polys, canonical=None, labels=None):
+        """One PC::commit call of the reference: queued in the open round (or computed at once, see _immediate)."""
         polys = list(polys)
+        if self._immediate():
+            self._pending.append(("r", self._commit_now(polys, canonical, labels)))
+            return
+        self.msms_run += len(polys)
+        if self.world == 1:
+            self.ck.commit_begin(polys, canonical=canonical)
+        else:
+            # sharded: this rank's slice of every polynomial
+            for sl, kd in zip(self._slices(polys), canonical or [False] * len(polys)):
+                if sl.shape[0]:
+                    self.ck.commit_begin([sl], canonical=[kd])
+                    self._pending.append(("q", 1))
+                else:
+                    self._pending.append(("z", 1))      # nothing of this polynomial falls into the rank's shard
+            return
+        self._pending.append(("q", len(polys)))
+
+    def _open_begin(self, polys, label):
+        """One PC::open call of the reference (prover.rs:582-591, 609-618)."""
+        if self._immediate() or self.world > 1:
+            from .msm import kzg_witness
+            # the witness polynomial is computed by every rank (replicated, like the NTTs); its MSM shards
+            w = kzg_witness(polys, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
+            self._round_begin([w], canonical=[True], labels=[label])
+            return
+        self.msms_run += 1
+        self.ck.open_begin(polys, self.z_mont, self.chi_mont)
+        self._pending.append(("q", 1))
+
+    def _round_end(self):
+        """Close the open round: the points of every call since the last close, in call order."""
+        pend, self._pending = self._pending, []
+        nq = sum(n for kind, n in pend if kind == "q")
+        got = []
+        if self.world == 1:
+            if nq:
+                got = self.ck.round_end(nq)
+        elif any(kind != "r" for kind, _ in pend):
+            L3 = 3 * self.cv.fq_limbs
+            got = self._gather(self.ck.round_end_partial(nq) if nq else np.zeros((0, L3), dtype=np.uint64), pend)
+        out, q = [], 0
+        for kind, v in pend:
+            if kind == "r":
+                out += v
+            else:                     # world > 1: one entry per job ("q" queued, "z" empty shard), `got` holds both
+                out += got[q:q + v]
+                q += v
+        return out
+
+    def _slices(self, polys):
+        return [p[self.lo:max(self.lo, min(self.hi, p.shape[0]))] for p in polys]
+
+    def _gather(self, parts, pend):
+        """Sharded round: ONE all-gather of every job's 3L-limb Jacobian partial, then the G-way sums."""
+        L3 = 3 * self.cv.fq_limbs
+        jobs = [kind for kind, _ in pend if kind != "r"]
+        full = np.zeros((len(jobs), L3), dtype=np.uint64)         # Z = 0: the empty shard's partial is the point at infinity
+        q = 0
+        for k, kind in enumerate(jobs):
+            if kind == "q":
+                full[k] = parts[q]
+                q += 1
+        return self._all_gather_sum(full)
+
+    def _all_gather_sum(self, parts):
+        torch = self.torch
+        L3 = 3 * self.cv.fq_limbs
+        n_jobs = parts.shape[0]
+        mine = torch.from_numpy(parts.view(np.int64).reshape(-1))
+        if self.dist.get_backend() == "nccl":
+            mine = mine.to(torch.device("cuda", self.ctx.device))
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine)
+        allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, n_jobs, L3)
+        return sum_partials_batch(allp, self.cv.curve_id)
+
+    def _commit_now(self, polys, canonical=None, labels=None):
         if self.dedup and labels is not None:
             todo = [k for k, lb in enumerate(labels) if lb not in self._cache and lb not in labels[:k]]
             if todo:
-                got = self._commit_round([polys[k] for k in todo], None if canonical is None else [canonical[k] for k in todo])
+                got = self._commit_now([polys[k] for k in todo], None if canonical is None else [canonical[k] for k in todo])
                 for k, pt in zip(todo, got):
                     self._cache[labels[k]] = pt
             return [self._cache[lb] for lb in labels]
@@ -168,23 +261,16 @@ class ProofSchedule:
                 self.msms_run -= self.ctx.commit_cache_stats()["hits"] - before
                 return res
             return self.ck.commit_batch(polys, canonical=canonical)
-        # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the round
-        torch = self.torch
+        # sharded: this rank's slice of every polynomial, one fused batch, ONE all-gather for the call
         L3 = 3 * self.cv.fq_limbs
-        slices = [p[self.lo:max(self.lo, min(self.hi, p.shape[0]))] for p in polys]
+        slices = self._slices(polys)
         if all(sl.shape[0] > 0 for sl in slices):
             parts = self.ck.commit_batch_partial(slices, canonical=canonical)
         else:
             kinds = canonical or [False] * len(polys)
             parts = np.stack([self.ck.commit_batch_partial([sl], canonical=[kd])[0] if sl.shape[0] else np.zeros(L3, dtype=np.uint64)
                               for sl, kd in zip(slices, kinds)])
-        mine = torch.from_numpy(parts.view(np.int64).reshape(-1))
-        if self.dist.get_backend() == "nccl":
-            mine = mine.to(polys[0].device)
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(gathered, mine)
-        allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, len(polys), L3)
-        return sum_partials_batch(allp, self.cv.curve_id)
+        return self._all_gather_sum(parts)
 
     def _set_proof(self, proof_id):
         """Every proof has its own witness: proof k's evaluation vectors are the seeded ones with k added to their first
@@ -224,7 +310,7 @@ class ProofSchedule:
             f_ev = lookup.compress_query(self.q_lookup, self.evals, self.zeta_mont, t_ev, curve=self.cv, ctx=self.ctx)   # :244-276
         c[4] = d.ifft(t_ev)                       # table_poly
         c[5] = d.ifft(f_ev)                       # f_poly
-        out += self._commit_round([c[5]], labels=["f"])
+        self._round_begin([c[5]], labels=["f"])                # PC::commit(f): prover.rs:289; collected with h_1 / h_2 below
         if self.lookup_round2:
             h1_ev, h2_ev = lookup.combine_split(t_ev, f_ev, self.cv, self.ctx)                                        # :295-297
         if self.ntt_batch:
@@ -232,8 +318,9 @@ class ProofSchedule:
         else:
             c[6] = d.ifft(h1_ev)                      # h1
             c[7] = d.ifft(h2_ev)                      # h2
-        out += self._commit_round([c[6]], labels=["h1"])     # two PC::commit calls of one polynomial each (prover.rs:312-317)
-        out += self._commit_round([c[7]], labels=["h2"])
+        self._round_begin([c[6]], labels=["h1"])              # two PC::commit calls of one polynomial each (prover.rs:312-317)
+        self._round_begin([c[7]], labels=["h2"])
+        out += self._round_end()                              # f, h_1, h_2 enter the transcript before beta is drawn (prover.rs:320)
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
@@ -241,11 +328,12 @@ class ProofSchedule:
             from . import permutation
             z_evals = permutation.permutation_evals(d, self.evals, sig, self.chi_mont, self.z_mont)       # beta, gamma
         c[8] = d.ifft(z_evals)                    # z
-        out += self._commit_round([c[8]], labels=["z"])
+        self._round_begin([c[8]], labels=["z"])               # prover.rs:361
         if self.grand_products:
             z2_evals = permutation.lookup_permutation_evals(self.ctx, self.cv, f_ev, t_ev, h1_ev, h2_ev, self.chi_mont, self.z_mont)  # delta, epsilon
         c[9] = d.ifft(z2_evals)                   # z2
-        out += self._commit_round([c[9]], labels=["z2"])
+        self._round_begin([c[9]], labels=["z2"])              # prover.rs:387
+        out += self._round_end()                              # z, z_2 enter the transcript before alpha is drawn (prover.rs:398)
         c[10] = d.ifft(self.aux_evals[6])         # pi
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         c[11] = d.ifft(self.aux_evals[7])         # l1
@@ -285,12 +373,11 @@ class ProofSchedule:
             out += self._commit_round(aw + [w1] + saw + [w2], canonical=[False] * 7 + [True] + [False] * 7 + [True],
                                       labels=aw_labels + ["W_z"] + saw_labels + ["W_zw"])
         else:
-            out += self._commit_round(aw, labels=aw_labels)                                  # PC::commit(aw_polys)
-            w1 = kzg_witness(aw_open, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
-            out += self._commit_round([w1], canonical=[True], labels=["W_z"])                # PC::open
-            out += self._commit_round(saw, labels=saw_labels)                                # PC::commit(saw_polys)
-            w2 = kzg_witness(saw, self.z_mont, self.chi_mont, self.cv.curve_id, self.ctx)
-            out += self._commit_round([w2], canonical=[True], labels=["W_zw"])               # PC::open
+            self._round_begin(aw, labels=aw_labels)                                          # PC::commit(aw_polys)
+            self._open_begin(aw_open, "W_z")                                                 # PC::open
+            self._round_begin(saw, labels=saw_labels)                                        # PC::commit(saw_polys)
+            self._open_begin(saw, "W_zw")                                                    # PC::open at z*omega
+            out += self._round_end()
         assert len(out) == 29
         return out
 

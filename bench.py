@@ -169,6 +169,13 @@ def self_launch(n_ranks: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def parse_table_window(v: str) -> int:
+    v = v.strip().lower()
+    if v.startswith("naf"):
+        return 0x100 | int(v[3:])
+    return int(v, 0)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +188,9 @@ def parse_args():
                     help="wire columns: uniform random, or BenchCircuit's periodic {6,7,-20,1} rows + 3 blinding rows (SURVEY.md 8d config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
-    ap.add_argument("--table-window", type=int, default=0, help="window c of the SRS table (0 = library default; 16..21), see zk_srs_precompute_ex")
+    ap.add_argument("--table-window", type=parse_table_window, default=0,
+                    help="SRS table: 0 = library default (c = 16, 16 rows); 16..21 = window c; naf17 = a row for every bit position "
+                         "(ZK_TABLE_EVERY_BIT | 17: 256 rows, 32 GiB per 2^20 points) with width-17 NAF digits; see zk_srs_precompute_ex")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
                     help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by "
@@ -207,7 +216,14 @@ def parse_args():
                     help="issue every transform as its own zk_ntt_dev call (a patched ark-poly sees one fft at a time) instead of batching the "
                          "independent adjacent ones (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts) into one launch per pass")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no in-library HIP-event scopes in the timed region (roofline fields empty)")
-    ap.add_argument("--check", action="store_true", help="print a digest of the 29 commitments (cross-rank / cross-N comparison)")
+    ap.add_argument("--no-check", dest="check", action="store_false",
+                    help="skip the digests: by default every leg re-proves proof 0 once OUTSIDE its timed region and the line reports "
+                         "whether the 29 commitments of each leg equal the headline's (commitments_match* fields)")
+    ap.add_argument("--check", dest="check", action="store_true", help="(default) see --no-check")
+    ap.set_defaults(check=True)
+    ap.add_argument("--block-every-call", action="store_true",
+                    help="the headline schedule blocks in each of its eleven PC calls (what an unchanged Prover::prove does) instead of "
+                         "collecting f|h1|h2, z|z2 and the last round's four calls once per group (zk_kzg_round_begin_dev ... zk_kzg_round_end)")
     return ap.parse_args()
 
 
@@ -268,7 +284,7 @@ def main():
         return hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in points)).hexdigest()
 
     def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps, log_n: int = args.log_n, precompute: bool = not args.no_precompute,
-                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False):
+                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False, defer_calls: bool = not args.block_every_call):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
         n_streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
         streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
@@ -288,7 +304,7 @@ def main():
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
                 kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, lookup_round2=glue, fuse_round5=args.fuse_round5,
-                          data=args.data, ntt_batch=not args.no_ntt_batch)
+                          data=args.data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
@@ -478,6 +494,12 @@ def main():
                                f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident"
                                + (", wire columns as BenchCircuit builds them (periodic {6,7,-20,1} rows + 3 blinding rows)" if args.data != "uniform" else ""),
                    "log_n": log_n, "curve": cv.name, "parallelism": par, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows",
+                   "pc_calls": ("the reference's eleven PC::commit / PC::open calls (4|1|1|1|1|1|4|7|1|7|1 polynomials), every call blocking"
+                                if args.block_every_call or args.dedup else
+                                "the reference's eleven PC::commit / PC::open calls (4|1|1|1|1|1|4|7|1|7|1 polynomials, 29 MSMs); calls whose inputs do not depend on each "
+                                "other's results (f|h1|h2, z|z2, the last round's four: prover.rs:289-317,361-389,579-618) go through zk_kzg_round_begin_dev / "
+                                "zk_kzg_open_begin_dev and are collected by one zk_kzg_round_end per group: 5 host waits per proof, identical points "
+                                "(`blocking_calls` leg: every call blocking)"),
                    "ntt_calls": "one zk_ntt_dev per transform" if args.no_ntt_batch else
                                 "adjacent independent transforms as zk_ntt_batch_dev (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts), the rest single"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -532,6 +554,15 @@ def main():
             return {"streams": r2["streams"], "steps": k2, "proofs_per_s": k2 / r2["dt"], "ms_per_proof_aggregate": r2["dt"] / k2 * 1e3,
                     "shared_srs": True, "commitments_match": (r2["digest"] == r["digest"]) if args.check else None}
         leg("concurrent_streams", streams_leg)
+    if world == 1 and S == 1 and extra and not args.block_every_call and not args.dedup:
+        def blocking_leg():
+            k2 = max(2, min(steps, 5))
+            rb = timed_region(False, 1, k2, warmup=1, defer_calls=False)
+            b_ms, b_n = rb["prof"]["msm_accumulate"]
+            return {"proofs_per_s": k2 / rb["dt"], "ms_per_proof": rb["dt"] / k2 * 1e3, "steps": k2, "accumulate_avg_launch_ms": b_ms / max(b_n, 1),
+                    "what": "the same 29 MSMs with every one of the eleven PC calls blocking (zk_kzg_round_batch_dev per call), as an unchanged Prover::prove issues them",
+                    "commitments_match": (rb["digest"] == r["digest"]) if args.check else None}
+        leg("blocking_calls", blocking_leg)
     if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
         def drop_in_leg():
             d = drop_in_region(max(2, min(steps, 3)))
@@ -658,7 +689,7 @@ def main():
                 rs = timed_region(True, log_n=lg)
                 sa_ms, sa_n = rs["prof"]["msm_accumulate"]
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
-                     "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per PC::commit / PC::open call (11 per proof)",
+                     "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per group of PC calls (5 per proof; 11 with --block-every-call)",
                      "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
                      "commitments_sha256": rs["digest"]}
                 if lg == log_n:

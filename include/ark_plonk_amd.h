@@ -60,6 +60,7 @@ typedef struct zk_srs zk_srs;
 #define ZK_ERR_UNSUPPORTED (-6)
 #define ZK_ERR_NOT_INVERTIBLE (-7) /* a grand-product denominator is zero (the reference panics: `inverse().unwrap()`) */
 #define ZK_ERR_NOT_INDEXED (-8)    /* a lookup query value is not in the table (the reference's Error::ElementNotIndexed) */
+#define ZK_ERR_PENDING (-9)        /* a deferred round (zk_kzg_round_begin_dev) is open on this ctx: close it with zk_kzg_round_end first */
 
 const char* zk_strerror(int code);
 
@@ -140,7 +141,16 @@ int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t
  * 256-bit digest over the host bytes, with no upload.  Handles are reference counted: call zk_srs_free once per
  * successful register.  An unreferenced cached SRS stays resident until zk_srs_cache_config's idle budget (default
  * 32 GiB) is exceeded, least recently used first.  zk_srs_register_dev (bases already on the device; d_inf_flags may
- * be NULL) is never cached. */
+ * be NULL) is never cached.
+ *
+ * Trust model of the content-addressed caches (this one and zk_ctx_set_commit_cache): a hit is accepted on equality of a
+ * 256-bit digest, without comparing contents.  The digests are KEYED with 256 bits drawn from the operating system once per
+ * process (the commitment cache mixes in a per-ctx value); they are never exported, so a client that chooses the cached bytes
+ * cannot search for two inputs with one digest offline.  The mixing functions are fast non-cryptographic ones (xxhash-style
+ * lanes; a sum of per-element keyed mixes on the device): a collision would return another SRS handle / another polynomial's
+ * commitment -- an invalid proof that the verifier rejects, never an unsound one.  A service that must not even produce an
+ * invalid proof for adversarial witnesses leaves the commitment cache off (the default) and registers its SRS from one
+ * trusted source. */
 int zk_srs_register(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out);
 int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const uint8_t* d_inf_flags, size_t n, zk_srs** out);
 /* Optional: build the table of window multiples 2^(c w) * P_i (w = 1..W-1) for this SRS, W x its
@@ -149,10 +159,23 @@ int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 /* Same with the table's window c chosen: 16 (default; 16 rows, 2^15 shared buckets) .. 21.  A larger window means fewer
  * rows (13 at c = 20: 13 mixed additions per scalar instead of 16, table 13 x the SRS) but 2^(c-1) buckets to reduce.
- * 0 = default.  ZK_ERR_UNSUPPORTED if the SRS already holds a table with another window. */
+ * 0 = default, or whatever table the SRS already holds.  The table belongs to the SRS, and a content-addressed
+ * zk_srs_register hands every caller that registers the same bytes the SAME handle: the first precompute wins.  A later call
+ * with window_bits = 0 (zk_srs_precompute) is a no-op; one that names a different window returns ZK_ERR_UNSUPPORTED and changes
+ * nothing -- read the window in use with zk_srs_table_info.  Results never depend on the window. */
 int zk_srs_precompute_ex(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits);
+/* window_bits = ZK_TABLE_EVERY_BIT | 17: the table holds 2^p * P_i for EVERY bit position p (scalar bits + 1 rows: 256 x the SRS,
+ * 32 GiB per 2^20 BLS12-381 points -- sized for the 288 GB of an MI355X; at most 2^23 - 1 points) instead of one row per window.
+ * A scalar is then recoded in width-17 non-adjacent form -- odd signed digits below 2^16 at arbitrary positions at least 17 bits
+ * apart -- which needs 14.7 mixed additions per 255-bit scalar on average instead of 16, into the same 2^15 shared buckets.
+ * Results are unchanged; ZK_ERR_OOM leaves the SRS as it was (fall back to zk_srs_precompute).  zk_srs_table_info reports
+ * window_bits with the flag set and windows = 16 (digit slots per scalar). */
+#define ZK_TABLE_EVERY_BIT 0x100u
 /* window_bits / windows (= rows = mixed additions per scalar) of the SRS's table; both 0 without a table. */
 int zk_srs_table_info(zk_srs* srs, uint32_t* window_bits, uint32_t* windows);
+/* One more owner of a live handle (a second zk_ctx / thread that keeps using the SRS on its own): pairs with one more
+ * zk_srs_free.  ZK_ERR_BAD_ARG for a handle whose last reference is gone. */
+int zk_srs_retain(zk_srs* srs);
 void zk_srs_free(zk_srs* srs);
 size_t zk_srs_len(const zk_srs* srs);
 /* SRS cache: bytes of unreferenced entries kept resident (0 = free on last zk_srs_free) / counters. */
@@ -218,6 +241,30 @@ int zk_kzg_commit_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, 
  * (n_jobs x 3L limbs); the opening witnesses of prover.rs:582-618 are passed as this rank's slice. */
 int zk_kzg_round_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
                                    const uint8_t* kinds, uint64_t* out_xyz);
+
+/* Deferred form of zk_kzg_round_batch_dev: a round OPENED by one or more calls and CLOSED by one.
+ * The reference issues commitments whose inputs do not depend on each other's results as separate blocking calls:
+ * f | h_1 | h_2 (prover.rs:289-317: no challenge is drawn between them), z | z_2 (prover.rs:361-389: delta and epsilon are
+ * drawn before z is committed), and the four calls of the last round (prover.rs:579-618: both opening challenges are drawn
+ * with no transcript append in between).  Every blocking call pays the latency of the bucket reduction's dependent-addition
+ * chains and a host round trip while the GPU idles.  zk_kzg_round_begin_dev queues sort + bucket accumulation of its jobs on
+ * the ctx stream and returns; other work (the next polynomial's NTT) and further begins may follow; zk_kzg_round_end reduces
+ * every queued job with ONE launch per reduction kernel, waits once, and returns all results in submission order (n_jobs must
+ * equal the number of jobs begun, else ZK_ERR_BAD_ARG and the round stays open).  Results are identical to the blocking
+ * calls.  At most 16 jobs per round, one SRS per round; the caller keeps the inputs and the SRS alive until the round ends.
+ * While a round is open the blocking MSM / commit / open entry points of the same ctx return ZK_ERR_PENDING (NTTs and the
+ * other device builders may run).  Jobs that do not take the window-table path (no table, fewer than 2^13 elements) and,
+ * with the commitment cache on, all jobs are computed at begin.  zk_kzg_open_begin_dev is zk_kzg_open_dev as a job of the
+ * round (witness polynomial built at once, its MSM deferred).  zk_kzg_round_end_partial returns Jacobian partials (n_jobs x
+ * 3L limbs) for a sharded SRS; zk_kzg_round_abort drops an open round (waits for the queued kernels). */
+int zk_kzg_round_begin_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
+                           const uint8_t* kinds);
+int zk_kzg_open_begin_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
+                          const uint64_t* z_mont, const uint64_t* challenge_mont);
+int zk_kzg_round_end(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
+int zk_kzg_round_end_partial(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xyz);
+int zk_kzg_round_pending(zk_ctx* ctx, uint32_t* n_jobs);
+int zk_kzg_round_abort(zk_ctx* ctx);
 
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).

@@ -1,0 +1,161 @@
+"""Deferred commitment rounds (zk_kzg_round_begin_dev / zk_kzg_open_begin_dev ... zk_kzg_round_end): the reference issues
+f | h_1 | h_2 (prover.rs:289-317), z | z_2 (prover.rs:361-389) and the four calls of its last round (prover.rs:579-618) as
+separate blocking PC calls although no result of one feeds the next; the deferred form queues them and collects once.
+Results must equal the blocking calls bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import ark_plonk_amd as zk
+from ark_plonk_amd import _lib
+from ark_plonk_amd.prover_schedule import ProofSchedule
+
+pytestmark = pytest.mark.gpu
+
+
+def _ck(ctx, cv, n, seed=5):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cv.curve_id, ks.data_ptr(), n, bases.data_ptr()))
+    return zk.CommitterKey(bases, cv, ctx)
+
+
+def _polys(n, k, seed):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return [torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g) for _ in range(k)]
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_deferred_round_equals_blocking_calls(ctx, cid):
+    """Commits of different lengths (table path, per-window path, empty), an opening and a canonical-scalar job, begun by five
+    calls and collected by one: the points of the blocking entry points, in submission order."""
+    cv = zk.get_curve(cid)
+    n = 1 << 14
+    ck = _ck(ctx, cv, n).precompute()
+    p = _polys(n, 6, 11)
+    z = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
+    chi = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
+    short = p[3][:1000]                    # below the table threshold: computed at begin, in its own buffer set
+    odd = p[4][: n - 3]                    # odd length: the separate into_repr pass of the sort
+    empty = p[5][:0]
+    w = zk.msm.kzg_witness([p[0], p[1]], z, chi, cid, ctx)
+    exp = ck.commit_batch([p[0], p[1]]) + [ck.commit(short)] + [ck.commit(odd)] + [ck.commit(empty)]
+    exp += [ck.open([p[2], p[0], odd], z, chi)] + ck.commit_batch([w], canonical=[True])
+    assert ck.round_pending() == 0
+    assert ck.commit_begin([p[0], p[1]]) == 2
+    assert ck.commit_begin([short]) == 3
+    assert ck.commit_begin([odd, empty]) == 5
+    assert ck.open_begin([p[2], p[0], odd], z, chi) == 6
+    assert ck.commit_begin([w], canonical=[True]) == 7
+    got = ck.round_end()
+    assert ck.round_pending() == 0
+    assert len(got) == len(exp) == 7
+    for k, (a, b) in enumerate(zip(got, exp)):
+        assert a == b, k
+    # a second round on the same buffers, other inputs: nothing of the first round survives
+    q = _polys(n, 3, 12)
+    exp2 = ck.commit_batch(q)
+    ck.commit_begin(q[:1])
+    ck.commit_begin(q[1:])
+    assert ck.round_end(3) == exp2
+    ck.close()
+
+
+def test_deferred_round_interleaved_with_transforms_and_sixteen_jobs(ctx):
+    """The shape of the prover's last round: 7 commits, an opening, 7 commits, an opening -- sixteen jobs, the most a round holds --
+    with NTTs queued between the calls (they share the stream, not the MSM buffers)."""
+    cv = zk.get_curve(0)
+    log_n = 13
+    n = 1 << log_n
+    ck = _ck(ctx, cv, n).precompute()
+    dom = zk.Radix2EvaluationDomain.new(n, 0, ctx)
+    ev = _polys(n, 14, 21)
+    z = np.array([5, 6, 7, 8], dtype=np.uint64)
+    chi = np.array([9, 10, 11, 12], dtype=np.uint64)
+    co = [dom.ifft(e) for e in ev]
+    exp = ck.commit_batch(co[:7]) + [ck.open(co[:7] + co[10:14], z, chi)] + ck.commit_batch(co[7:14]) + [ck.open(co[7:14], z, chi)]
+    ck.commit_begin([dom.ifft(e) for e in ev[:7]])
+    ck.open_begin(co[:7] + co[10:14], z, chi)
+    late = [dom.ifft(e) for e in ev[7:14]]          # transforms queued while the round is open
+    ck.commit_begin(late)
+    assert ck.open_begin(late, z, chi) == 16
+    with pytest.raises(_lib.ZkError) as e:           # a seventeenth job does not fit
+        ck.commit_begin(co[:1])
+    assert e.value.code == _lib.ZK_ERR_UNSUPPORTED
+    assert ck.round_end() == exp
+    ck.close()
+
+
+def test_open_round_blocks_the_blocking_entry_points_and_survives_a_wrong_count(ctx):
+    cv = zk.get_curve(0)
+    n = 1 << 13
+    ck = _ck(ctx, cv, n).precompute()
+    p = _polys(n, 2, 31)
+    exp = ck.commit_batch(p)
+    ck.commit_begin(p[:1])
+    for call in (lambda: ck.commit(p[1]), lambda: ck.commit_batch(p), lambda: ck.msm(p[1]),
+                 lambda: ck.open(p, np.ones(4, dtype=np.uint64), np.ones(4, dtype=np.uint64)),
+                 lambda: ctx.set_commit_cache(True)):
+        with pytest.raises(_lib.ZkError) as e:
+            call()
+        assert e.value.code == _lib.ZK_ERR_PENDING
+    ck.commit_begin(p[1:])
+    with pytest.raises(_lib.ZkError) as e:           # wrong job count: refused, the round stays open
+        ck.round_end(3)
+    assert e.value.code == _lib.ZK_ERR_BAD_ARG and ck.round_pending() == 2
+    assert ck.round_end(2) == exp
+    # abort: the round is dropped, the ctx usable again
+    ck.commit_begin(p)
+    ck.round_abort()
+    assert ck.round_pending() == 0 and ck.commit_batch(p) == exp
+    # an empty round closes with no outputs
+    assert ck.round_end(0) == []
+    ck.close()
+
+
+def test_deferred_round_with_the_commitment_cache_and_partials(ctx):
+    """With the ABI's commitment cache on every job is answered at begin (hits cost no MSM); the sharded form returns Jacobian
+    partials that sum to the same points."""
+    cv = zk.get_curve(0)
+    n = 1 << 13
+    ck = _ck(ctx, cv, n).precompute()
+    p = _polys(n, 3, 41)
+    exp = ck.commit_batch(p)
+    ctx.set_commit_cache(True)
+    try:
+        ck.commit_begin(p[:2])
+        ck.commit_begin([p[2], p[0]])
+        got = ck.round_end()
+        assert got == exp + exp[:1]
+        st = ctx.commit_cache_stats()
+        assert st["hits"] >= 1
+    finally:
+        ctx.set_commit_cache(False)
+    ck.commit_begin(p[:1])
+    ck.commit_begin(p[1:])
+    parts = ck.round_end_partial(3)
+    assert parts.shape == (3, 3 * cv.fq_limbs)
+    for k in range(3):
+        assert zk.msm.sum_partials(parts[k:k + 1], 0) == exp[k]
+    ck.close()
+
+
+@pytest.mark.parametrize("log_n", [10, 13])
+def test_schedule_deferred_equals_blocking(ctx, log_n):
+    """The per-proof schedule with its eleven calls collected in five groups (default) against every call blocking."""
+    cv = zk.get_curve("bls12_381")
+    ck = _ck(ctx, cv, 1 << log_n, seed=3).precompute()
+    a = ProofSchedule(log_n, ctx, ck, cv, defer_calls=False)
+    b = ProofSchedule(log_n, ctx, ck, cv)
+    assert b.defer_calls
+    pa, pb = a.run_once(proof_id=0), b.run_once(proof_id=0)
+    assert a.msms_run == b.msms_run == 29
+    assert pa == pb
+    assert b.run_once(proof_id=1) == a.run_once(proof_id=1)
+    ck.close()

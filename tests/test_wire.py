@@ -140,6 +140,12 @@ def test_g1_deserialize_rejects_invalid(cid):
     g[-1] |= 0xC0
     with pytest.raises(_lib.ZkError):
         tr.g1_deserialize(bytes(g), cid)
+    # ... in the uncompressed form as well (SWFlags::from_u8 returns None for it; the flags sit on y's last byte)
+    gu = bytearray(tr.g1_serialize(point(cv, (cv.gx, cv.gy)), cid, compressed=False))
+    assert tr.g1_deserialize(bytes(gu), cid, compressed=False) == point(cv, (cv.gx, cv.gy))
+    gu[-1] |= 0xC0
+    with pytest.raises(_lib.ZkError):
+        tr.g1_deserialize(bytes(gu), cid, compressed=False)
     with pytest.raises(_lib.ZkError):
         tr.g1_deserialize(cv.q.to_bytes(n, "little"), cid)
     if cid == 0:
@@ -153,6 +159,27 @@ def test_g1_deserialize_rejects_invalid(cid):
             x += 1
         with pytest.raises(_lib.ZkError):
             tr.g1_deserialize(wo.ser_g1(cv, (x, y)), cid)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_zero_public_inputs_are_not_part_of_the_message(cid):
+    """`PublicInputs::insert` (pi.rs:56-65) drops zero values, so the reference's BTreeMap -- the prover's and the one the verifier
+    rebuilds -- never holds one: a caller's explicit zero must hash like an absent position."""
+    cv = bo.CURVES[cid]
+    with_zero = {2: 0, 5: 77, 9: cv.r - 1, 11: 0}
+    without = {5: 77, 9: cv.r - 1}
+    assert wo.ser_public_inputs(cv, with_zero) == wo.ser_public_inputs(cv, without)
+    outs = []
+    for pi in (with_zero, without):
+        t = tr.Transcript(b"pi-test", cid)
+        t.append_public_inputs("pi", {k: fr_limbs(cv, v) for k, v in pi.items()})
+        outs.append(t.challenge_scalar("c").tobytes())
+    ref = wo.PlonkTranscript(b"pi-test", cv)
+    ref.append_message(b"pi", wo.ser_public_inputs(cv, with_zero))
+    assert outs[0] == outs[1]
+    assert outs[0] == fr_limbs(cv, ref.challenge_scalar(b"c")).tobytes()
+    # all-zero map: count 0, nothing else
+    assert wo.ser_public_inputs(cv, {4: 0}) == (0).to_bytes(8, "little")
 
 
 def _replay(cv, w):

@@ -869,13 +869,25 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
     }
 }
 
+// References per lane actually used.  The launch is sized for nf = L0 * n_lanes references, but the sorted list holds E <= nf (zero
+// digits and, on the every-bit table, the empty NAF slots are not in it).  Cutting the E references into n_lanes equal chunks keeps
+// every lane of the launch busy -- with fixed chunks of L0 a list 8 % shorter leaves the last round of resident wavefronts 16 %
+// empty and takes exactly as long.  msm_accumulate and the msm_combine* kernels derive the same value from the same inputs.
+ZK_D uint32_t chunk_len(uint32_t E, uint32_t n_lanes, uint32_t L0) {
+    const uint32_t need = (uint32_t)(((uint64_t)E + n_lanes - 1) / n_lanes);
+    const uint32_t lo = L0 < 16u ? L0 : 16u;       // never below 16 (or L0): shorter chunks only multiply the chunk-edge partials
+    return need < lo ? lo : need;
+}
+
 // Every lane sums entries [t*L, (t+1)*L) of the bucket-sorted reference list.
 // PRE: references carry a window number and `bases` is the window-multiples table [W][n_srs]
 // (row w holds 2^(c w) P_i); tab_stride = n_srs, tab_off = base_offset.
 template <class F, bool PRE>
 ZK_D void accumulate_chunk(const uint32_t t, const uint32_t* entries, const uint32_t* offsets, uint32_t nb, const void* bases, void* buckets,
-                           void* part_pt, uint32_t L, uint64_t tab_stride, uint64_t tab_off, uint32_t row_shift, uint32_t row_mask) {
+                           void* part_pt, uint32_t L0, uint32_t n_lanes, uint64_t tab_stride, uint64_t tab_off, uint32_t row_shift,
+                           uint32_t row_mask) {
     const uint32_t E = offsets[nb];
+    const uint32_t L = chunk_len(E, n_lanes, L0);
     const uint64_t e0 = (uint64_t)t * L;
     if (e0 >= E) return;
     const uint32_t e1 = (uint32_t)min((uint64_t)E, e0 + L);
@@ -937,7 +949,7 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
                                                        uint64_t tab_off, uint32_t row_shift, uint32_t row_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
-    accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, tab_stride, tab_off, row_shift, row_mask);
+    accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, n_lanes, tab_stride, tab_off, row_shift, row_mask);
 }
 
 // The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by
@@ -953,7 +965,9 @@ struct RJobs {
     void* seg_acc[MAX_RJOBS];
     uint32_t* win_s[MAX_RJOBS];
     uint32_t* win_t[MAX_RJOBS];
-    uint32_t L[MAX_RJOBS];
+    uint32_t L[MAX_RJOBS];          // references per lane the accumulate launch was sized for ...
+    uint32_t lanes[MAX_RJOBS];      // ... its lanes, and the bucket count (offsets[nbk] = references in the list): see chunk_len
+    uint32_t nbk[MAX_RJOBS];
 };
 
 constexpr uint32_t COMBINE_SMALL = 32;     // buckets spanning <= this many chunks: summed by one lane
@@ -993,7 +1007,7 @@ __global__ void __launch_bounds__(128) msm_combine(RJobs jobs, uint32_t nb) {
     const uint32_t* offsets = jobs.offsets[blockIdx.y];
     void* buckets = jobs.buckets[blockIdx.y];
     uint32_t* q = jobs.q[blockIdx.y];
-    const uint32_t L = jobs.L[blockIdx.y];
+    const uint32_t L = chunk_len(offsets[jobs.nbk[blockIdx.y]], jobs.lanes[blockIdx.y], jobs.L[blockIdx.y]);
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = id / COMBINE_SG, sub = id % COMBINE_SG;
     // every lane stays to the end: the sub-group sums below are wave shuffles
@@ -1038,7 +1052,7 @@ __global__ void __launch_bounds__(256) msm_combine_wave(RJobs jobs) {
     const uint32_t* offsets = jobs.offsets[blockIdx.y];
     void* buckets = jobs.buckets[blockIdx.y];
     const uint32_t* q = jobs.q[blockIdx.y];
-    const uint32_t L = jobs.L[blockIdx.y];
+    const uint32_t L = chunk_len(offsets[jobs.nbk[blockIdx.y]], jobs.lanes[blockIdx.y], jobs.L[blockIdx.y]);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -1062,7 +1076,7 @@ __global__ void __launch_bounds__(256) msm_combine_block(RJobs jobs, uint32_t nb
     const uint32_t* offsets = jobs.offsets[blockIdx.y];
     void* buckets = jobs.buckets[blockIdx.y];
     const uint32_t* q = jobs.q[blockIdx.y];
-    const uint32_t L = jobs.L[blockIdx.y];
+    const uint32_t L = chunk_len(offsets[jobs.nbk[blockIdx.y]], jobs.lanes[blockIdx.y], jobs.L[blockIdx.y]);
     const uint32_t u = threadIdx.x;
     const uint32_t nl = q[1];
     for (uint32_t h = blockIdx.x; h < nl; h += gridDim.x) {
@@ -1195,7 +1209,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const uint32_t* offsets = jobs.offsets[blockIdx.y];
     void* buckets = jobs.buckets[blockIdx.y];
     uint32_t* q = jobs.q[blockIdx.y];
-    const uint32_t L = jobs.L[blockIdx.y];
+    const uint32_t L = chunk_len(offsets[jobs.nbk[blockIdx.y]], jobs.lanes[blockIdx.y], jobs.L[blockIdx.y]);
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = id >> 2, role = id & 3;
     uint32_t s = 0, ta = 0, np = 0;     // np = partials this quad sums itself (0: nothing to do)
@@ -1715,6 +1729,8 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
         jobs.win_s[0] = (uint32_t*)mb.win.p;
         jobs.win_t[0] = nullptr;
         jobs.L[0] = CHUNK_L;
+        jobs.lanes[0] = n_lanes;
+        jobs.nbk[0] = g.nb;
         if ((rc = queue_reduce<F>(c, jobs, 1, g.nb, g, st))) return rc;
     }
     // window sums -> host, Horner (high window first), Jacobian out
@@ -2142,6 +2158,8 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
         jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
         jobs.L[k] = pls[k].chunk_l;
+        jobs.lanes[k] = pls[k].n_lanes;
+        jobs.nbk[k] = p0.g1.nb;
     }
     // the queue counters were cleared by the job's sort (psort_hist / the memset of the fallback sort)
     if (p0.wide) {

@@ -1,0 +1,289 @@
+//! `GpuKZG10`: SonicKZG10 with `commit` / `open` on the GPU.
+//!
+//! Reference call sites this type has to satisfy unchanged:
+//! * `PC::trim(u_params, circuit_size, 0, None)`            -- circuit.rs:236,276 (on EVERY `gen_proof`)
+//! * `PC::commit(commit_key, polys.iter(), None)`            -- prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,606
+//! * `PC::open(commit_key, polys, comms, &point, challenge, rands, None)` -- prover.rs:582-591,609-618
+//! * `PC::check(..)` / `PC::batch_check(..)`                 -- proof.rs (verifier; stays on the CPU)
+//! * `HomomorphicCommitment::multi_scalar_mul(&comms, &scalars)` -- commitment.rs:33-48; proof.rs:317-325,602
+//!
+//! The prover passes no degree bounds, no hiding bounds and `rng = None` (prover.rs: every `label_polynomial!` is
+//! `LabeledPolynomial::new(label, poly, None, None)`, util.rs:175-184); any call that does is forwarded to SonicKZG10 as is.
+
+use crate::{check, ctx, fr_ptr, pack_affine, unpack_affine, GpuError, CURVE, FQ_LIMBS};
+use ark_bls12_381::{Bls12_381, Fr, G1Affine};
+use ark_ec::msm::VariableBaseMSM;
+use ark_ff::PrimeField;
+use ark_poly::univariate::DensePolynomial;
+use ark_poly_commit::{
+    kzg10, sonic_pc, sonic_pc::SonicKZG10, LabeledCommitment, LabeledPolynomial, PCCommitterKey, PCRandomness, PolynomialCommitment,
+};
+use plonk_core::commitment::HomomorphicCommitment;
+use plonk_gpu_sys as sys;
+use rand_core::RngCore;
+use std::sync::Arc;
+
+type Poly = DensePolynomial<Fr>;
+type Sonic = SonicKZG10<Bls12_381, Poly>;
+
+/// The device-resident copy of `powers_of_g` (+ its window table); freed with the last clone of the key.
+#[derive(Debug)]
+pub struct SrsHandle(*mut sys::ZkSrs);
+// a zk_srs belongs to the device, not to a thread (include/ark_plonk_amd.h)
+unsafe impl Send for SrsHandle {}
+unsafe impl Sync for SrsHandle {}
+
+impl Drop for SrsHandle {
+    fn drop(&mut self) {
+        if !self.0.is_null() {
+            unsafe { sys::zk_srs_free(self.0) }; // a reference count: a cached SRS stays resident for the next trim
+        }
+    }
+}
+
+/// SonicKZG10's committer key plus the handle of its GPU copy (`None`: no device -- every call takes the CPU path).
+#[derive(Clone, Debug)]
+pub struct GpuCommitterKey {
+    pub inner: sonic_pc::CommitterKey<Bls12_381>,
+    pub srs: Option<Arc<SrsHandle>>,
+}
+
+impl PCCommitterKey for GpuCommitterKey {
+    fn max_degree(&self) -> usize {
+        self.inner.max_degree()
+    }
+    fn supported_degree(&self) -> usize {
+        self.inner.supported_degree()
+    }
+}
+
+/// Same key / commitment / proof types as `SonicKZG10<Bls12_381, DensePolynomial<Fr>>`; only `trim`, `commit` and `open` differ.
+pub struct GpuKZG10;
+
+impl GpuKZG10 {
+    /// Park `powers_of_g` on the device.  circuit.rs:276 trims on every `gen_proof`: `zk_srs_register` is content-addressed,
+    /// so the second call with the same bytes is one keyed digest pass over them (0.7 ms for 2^20 points) and returns the
+    /// resident handle with its window table.
+    fn register(powers: &[G1Affine]) -> Option<Arc<SrsHandle>> {
+        let c = ctx();
+        if c.is_null() || powers.is_empty() {
+            return None;
+        }
+        let (xy, inf) = pack_affine(powers);
+        let mut srs: *mut sys::ZkSrs = core::ptr::null_mut();
+        let rc = unsafe { sys::zk_srs_register(c, CURVE, xy.as_ptr(), inf.as_ptr(), powers.len(), &mut srs) };
+        if check(rc).is_err() {
+            return None;
+        }
+        let handle = Arc::new(SrsHandle(srs));
+        // the window table: 16 rows by default; ARK_PLONK_AMD_TABLE=every-bit asks for the every-bit-position table
+        // (256 x the SRS in HBM, ~8 % fewer additions per MSM); on ZK_ERR_OOM the default table is built instead
+        let every_bit = std::env::var("ARK_PLONK_AMD_TABLE").map(|v| v == "every-bit").unwrap_or(false);
+        let mut rc = sys::ZK_ERR_UNSUPPORTED;
+        if every_bit {
+            rc = unsafe { sys::zk_srs_precompute_ex(c, srs, sys::ZK_TABLE_EVERY_BIT | 17) };
+        }
+        if rc != sys::ZK_OK {
+            rc = unsafe { sys::zk_srs_precompute(c, srs) };
+        }
+        if check(rc).is_err() {
+            return None; // no table: MSMs would still work, but the key then simply takes the CPU path
+        }
+        Some(handle)
+    }
+
+    fn gpu_commit(srs: &SrsHandle, polys: &[&LabeledPolynomial<Fr, Poly>]) -> Result<Vec<G1Affine>, GpuError> {
+        // the whole slice of one PC::commit call goes down in one piece: polynomial k+1 is uploaded while polynomial k's MSM
+        // runs, and the bucket reductions of the call are one launch per kernel.  Coefficients are passed as the Montgomery
+        // limbs they are stored as; `into_repr` happens on the device.
+        let ptrs: Vec<*const u64> = polys.iter().map(|p| fr_ptr(p.polynomial().coeffs())).collect();
+        let lens: Vec<usize> = polys.iter().map(|p| p.polynomial().coeffs().len()).collect();
+        let mut xy = vec![0u64; 2 * FQ_LIMBS * polys.len()];
+        let mut inf = vec![0u8; polys.len()];
+        let rc = unsafe {
+            sys::zk_kzg_commit_batch(ctx(), srs.0, polys.len() as u32, ptrs.as_ptr(), lens.as_ptr(), xy.as_mut_ptr(), inf.as_mut_ptr())
+        };
+        check(rc)?;
+        Ok((0..polys.len()).map(|k| unpack_affine(&xy[2 * FQ_LIMBS * k..2 * FQ_LIMBS * (k + 1)], inf[k])).collect())
+    }
+
+    fn gpu_open(srs: &SrsHandle, polys: &[&LabeledPolynomial<Fr, Poly>], point: &Fr, challenge: &Fr) -> Result<G1Affine, GpuError> {
+        // p = sum_k challenge^k p_k, witness = (p - p(point)) / (X - point), commit(witness): RLC, division and MSM on the device
+        let ptrs: Vec<*const u64> = polys.iter().map(|p| fr_ptr(p.polynomial().coeffs())).collect();
+        let lens: Vec<usize> = polys.iter().map(|p| p.polynomial().coeffs().len()).collect();
+        let mut xy = [0u64; 2 * FQ_LIMBS];
+        let mut inf = 0u8;
+        let rc = unsafe {
+            sys::zk_kzg_open(
+                ctx(),
+                srs.0,
+                polys.len() as u32,
+                ptrs.as_ptr(),
+                lens.as_ptr(),
+                fr_ptr(core::slice::from_ref(point)),
+                fr_ptr(core::slice::from_ref(challenge)),
+                xy.as_mut_ptr(),
+                &mut inf,
+            )
+        };
+        check(rc)?;
+        Ok(unpack_affine(&xy, inf))
+    }
+
+    /// The prover's shape: no degree bound, no hiding bound, at most 16 polynomials, everything within the registered SRS.
+    fn plain(ck: &GpuCommitterKey, polys: &[&LabeledPolynomial<Fr, Poly>]) -> bool {
+        polys.len() <= 16
+            && polys.iter().all(|p| {
+                p.degree_bound().is_none() && p.hiding_bound().is_none() && p.polynomial().coeffs().len() <= ck.inner.powers_of_g.len()
+            })
+    }
+}
+
+impl PolynomialCommitment<Fr, Poly> for GpuKZG10 {
+    type UniversalParams = <Sonic as PolynomialCommitment<Fr, Poly>>::UniversalParams;
+    type CommitterKey = GpuCommitterKey;
+    type VerifierKey = <Sonic as PolynomialCommitment<Fr, Poly>>::VerifierKey;
+    type PreparedVerifierKey = <Sonic as PolynomialCommitment<Fr, Poly>>::PreparedVerifierKey;
+    type Commitment = <Sonic as PolynomialCommitment<Fr, Poly>>::Commitment;
+    type PreparedCommitment = <Sonic as PolynomialCommitment<Fr, Poly>>::PreparedCommitment;
+    type Randomness = <Sonic as PolynomialCommitment<Fr, Poly>>::Randomness;
+    type Proof = <Sonic as PolynomialCommitment<Fr, Poly>>::Proof;
+    type BatchProof = <Sonic as PolynomialCommitment<Fr, Poly>>::BatchProof;
+    type Error = <Sonic as PolynomialCommitment<Fr, Poly>>::Error;
+
+    fn setup<R: RngCore>(max_degree: usize, num_vars: Option<usize>, rng: &mut R) -> Result<Self::UniversalParams, Self::Error> {
+        Sonic::setup(max_degree, num_vars, rng)
+    }
+
+    fn trim(
+        pp: &Self::UniversalParams,
+        supported_degree: usize,
+        supported_hiding_bound: usize,
+        enforced_degree_bounds: Option<&[usize]>,
+    ) -> Result<(Self::CommitterKey, Self::VerifierKey), Self::Error> {
+        let (inner, vk) = Sonic::trim(pp, supported_degree, supported_hiding_bound, enforced_degree_bounds)?;
+        let srs = Self::register(&inner.powers_of_g);
+        Ok((GpuCommitterKey { inner, srs }, vk))
+    }
+
+    fn commit<'a>(
+        ck: &Self::CommitterKey,
+        polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<Fr, Poly>>,
+        rng: Option<&mut dyn RngCore>,
+    ) -> Result<(Vec<LabeledCommitment<Self::Commitment>>, Vec<Self::Randomness>), Self::Error>
+    where
+        Poly: 'a,
+    {
+        let polys: Vec<&LabeledPolynomial<Fr, Poly>> = polynomials.into_iter().collect();
+        if let Some(srs) = ck.srs.as_ref() {
+            if Self::plain(ck, &polys) {
+                if let Ok(points) = Self::gpu_commit(srs, &polys) {
+                    let comms = polys
+                        .iter()
+                        .zip(points)
+                        .map(|(p, g)| LabeledCommitment::new(p.label().clone(), kzg10::Commitment(g), None))
+                        .collect();
+                    return Ok((comms, vec![Self::Randomness::empty(); polys.len()]));
+                }
+            }
+        }
+        // anything else (bounds, hiding, no device, a failed call): SonicKZG10's CPU path, never a wrong answer
+        Sonic::commit(&ck.inner, polys.into_iter(), rng)
+    }
+
+    fn open<'a>(
+        ck: &Self::CommitterKey,
+        labeled_polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<Fr, Poly>>,
+        commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+        point: &'a Fr,
+        opening_challenge: Fr,
+        rands: impl IntoIterator<Item = &'a Self::Randomness>,
+        rng: Option<&mut dyn RngCore>,
+    ) -> Result<Self::Proof, Self::Error>
+    where
+        Self::Randomness: 'a,
+        Self::Commitment: 'a,
+        Poly: 'a,
+    {
+        let polys: Vec<&LabeledPolynomial<Fr, Poly>> = labeled_polynomials.into_iter().collect();
+        if let Some(srs) = ck.srs.as_ref() {
+            if Self::plain(ck, &polys) {
+                if let Ok(w) = Self::gpu_open(srs, &polys, point, &opening_challenge) {
+                    return Ok(kzg10::Proof { w, random_v: None });
+                }
+            }
+        }
+        Sonic::open(&ck.inner, polys.into_iter(), commitments, point, opening_challenge, rands, rng)
+    }
+
+    fn open_individual_opening_challenges<'a>(
+        ck: &Self::CommitterKey,
+        labeled_polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<Fr, Poly>>,
+        commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+        point: &'a Fr,
+        opening_challenges: &dyn Fn(u64) -> Fr,
+        rands: impl IntoIterator<Item = &'a Self::Randomness>,
+        rng: Option<&mut dyn RngCore>,
+    ) -> Result<Self::Proof, Self::Error>
+    where
+        Self::Randomness: 'a,
+        Self::Commitment: 'a,
+        Poly: 'a,
+    {
+        // arbitrary per-polynomial challenges are not powers of one value: the device entry point takes the latter only
+        Sonic::open_individual_opening_challenges(&ck.inner, labeled_polynomials, commitments, point, opening_challenges, rands, rng)
+    }
+
+    fn check<'a>(
+        vk: &Self::VerifierKey,
+        commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+        point: &'a Fr,
+        values: impl IntoIterator<Item = Fr>,
+        proof: &Self::Proof,
+        opening_challenge: Fr,
+        rng: Option<&mut dyn RngCore>,
+    ) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        Sonic::check(vk, commitments, point, values, proof, opening_challenge, rng) // pairings stay on the CPU
+    }
+
+    fn check_individual_opening_challenges<'a>(
+        vk: &Self::VerifierKey,
+        commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+        point: &'a Fr,
+        values: impl IntoIterator<Item = Fr>,
+        proof: &Self::Proof,
+        opening_challenges: &dyn Fn(u64) -> Fr,
+        rng: Option<&mut dyn RngCore>,
+    ) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        Sonic::check_individual_opening_challenges(vk, commitments, point, values, proof, opening_challenges, rng)
+    }
+}
+
+impl HomomorphicCommitment<Fr> for GpuKZG10 {
+    /// commitment.rs:33-48: `into_repr` on the scalars, then one `VariableBaseMSM::multi_scalar_mul` over the commitments'
+    /// points.  The verifier's sizes (4 and 19 points, proof.rs:317-325,602) are microseconds on the CPU and stay there; a
+    /// caller with thousands of commitments gets `zk_msm_g1`.
+    fn multi_scalar_mul(commitments: &[Self::Commitment], scalars: &[Fr]) -> Self::Commitment {
+        let points: Vec<G1Affine> = commitments.iter().map(|c| c.0).collect();
+        let n = core::cmp::min(points.len(), scalars.len());
+        let c = ctx();
+        if n >= 4096 && !c.is_null() {
+            let (xy, inf) = pack_affine(&points[..n]);
+            let repr: Vec<u64> = scalars[..n].iter().flat_map(|s| s.into_repr().0).collect(); // canonical limbs
+            let mut out = [0u64; 2 * FQ_LIMBS];
+            let mut out_inf = 0u8;
+            let rc = unsafe { sys::zk_msm_g1(c, CURVE, xy.as_ptr(), inf.as_ptr(), repr.as_ptr(), n, out.as_mut_ptr(), &mut out_inf) };
+            if rc == sys::ZK_OK {
+                return kzg10::Commitment(unpack_affine(&out, out_inf));
+            }
+        }
+        let repr: Vec<_> = scalars.iter().map(|s| s.into_repr()).collect();
+        kzg10::Commitment(VariableBaseMSM::multi_scalar_mul(&points, &repr).into())
+    }
+}

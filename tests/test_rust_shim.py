@@ -1,0 +1,135 @@
+"""rust-shim/ cannot be compiled in this pipeline (no cargo / rustc).  What can be checked on the CPU: the `extern "C"` block of
+plonk-gpu-sys says what include/ark_plonk_amd.h says (name, arity, pointer / integer widths of every parameter and of the
+return value), it is the generator's current output, every library symbol is exported, and every `sys::zk_*` call of the
+hand-written crate exists with the right number of arguments.  Reference interface mirrored: plonk-core/src/commitment.rs:8-49,
+proof_system/prover.rs:32-37, circuit.rs:264-287."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ark_plonk_amd.h")
+SYS_RS = os.path.join(ROOT, "rust-shim", "plonk-gpu-sys", "src", "lib.rs")
+SHIM_SRC = os.path.join(ROOT, "rust-shim", "plonk-gpu", "src")
+
+
+def _c_class(ctype: str) -> str:
+    """width class of a C parameter type, derived independently of tools/gen_rust_ffi.py"""
+    t = ctype.replace("const", " ").replace("[4]", "*").replace("[]", "*")
+    depth = t.count("*")
+    base = t.replace("*", " ").split()[0]
+    widths = {"int": "i32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "char": "i8",
+              "void": "void"}
+    b = widths.get(base, "struct:" + base)
+    return "ptr" * 0 + ("p" * depth + ":" + b if depth else b)
+
+
+def _rust_class(rtype: str) -> str:
+    depth = len(re.findall(r"\*(?:const|mut)", rtype))
+    base = re.sub(r"\*(?:const|mut)\s*", "", rtype).strip()
+    names = {"c_char": "i8", "c_void": "void", "ZkCtx": "struct:zk_ctx", "ZkSrs": "struct:zk_srs", "ZkTranscript": "struct:zk_transcript",
+             "ZkDomainInfo": "struct:zk_domain_info", "ZkQuotientArgs": "struct:zk_quotient_args", "ZkProof": "struct:zk_proof"}
+    b = names.get(base, base)
+    return "p" * depth + ":" + b if depth else b
+
+
+def _split_top(s: str):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{<":
+            depth += 1
+        elif ch in ")]}>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out]
+
+
+def c_prototypes():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\n((?:const\s+)?(?:int|void|size_t|char|zk_transcript)\s*\*?\s*)(zk_\w+)\s*\(([^;{]*)\)\s*;", text):
+        ret = " ".join(m.group(1).split())
+        params = []
+        for a in _split_top(" ".join(m.group(3).split())):
+            if not a or a == "void":
+                continue
+            mm = re.match(r"(.*?)(\w+)\s*(\[\d*\])?$", a)
+            params.append(_c_class(mm.group(1) + (mm.group(3) or "")))
+        protos[m.group(2)] = (None if ret == "void" else _c_class(ret), params)
+    return protos
+
+
+def rust_externs():
+    text = open(SYS_RS).read()
+    block = text[text.index('extern "C" {'):]
+    fns = {}
+    for m in re.finditer(r"pub fn (zk_\w+)\((.*?)\)(?:\s*->\s*([^;]+))?;", block):
+        params = [_rust_class(p.split(":", 1)[1]) for p in _split_top(m.group(2)) if p]
+        fns[m.group(1)] = (None if m.group(3) is None else _rust_class(m.group(3)), params)
+    return fns
+
+
+def test_generated_ffi_is_current():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--stdout"], capture_output=True, text=True, check=True)
+    assert out.stdout == open(SYS_RS).read(), "rust-shim/plonk-gpu-sys/src/lib.rs is stale: run python tools/gen_rust_ffi.py"
+
+
+def test_every_extern_matches_its_c_prototype():
+    c, r = c_prototypes(), rust_externs()
+    assert len(c) >= 90
+    assert set(c) == set(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name in sorted(c):
+        assert c[name][0] == r[name][0], (name, "return", c[name][0], r[name][0])
+        assert len(c[name][1]) == len(r[name][1]), (name, "arity")
+        for k, (a, b) in enumerate(zip(c[name][1], r[name][1])):
+            assert a == b, (name, k, a, b)
+
+
+def test_the_binding_table_of_the_python_mirror_agrees_too():
+    """ark_plonk_amd/_lib.py binds the same header by hand (ctypes): same names, same arity."""
+    from ark_plonk_amd import _lib
+    c = c_prototypes()
+    assert set(_lib.SYMBOLS) == set(c), (sorted(set(c) - set(_lib.SYMBOLS)), sorted(set(_lib.SYMBOLS) - set(c)))
+    for name, (_, args) in _lib.SYMBOLS.items():
+        assert len(args) == len(c[name][1]), name
+
+
+def test_hand_written_crate_calls_declared_functions_with_the_right_arity():
+    fns = rust_externs()
+    used = set()
+    for fn in sorted(os.listdir(SHIM_SRC)):
+        src = open(os.path.join(SHIM_SRC, fn)).read()
+        src = re.sub(r"//[^\n]*", "", src)
+        assert "..." not in src and "todo!" not in src and "unimplemented!" not in src, fn
+        for m in re.finditer(r"sys::(zk_\w+)\s*\(", src):
+            name = m.group(1)
+            assert name in fns, (fn, name)
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            args = _split_top(src[m.end():i - 1])
+            assert len(args) == len(fns[name][1]), (fn, name, len(args), len(fns[name][1]))
+            used.add(name)
+    # the calls the reference's interface needs: trim -> register + table, commit, open, the verifier-side MSM, the four transforms
+    assert {"zk_ctx_create", "zk_srs_register", "zk_srs_precompute", "zk_srs_free", "zk_kzg_commit_batch", "zk_kzg_open", "zk_msm_g1",
+            "zk_ntt", "zk_strerror"} <= used
+
+
+def test_gpu_kzg10_implements_every_required_method():
+    """PolynomialCommitment 0.3's required items + plonk-core's HomomorphicCommitment (commitment.rs:8-19), written out."""
+    src = open(os.path.join(SHIM_SRC, "kzg.rs")).read()
+    assert "impl PolynomialCommitment<Fr, Poly> for GpuKZG10" in src and "impl HomomorphicCommitment<Fr> for GpuKZG10" in src
+    for item in ("type UniversalParams", "type CommitterKey", "type VerifierKey", "type PreparedVerifierKey", "type Commitment",
+                 "type PreparedCommitment", "type Randomness", "type Proof", "type BatchProof", "type Error",
+                 "fn setup", "fn trim", "fn commit", "fn open<", "fn open_individual_opening_challenges", "fn check<",
+                 "fn check_individual_opening_challenges", "fn multi_scalar_mul"):
+        assert item in src, item

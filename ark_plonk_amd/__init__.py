@@ -13,11 +13,10 @@ from .curves import BLS12_381, BN254, get_curve  # noqa: F401
 from .domain import GeneralEvaluationDomain, Radix2EvaluationDomain  # noqa: F401
 from . import linearisation, lookup, permutation, prover, quotient, transcript  # noqa: F401
 from . import _lib, msm  # noqa: F401
-from ._lib import ZK_TABLE_EVERY_BIT as TABLE_EVERY_BIT  # noqa: F401
 from .msm import (CommitterKey, G1Affine, VariableBaseMSM, kzg_witness, srs_cache_config, srs_cache_stats, sum_partials,  # noqa: F401
                   sum_partials_batch)
 
 __all__ = [
     "Context", "default_context", "BLS12_381", "BN254", "get_curve", "GeneralEvaluationDomain",
-    "Radix2EvaluationDomain", "TABLE_EVERY_BIT", "CommitterKey", "G1Affine", "VariableBaseMSM", "kzg_witness", "sum_partials", "sum_partials_batch", "srs_cache_stats", "srs_cache_config", "permutation", "quotient", "lookup", "linearisation", "prover", "transcript",
+    "Radix2EvaluationDomain", "CommitterKey", "G1Affine", "VariableBaseMSM", "kzg_witness", "sum_partials", "sum_partials_batch", "srs_cache_stats", "srs_cache_config", "permutation", "quotient", "lookup", "linearisation", "prover", "transcript",
 ]

@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libark_plonk_amd.so")
+# ARK_PLONK_AMD_LIB: another build of the SAME HIP library (A/B measurements of kernel variants in one GPU session, tools/ab_bench.sh);
+# there is still no CPU fallback behind it
+LIB_PATH = os.environ.get("ARK_PLONK_AMD_LIB") or os.path.join(_HERE, "libark_plonk_amd.so")
 
 ZK_OK = 0
 ZK_ERR_BAD_ARG = -1
@@ -20,7 +22,6 @@ ZK_ERR_UNSUPPORTED = -6
 ZK_ERR_NOT_INVERTIBLE = -7
 ZK_ERR_NOT_INDEXED = -8
 ZK_ERR_PENDING = -9
-ZK_TABLE_EVERY_BIT = 0x100     # zk_srs_precompute_ex: | 17 = a table row for every bit position, width-17 NAF digits
 
 c_void_p = ctypes.c_void_p
 c_size_t = ctypes.c_size_t

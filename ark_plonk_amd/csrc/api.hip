@@ -161,7 +161,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
         return ZK_ERR_HIP;
     }
     c->stream = c->own_stream;
-    c->pool.reset(new HostPool(7));
+    c->pool.reset(new HostPool(15));
     zk_process_key(c->digest_key);
     c->digest_key[0] ^= (uint64_t)(uintptr_t)c * 0x9E3779B97F4A7C15ull;      // caches are per ctx: so are their keys
     for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
@@ -350,7 +350,7 @@ static size_t g_srs_idle_limit = (size_t)32 << 30;   // bytes of UNREFERENCED ca
 static uint64_t g_srs_hits = 0, g_srs_misses = 0;
 
 typedef std::shared_lock<std::shared_mutex> SrsReadLock;
-static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_naf ? s->pre_rows : s->pre_W ? s->pre_W : 1); }
+static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_W ? s->pre_W : 1); }
 
 static void srs_destroy(zk_srs* s) {
     if (s->d_xy) {
@@ -474,18 +474,11 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
 
 int zk_srs_precompute_ex(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     if (!c || !s || s->device != c->device) return ZK_ERR_BAD_ARG;
-    if (window_bits & ZK_TABLE_EVERY_BIT) {
-        if (window_bits != (ZK_TABLE_EVERY_BIT | 17u)) return ZK_ERR_BAD_ARG;
-    } else if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) {
-        return ZK_ERR_BAD_ARG;
-    }
+    if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     std::unique_lock<std::shared_mutex> wl(s->mu);   // no MSM of any ctx is reading or enqueueing on this SRS
     if (s->n == 0) return ZK_OK;
-    if (s->pre_W) {                                    // one table per SRS: the first precompute wins
-        const uint32_t have = s->pre_c | (s->pre_naf ? (uint32_t)ZK_TABLE_EVERY_BIT : 0u);
-        return (window_bits == 0 || window_bits == have) ? ZK_OK : ZK_ERR_UNSUPPORTED;
-    }
+    if (s->pre_W) return (window_bits == 0 || window_bits == s->pre_c) ? ZK_OK : ZK_ERR_UNSUPPORTED;   // one table per SRS: the first precompute wins
     ZK_HIP_TRY(hipDeviceSynchronize());               // ... and none it enqueued earlier is still running
     return msm_precompute_dev(c, s, window_bits);
 }
@@ -495,7 +488,7 @@ int zk_srs_precompute(zk_ctx* c, zk_srs* s) { return zk_srs_precompute_ex(c, s, 
 int zk_srs_table_info(zk_srs* s, uint32_t* window_bits, uint32_t* windows) {
     if (!s) return ZK_ERR_BAD_ARG;
     SrsReadLock rl(s->mu);
-    if (window_bits) *window_bits = s->pre_c | (s->pre_naf ? (uint32_t)ZK_TABLE_EVERY_BIT : 0u);
+    if (window_bits) *window_bits = s->pre_c;
     if (windows) *windows = s->pre_W;
     return ZK_OK;
 }

@@ -195,7 +195,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::recursive_mutex mu;
-    std::unique_ptr<HostPool> pool;   // created with the ctx (7 workers + the calling thread)
+    std::unique_ptr<HostPool> pool;   // created with the ctx (15 workers + the calling thread)
     int msm_window = 0;  // 0 = auto
     bool profiling = false;
     int profile_level = 0;   // 1: every scope; 2: msm_accumulate only (an event pair costs ~14 us of host time and a bubble on the stream)
@@ -287,12 +287,6 @@ struct zk_srs {
     // with it all windows of an MSM share ONE bucket set (no per-window reduction, no host doublings)
     void* d_pre = nullptr;
     uint32_t pre_c = 0, pre_W = 0;
-    // "every bit position" form of the table (zk_srs_precompute_ex with ZK_TABLE_EVERY_BIT): row p holds 2^p * P_i for EVERY bit
-    // position p = 0 .. pre_rows-1 (scalar bits + 1 rows), so a scalar can be recoded in width-pre_c non-adjacent form -- odd digits
-    // at arbitrary positions, at least pre_c apart: ~14.7 instead of 16 mixed additions per 255-bit scalar at pre_c = 17, into 2^(pre_c-2)
-    // shared buckets.  pre_W is then the number of digit slots per scalar (16).
-    bool pre_naf = false;
-    uint32_t pre_rows = 0;
 };
 
 // profiling helpers (ctx mutex held by caller)

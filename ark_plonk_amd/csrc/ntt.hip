@@ -63,6 +63,20 @@ __global__ void gen_pow_table(void* out, uint64_t n, PowBits<Fr> pb, Fr mul, int
     st_fr<Fr>(out, i, Fr::mul(r, to_rp));
 }
 
+// packed 32-byte table entries -> the 29-bit limbs of the pass kernels' field type, 48 B per entry (ntt_pass.cuh: ld_limbs)
+template <class FU>
+__global__ void split_table(const void* packed, void* out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FU x = ld_u<FU>(packed, i);
+    uint32_t w[4 * TW_INNER_U4];
+#pragma unroll
+    for (int k = 0; k < 4 * TW_INNER_U4; ++k) w[k] = k < FU::NL ? x.v[k] : 0u;
+    uint4* q = reinterpret_cast<uint4*>(out) + TW_INNER_U4 * i;
+#pragma unroll
+    for (int k = 0; k < TW_INNER_U4; ++k) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
 // tiny transforms (N = 1, 2, 4): one lane, straight from the definition (arkworks-form arithmetic)
 template <class Fr>
 __global__ void ntt_tiny(const void* in, void* out, uint64_t in_len, uint32_t log_n, Fr w /* w_N or its inverse */, Fr pre_g /* g or 1 */,
@@ -169,12 +183,26 @@ int get_inner_tw(zk_ctx* c, int s, bool inverse, void** out) {
         return ZK_OK;
     }
     uint64_t cnt = s >= 1 ? (1ull << (s - 1)) : 1;
+    void* packed = nullptr;
     void* p = nullptr;
-    ZK_HIP_TRY(hipMalloc(&p, cnt * sizeof(Fr)));
+    ZK_HIP_TRY(hipMalloc(&packed, cnt * sizeof(Fr)));
+    if (hipMalloc(&p, cnt * TW_INNER_U4 * 16) != hipSuccess) {
+        (void)hipFree(packed);
+        return ZK_ERR_OOM;
+    }
     Fr w = root_of_unity_host<C>((uint32_t)s);
     if (inverse) w = Fr::inverse(w);
-    int rc = launch_pow_table<C>(c, p, cnt, w, Fr::one(), 0, 0, 0);
-    if (rc) return rc;
+    int rc = launch_pow_table<C>(c, packed, cnt, w, Fr::one(), 0, 0, 0);
+    if (!rc) {
+        const int T = 256;
+        hipLaunchKernelGGL(split_table<typename C::FrU>, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, c->stream, packed, p, cnt);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    }
+    (void)hipFree(packed);
+    if (rc) {
+        (void)hipFree(p);
+        return rc;
+    }
     c->inner_tw[key] = p;
     *out = p;
     return ZK_OK;

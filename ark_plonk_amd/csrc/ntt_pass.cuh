@@ -23,7 +23,7 @@ typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
 struct NttPassArgs {
     const void* in;
     void* out;
-    const void* tw_inner;   // 2^S / 2 entries w_L^j (R'-form, 32 B packed)
+    const void* tw_inner;   // 2^S / 2 entries w_L^j (R'-form), already split into 29-bit limbs: 48 B per entry (ld_limbs)
     const void* tw_pass;    // inter-pass table [k][col] (R'-form), nullptr on the last pass
     const void* pre_mul;    // g^j table (first pass of coset_fft) or nullptr
     const void* post_mul;   // g^-j table (last pass of coset_ifft) or nullptr
@@ -72,6 +72,27 @@ ZK_D void st_u(void* base, uint64_t idx, const F& x) {
     uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// inner twiddles are stored as the 29-bit limbs the products consume (NL <= 12 words, padded to 48 B): the table is a few KiB
+// and L1-resident, and every butterfly of a pass reads one entry -- splitting 32-byte words into limbs at each use was ~27 of
+// the ~315 vector instructions of a butterfly
+constexpr int TW_INNER_U4 = 3;
+template <class F>
+ZK_D F ld_limbs(const void* base, uint64_t idx) {
+    static_assert(F::NL <= 4 * TW_INNER_U4, "inner twiddle entry too small");
+    const uint4* q = reinterpret_cast<const uint4*>(base) + TW_INNER_U4 * idx;
+    F r;
+#pragma unroll
+    for (int i = 0; i < TW_INNER_U4; ++i) {
+        if (4 * i >= F::NL) break;
+        const uint4 a = q[i];
+        if (4 * i + 0 < F::NL) r.v[4 * i + 0] = a.x;
+        if (4 * i + 1 < F::NL) r.v[4 * i + 1] = a.y;
+        if (4 * i + 2 < F::NL) r.v[4 * i + 2] = a.z;
+        if (4 * i + 3 < F::NL) r.v[4 * i + 3] = a.w;
+    }
+    return r;
 }
 
 template <int B0>
@@ -130,7 +151,7 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw, bool quarter) {
             }
             const uint32_t plow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
             const uint32_t j = plow << (S - 1 - t);
-            F w = ld_u<F>(tw, j);
+            F w = ld_limbs<F>(tw, j);
             F m = F::mul(x[eo], w);            // < 2r
             x[eo] = F::sub2(x[e], m);
             x[e] = F::add(x[e], m);

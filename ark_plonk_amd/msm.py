@@ -92,9 +92,7 @@ class CommitterKey:
 
     def precompute(self, window_bits: int = 0):
         """Build the window-multiples table (16x the SRS in HBM at the default window c = 16); later MSMs share one
-        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets), or
-        TABLE_EVERY_BIT | 17: a row for every bit position (256x the SRS) and width-17 NAF digits -- 14.7 instead of 16
-        additions per 255-bit scalar into the same 2^15 buckets."""
+        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets)."""
         self.ctx.use_torch_stream() if _has_torch_cuda() else None
         check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
         return self

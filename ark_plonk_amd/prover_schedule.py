@@ -29,6 +29,22 @@ from .domain import Radix2EvaluationDomain
 from .msm import CommitterKey, sum_partials_batch
 
 
+def all_gather_partials(dist, parts: np.ndarray, world: int, device) -> np.ndarray:
+    """The one exchange step of the sharded MSM: every rank's (jobs, 3L) Jacobian partials -> (world, jobs, 3L) on every rank.
+    `device`: where the collective's tensors live -- the rank's GPU for RCCL (backend "nccl": 144 bytes per job over xGMI), the
+    CPU for gloo.  One small H2D, one all_gather, one D2H per group of PC calls (5 per proof); the G-way sums are host work on
+    a few hundred bytes (zk_g1_sum_partials_batch)."""
+    import torch
+    jobs, l3 = parts.shape
+    mine = torch.from_numpy(np.ascontiguousarray(parts).view(np.int64).reshape(-1)).to(device, non_blocking=True)
+    out = torch.empty((world, jobs * l3), dtype=torch.int64, device=device)
+    if hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(out.view(-1), mine)
+    else:
+        dist.all_gather(list(out.unbind(0)), mine)
+    return out.cpu().numpy().view(np.uint64).reshape(world, jobs, l3)
+
+
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
@@ -234,15 +250,8 @@ class ProofSchedule:
         return self._all_gather_sum(full)
 
     def _all_gather_sum(self, parts):
-        torch = self.torch
-        L3 = 3 * self.cv.fq_limbs
-        n_jobs = parts.shape[0]
-        mine = torch.from_numpy(parts.view(np.int64).reshape(-1))
-        if self.dist.get_backend() == "nccl":
-            mine = mine.to(torch.device("cuda", self.ctx.device))
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(gathered, mine)
-        allp = torch.stack(gathered).cpu().numpy().view(np.uint64).reshape(self.world, n_jobs, L3)
+        dev = self.torch.device("cuda", self.ctx.device) if self.dist.get_backend() == "nccl" else self.torch.device("cpu")
+        allp = all_gather_partials(self.dist, parts, self.world, dev)
         return sum_partials_batch(allp, self.cv.curve_id)
 
     def _commit_now(self, polys, canonical=None, labels=None):

@@ -169,13 +169,6 @@ def self_launch(n_ranks: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def parse_table_window(v: str) -> int:
-    v = v.strip().lower()
-    if v.startswith("naf"):
-        return 0x100 | int(v[3:])
-    return int(v, 0)
-
-
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,9 +181,7 @@ def parse_args():
                     help="wire columns: uniform random, or BenchCircuit's periodic {6,7,-20,1} rows + 3 blinding rows (SURVEY.md 8d config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="per-window MSM path (no window-multiples table)")
-    ap.add_argument("--table-window", type=parse_table_window, default=0,
-                    help="SRS table: 0 = library default (c = 16, 16 rows); 16..21 = window c; naf17 = a row for every bit position "
-                         "(ZK_TABLE_EVERY_BIT | 17: 256 rows, 32 GiB per 2^20 points) with width-17 NAF digits; see zk_srs_precompute_ex")
+    ap.add_argument("--table-window", type=int, default=0, help="window c of the SRS table (0 = library default; 16..21), see zk_srs_precompute_ex")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-card rehearsals)")
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
                     help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by "

@@ -185,6 +185,44 @@ class CommitterKey {
         }
         return out;
     }
+    // The deferred form of the same call (zk_kzg_round_begin_dev ... zk_kzg_round_end): commitments whose inputs do not depend on
+    // each other's results -- f | h_1 | h_2 (prover.rs:289-317), z | z_2 (prover.rs:361-389), the last round's four calls
+    // (prover.rs:579-618) -- are begun call by call and collected once, in submission order.
+    void commit_begin(const std::vector<const DeviceVec*>& polys) const {
+        const uint32_t k = (uint32_t)polys.size();
+        std::vector<const void*> ptrs(k);
+        std::vector<size_t> lens(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            ptrs[i] = polys[i]->data();
+            lens[i] = polys[i]->size();
+        }
+        check(zk_kzg_round_begin_dev(ctx_->handle(), h_, k, ptrs.data(), lens.data(), nullptr), "zk_kzg_round_begin_dev");
+    }
+    // PC::open as a job of the open round (prover.rs:582-591,609-618)
+    void open_begin(const std::vector<const DeviceVec*>& polys, const uint64_t* z_mont, const uint64_t* challenge_mont) const {
+        const uint32_t k = (uint32_t)polys.size();
+        std::vector<const void*> ptrs(k);
+        std::vector<size_t> lens(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            ptrs[i] = polys[i]->data();
+            lens[i] = polys[i]->size();
+        }
+        check(zk_kzg_open_begin_dev(ctx_->handle(), h_, k, ptrs.data(), lens.data(), z_mont, challenge_mont), "zk_kzg_open_begin_dev");
+    }
+    std::vector<G1Affine> round_end() const {
+        const int L = fq_limbs(curve_);
+        uint32_t k = 0;
+        check(zk_kzg_round_pending(ctx_->handle(), &k), "zk_kzg_round_pending");
+        std::vector<uint64_t> xy((size_t)(k ? k : 1) * 2 * L);
+        std::vector<uint8_t> inf(k ? k : 1);
+        check(zk_kzg_round_end(ctx_->handle(), k, xy.data(), inf.data()), "zk_kzg_round_end");
+        std::vector<G1Affine> out(k);
+        for (uint32_t i = 0; i < k; ++i) {
+            out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
+            out[i].infinity = inf[i] != 0;
+        }
+        return out;
+    }
     // PC::commit(ck, polys, None) with host coefficient vectors (prover.rs:213,579,606): uploads overlap the MSMs
     std::vector<G1Affine> commit(const std::vector<const std::vector<uint64_t>*>& polys) const {
         const int L = fq_limbs(curve_);

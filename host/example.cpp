@@ -53,6 +53,12 @@ int main(int argc, char** argv) {
         auto round = ck.commit_round({&d_coeffs, &d_coeffs});
         std::printf("commit_round %s\n", (round[0].xy == single.xy && round[1].xy == single.xy && !single.infinity) ? "ok" : "MISMATCH");
         print("commit_x", single.xy, 6);
+        // the same two commitments as two deferred calls collected once (f | h_1 of prover.rs:289-312)
+        ck.commit_begin({&d_coeffs});
+        zk::DeviceVec d_again = dom.transform(ZK_NTT_IFFT, d_ev);      // a transform queued while the round is open
+        ck.commit_begin({&d_again});
+        auto deferred = ck.round_end();
+        std::printf("deferred_round %s\n", (deferred.size() == 2 && deferred[0].xy == single.xy && deferred[1].xy == single.xy) ? "ok" : "MISMATCH");
         // the unchanged caller's PC::commit(ck, polys): host vectors, one call for the whole slice (prover.rs:213)
         auto host_round = ck.commit({&coeffs, &ev, &coeffs});
         zk::CommitterKey again(ctx, srs);                 // PC::trim on the next gen_proof: the same bytes -> the resident SRS and table

@@ -164,13 +164,6 @@ int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
  * with window_bits = 0 (zk_srs_precompute) is a no-op; one that names a different window returns ZK_ERR_UNSUPPORTED and changes
  * nothing -- read the window in use with zk_srs_table_info.  Results never depend on the window. */
 int zk_srs_precompute_ex(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits);
-/* window_bits = ZK_TABLE_EVERY_BIT | 17: the table holds 2^p * P_i for EVERY bit position p (scalar bits + 1 rows: 256 x the SRS,
- * 32 GiB per 2^20 BLS12-381 points -- sized for the 288 GB of an MI355X; at most 2^23 - 1 points) instead of one row per window.
- * A scalar is then recoded in width-17 non-adjacent form -- odd signed digits below 2^16 at arbitrary positions at least 17 bits
- * apart -- which needs 14.7 mixed additions per 255-bit scalar on average instead of 16, into the same 2^15 shared buckets.
- * Results are unchanged; ZK_ERR_OOM leaves the SRS as it was (fall back to zk_srs_precompute).  zk_srs_table_info reports
- * window_bits with the flag set and windows = 16 (digit slots per scalar). */
-#define ZK_TABLE_EVERY_BIT 0x100u
 /* window_bits / windows (= rows = mixed additions per scalar) of the SRS's table; both 0 without a table. */
 int zk_srs_table_info(zk_srs* srs, uint32_t* window_bits, uint32_t* windows);
 /* One more owner of a live handle (a second zk_ctx / thread that keeps using the SRS on its own): pairs with one more

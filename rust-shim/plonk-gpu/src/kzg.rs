@@ -76,16 +76,8 @@ impl GpuKZG10 {
             return None;
         }
         let handle = Arc::new(SrsHandle(srs));
-        // the window table: 16 rows by default; ARK_PLONK_AMD_TABLE=every-bit asks for the every-bit-position table
-        // (256 x the SRS in HBM, ~8 % fewer additions per MSM); on ZK_ERR_OOM the default table is built instead
-        let every_bit = std::env::var("ARK_PLONK_AMD_TABLE").map(|v| v == "every-bit").unwrap_or(false);
-        let mut rc = sys::ZK_ERR_UNSUPPORTED;
-        if every_bit {
-            rc = unsafe { sys::zk_srs_precompute_ex(c, srs, sys::ZK_TABLE_EVERY_BIT | 17) };
-        }
-        if rc != sys::ZK_OK {
-            rc = unsafe { sys::zk_srs_precompute(c, srs) };
-        }
+        // the window table (16 rows, 2 GiB per 2^20 points); idempotent: built once per distinct SRS
+        let rc = unsafe { sys::zk_srs_precompute(c, srs) };
         if check(rc).is_err() {
             return None; // no table: MSMs would still work, but the key then simply takes the CPU path
         }

@@ -137,7 +137,7 @@ def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
         polys.append(p)
     exp = [oracle_cpu.kzg_commit(cid, bases_h, p) for p in polys]
     d_polys = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
-    for c in (16, 17, 18, 19, 20, 21, zk.TABLE_EVERY_BIT | 17):
+    for c in (16, 17, 18, 19, 20, 21):
         ck = zk.CommitterKey(bases, cid, ctx).precompute(c)
         assert ck.table_window_bits() == c and 12 <= ck.table_windows() <= 16
         batch = ck.commit_batch(d_polys)
@@ -146,83 +146,6 @@ def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
         for j, (pt, (xy, inf)) in enumerate(zip(batch, exp)):
             assert pt.infinity == bool(inf) and np.array_equal(pt.xy(), xy), (c, j)
         assert single == batch[:2]
-
-
-@pytest.mark.parametrize("cid", [0, 1])
-def test_every_bit_table_naf_recoding_edge_cases(cid, ctx, oracle_cpu):
-    """ZK_TABLE_EVERY_BIT | 17: scalars recoded in width-17 NAF against a table with a row per bit position.  The recoding never
-    modifies the scalar (a borrow is a carry flag that runs through the ones above a negative digit), so the inputs here are the
-    ones that stress it: runs of ones of every length and position, isolated bits, r - 1 and neighbours, the top bits, zero;
-    single MSMs with a base offset, round batches, deferred rounds and openings -- all against the CPU restatement."""
-    import torch
-    n = 1 << 13
-    cv = bo.CURVES[cid]
-    bits = cv.r.bit_length()
-    pw_c, _ = tau_powers(oracle_cpu, cid, n + 64)
-    bases = srs_from_powers(ctx, cid, pw_c)
-    bases_h = bases.cpu().numpy().view(np.uint64)
-    rng = np.random.default_rng(99 + cid)
-    vals = [0, 1, 2, 3, cv.r - 1, cv.r - 2, cv.r - 3, (cv.r - 1) // 2, (cv.r + 1) // 2, (1 << (bits - 1)), (1 << (bits - 1)) - 1,
-            (1 << 16) - 1, 1 << 16, (1 << 16) + 1, (1 << 17) - 1, 1 << 17, 0xffff << (bits - 18), 0x1ffff << (bits - 19)]
-    while len(vals) < n:
-        kind = len(vals) % 4
-        if kind == 0:
-            v = ((1 << int(rng.integers(1, bits))) - 1) << int(rng.integers(0, 64))       # one run of ones
-        elif kind == 1:
-            v = sum(1 << int(b) for b in rng.integers(0, bits - 1, size=int(rng.integers(1, 6))))   # a few isolated bits
-        elif kind == 2:
-            v = int.from_bytes(rng.bytes(32), "little") | (((1 << 40) - 1) << int(rng.integers(0, 200)))   # random with a long run
-        else:
-            v = int.from_bytes(rng.bytes(32), "little")
-        vals.append(v % cv.r)
-    canon = zk.curves.ints_to_limbs(vals, 4)
-    mont = oracle_cpu.convert(cid, "fr", True, canon)
-    d_canon = torch.from_numpy(canon.view(np.int64)).cuda()
-    d_mont = torch.from_numpy(mont.view(np.int64)).cuda()
-    ck = zk.CommitterKey(bases, cid, ctx).precompute(zk.TABLE_EVERY_BIT | 17)
-    assert ck.table_window_bits() == zk.TABLE_EVERY_BIT | 17 and ck.table_windows() == 16
-    for off in (0, 37):
-        xy, inf = oracle_cpu.msm_g1(cid, bases_h[off:off + n], canon)
-        got = ck.msm(d_canon, base_offset=off)
-        assert got.infinity == bool(inf) and np.array_equal(got.xy(), xy), off
-    exp = oracle_cpu.kzg_commit(cid, bases_h, mont)
-    exp_odd = oracle_cpu.kzg_commit(cid, bases_h, mont[: n - 1])
-    a, b, c = ck.commit_batch([d_mont, d_mont[: n - 1], d_canon], canonical=[False, False, True])
-    for pt, (xy, inf) in ((a, exp), (b, exp_odd), (c, exp)):
-        assert pt.infinity == bool(inf) and np.array_equal(pt.xy(), xy)
-    z = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
-    chi = np.array([0x2468ace, 0x7654321, 0x2222222, 0x0111111], dtype=np.uint64)
-    ck16 = zk.CommitterKey(bases, cid, ctx).precompute()
-    want_open = ck16.open([d_mont, d_mont[: n - 1]], z, chi)
-    ck16.close()
-    ck.commit_begin([d_mont])
-    ck.open_begin([d_mont, d_mont[: n - 1]], z, chi)
-    got = ck.round_end()
-    assert got[0] == a and got[1] == want_open
-    # another window on the same handle is refused, the same one is a no-op
-    with pytest.raises(zk._lib.ZkError):
-        ck.precompute(16)
-    ck.precompute(zk.TABLE_EVERY_BIT | 17).precompute()
-    ck.close()
-
-
-def test_every_bit_table_identity_2_20(ctx, oracle_cpu):
-    """The benchmark size: 2^20 points, 32 GiB of table, uniform and skewed scalars against the KZG identity."""
-    import torch
-    cid, n = 0, 1 << 20
-    pw_c, pw_m = tau_powers(oracle_cpu, cid, n)
-    bases = srs_from_powers(ctx, cid, pw_c)
-    del pw_c
-    ck = zk.CommitterKey(bases, cid, ctx).precompute(zk.TABLE_EVERY_BIT | 17)
-    del bases
-    for seed, skew in ((3030, False), (3031, True)):
-        scal = _rand_scalars(n, seed)
-        if skew:
-            scal[: n // 2] = np.tile(np.array([[6, 0, 0, 0], [7, 0, 0, 0]], dtype=np.uint64), (n // 4, 1))
-        k = sum_scalar_times_powers(oracle_cpu, cid, scal, pw_m)
-        got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
-        assert_is_scalar_times_g(got, k, cid)
-    ck.close()
 
 
 def test_table_window_20_identity_2_20(ctx, oracle_cpu):

@@ -171,3 +171,113 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+
+
+# ---- the exchange step itself (prover_schedule.all_gather_partials): one all_gather of every job's Jacobian partial per group of PC calls
+class _StubDist:
+    """What the `nccl` branch sees of torch.distributed, single process: records the tensors it is handed and plays `world` ranks
+    that all contributed the same partials."""
+
+    def __init__(self, backend, world, with_into_tensor=True):
+        self.backend, self.world, self.calls = backend, world, []
+        if with_into_tensor:
+            self.all_gather_into_tensor = self._into
+
+    def get_backend(self):
+        return self.backend
+
+    def _into(self, out, inp):
+        self.calls.append(("into", out.device, inp.device, out.dtype, inp.dtype, tuple(out.shape), tuple(inp.shape)))
+        out.view(self.world, -1).copy_(inp.unsqueeze(0).expand(self.world, -1))
+
+    def all_gather(self, outs, inp):
+        self.calls.append(("list", outs[0].device, inp.device, outs[0].dtype, inp.dtype, (len(outs),) + tuple(outs[0].shape), tuple(inp.shape)))
+        for o in outs:
+            o.copy_(inp)
+
+
+@pytest.mark.parametrize("into", [True, False])
+def test_all_gather_partials_shapes_and_placement_cpu(into):
+    """dtype / shape / device of what goes into the collective, on the CPU device (gloo's placement; the nccl branch differs only
+    in `device`, exercised on the card by the gpu test below)."""
+    import torch
+    from ark_plonk_amd.prover_schedule import all_gather_partials
+    world, jobs, l3 = 4, 5, 18
+    parts = np.arange(jobs * l3, dtype=np.uint64).reshape(jobs, l3) + (1 << 63)       # top bit set: survives the int64 view
+    d = _StubDist("gloo", world, with_into_tensor=into)
+    got = all_gather_partials(d, parts, world, torch.device("cpu"))
+    assert got.shape == (world, jobs, l3) and got.dtype == np.uint64
+    for r in range(world):
+        assert np.array_equal(got[r], parts)
+    kind, odev, idev, odt, idt, oshape, ishape = d.calls[0]
+    assert kind == ("into" if into else "list") and odev.type == idev.type == "cpu" and odt == idt == torch.int64
+    assert ishape == (jobs * l3,) and oshape == ((world * jobs * l3,) if into else (world, jobs * l3))
+
+
+def _worker_gather(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ark_plonk_amd.prover_schedule import all_gather_partials
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    parts = (np.arange(3 * 18, dtype=np.uint64).reshape(3, 18) + 1000 * (rank + 1))
+    got = all_gather_partials(dist, parts, world, torch.device("cpu"))
+    q.put((rank, got.tolist()))
+    dist.destroy_process_group()
+
+
+def test_all_gather_partials_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gather, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(3 * 18, dtype=np.uint64).reshape(3, 18)
+    for rank in (0, 1):
+        got = np.array(res[rank], dtype=np.uint64)
+        assert got.shape == (2, 3, 18)
+        assert np.array_equal(got[0], base + 1000) and np.array_equal(got[1], base + 2000)
+
+
+@pytest.mark.gpu
+def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx):
+    """ProofSchedule with world = 2 and a `dist` that reports backend "nccl": the partials of every group of PC calls must enter
+    the collective as int64 tensors on the rank's GPU (RCCL cannot take host tensors), one all_gather per group; with both "ranks"
+    contributing this rank's shard the result is twice the shard's commitment."""
+    import torch
+    import ark_plonk_amd as zk
+    from ark_plonk_amd import _lib
+    from ark_plonk_amd.prover_schedule import ProofSchedule
+    cv = zk.get_curve(0)
+    log_n = 13
+    n = 1 << log_n
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
+    ck_full = zk.CommitterKey(bases, cv, ctx).precompute()
+    ck_shard = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()      # rank 0 of 2 owns SRS[0, n/2)
+    d = _StubDist("nccl", 2)
+    sched = ProofSchedule(log_n, ctx, ck_shard, cv, rank=0, world=2, dist=d)
+    out = sched.run_once(proof_id=0)
+    assert len(out) == 29 and len(d.calls) == 5              # five groups of PC calls, one collective each
+    for kind, odev, idev, odt, idt, oshape, ishape in d.calls:
+        assert odev.type == idev.type == "cuda" and odev.index == idev.index == ctx.device and odt == idt == torch.int64
+        assert ishape[0] % (3 * cv.fq_limbs) == 0 and oshape == (2 * ishape[0],)
+    # rank 0's shard of w_l committed by both stub ranks = 2 * commit(w_l[: n/2]) over SRS[: n/2]
+    half = ck_shard.commit(sched.coef[0][: n // 2])
+    two = zk.msm.sum_partials(np.stack([ck_shard.commit_batch_partial([sched.coef[0][: n // 2]])[0]] * 2), 0)
+    assert out[0] == two and out[0] != half
+    ck_full.close()
+    ck_shard.close()

@@ -166,6 +166,30 @@ def test_precomputed_table_2_20_skewed(ctx):
     _kzg_identity(0, 20, ctx, skew=True, precompute=True)
 
 
+def test_precomputed_table_2_20_vs_cpu_pippenger_limb_for_limb(ctx, oracle_cpu):
+    """The benchmark MSM -- 2^20 points, window table -- against the C++ restatement of ark 0.3's Pippenger (c = 15, 17 windows;
+    ~1 s on the test box), limb for limb; the KZG identity above checks the same size against a different kind of witness."""
+    import torch
+    cid, n = 0, 1 << 20
+    cv = bo.CURVES[cid]
+    g = torch.Generator(device="cuda").manual_seed(2020)
+    ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, ks.data_ptr(), n, bases.data_ptr()))
+    rng = np.random.default_rng(77)
+    scal = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    scal[:, 3] &= np.uint64((1 << 62) - 1)          # < 2^254 < r: canonical
+    scal[:1000] = 0
+    scal[1000:2000] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    ck = zk.CommitterKey(bases, cid, ctx).precompute()
+    got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
+    ck.close()
+    exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases.cpu().numpy().view(np.uint64), scal)
+    assert_point(got, exp_xy, exp_inf, cid)
+
+
 def test_precomputed_table_threshold_sizes(ctx):
     # smallest sizes that take the shared-bucket path (ZK_PRE_MIN_N = 2^13) and one just above
     _kzg_identity(0, 13, ctx, precompute=True)

@@ -281,3 +281,26 @@ def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx):
     assert out[0] == two and out[0] != half
     ck_full.close()
     ck_shard.close()
+
+
+@pytest.mark.gpu
+def test_config3_size_two_concurrent_ranks_with_a_collective():
+    """BASELINE config 3's size (2^22 points per MSM) as bench.py runs it on N > 1: two ranks CONCURRENTLY on this box's one card,
+    every MSM point-sharded (2^21 points and a 4 GiB window table per rank), one all_gather of the Jacobian partials per group
+    of PC calls (gloo here, RCCL on a node), NTTs replicated.  The 29 commitments must equal the single-rank run's."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = [os.path.join(ROOT, "bench.py"), "--log-n", "22", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--extra-legs", "off",
+              "--streams-leg", "0", "--no-profile"]
+    one = subprocess.run([sys.executable] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    two = subprocess.run([sys.executable] + common + ["--gpus", "2", "--backend", "gloo", "--mode", "shard"],
+                         capture_output=True, text=True, env=env, timeout=1200)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and "2^22" in d2["metric"]
+    assert d1["commitments_sha256"] == d2["commitments_sha256"]

@@ -116,27 +116,31 @@ def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcrip
     table_poly = d.ifft(t_ev)                                                                             # :240-242
     f_ev = lookup.compress_query(pk.q_lookup_evals, list(wires), ch["zeta"], t_ev, n=n, curve=cv, ctx=ctx)   # :244-276
     f_poly = d.ifft(f_ev)                                                                                 # :279-283
+    # lean=False: the reference's three PC::commit calls, issued where the reference issues them and collected once -- no challenge
+    # is drawn between them (zk_kzg_round_begin_dev ... zk_kzg_round_end; the points and the transcript bytes are the same)
     if not lean:
-        f_commit = ck.commit_batch([f_poly])[0]                                                           # :289-291
+        ck.commit_begin([f_poly])                                                                         # :289-291
     h1_ev, h2_ev = lookup.combine_split(t_ev, f_ev, cv, ctx)                                              # :295-297
     h1_poly, h2_poly = d.batch(1, [h1_ev, h2_ev])                                                         # :300-305
     if lean:
         f_commit, h1_commit, h2_commit = ck.commit_batch([f_poly, h1_poly, h2_poly])
     else:
-        h1_commit = ck.commit_batch([h1_poly])[0]                                                         # :312-317
-        h2_commit = ck.commit_batch([h2_poly])[0]
+        ck.commit_begin([h1_poly])                                                                        # :312-317
+        ck.commit_begin([h2_poly])
+        f_commit, h1_commit, h2_commit = ck.round_end(3)
     ch.update(tr.round2(f_commit, h1_commit, h2_commit))                                                  # :294,320-337
     for a, b in (("beta", "gamma"), ("beta", "delta"), ("beta", "epsilon"), ("gamma", "delta"), ("gamma", "epsilon"), ("delta", "epsilon")):
         assert not np.array_equal(ch[a], ch[b]), "challenges must be different"                           # :340-345
     # -- round 3
     z_poly = d.ifft(permutation.permutation_evals(d, list(wires), pk.sigma_evals, ch["beta"], ch["gamma"]))     # :347-358
     if not lean:
-        z_commit = ck.commit_batch([z_poly])[0]                                                           # :361-363
+        ck.commit_begin([z_poly])                                                                         # :361-363
     z2_poly = d.ifft(permutation.lookup_permutation_evals(ctx, cv, f_ev, t_ev, h1_ev, h2_ev, ch["delta"], ch["epsilon"]))   # :370-380
     if lean:
         z_commit, z2_commit = ck.commit_batch([z_poly, z2_poly])
     else:
-        z2_commit = ck.commit_batch([z2_poly])[0]                                                         # :387-389
+        ck.commit_begin([z2_poly])                                                                        # :387-389
+        z_commit, z2_commit = ck.round_end(2)
     pi_ev = torch.zeros((n, 4), dtype=torch.int64, device=wires[0].device)                                # :392 into_dense_poly
     for pos, v in public_inputs.items():
         pi_ev[pos] = torch.from_numpy(np.asarray(v, dtype=np.uint64).reshape(4).view(np.int64)).to(pi_ev.device)
@@ -158,20 +162,25 @@ def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcrip
     aw_ch, saw_ch = tr.round5({lb: ev[_EVAL_FIELD[lb]] for lb in EVAL_LABELS}, [(lb, ev[lb]) for lb in CUSTOM_EVAL_LABELS])  # :516-563,593-594
     ch["aw_challenge"], ch["saw_challenge"] = aw_ch, saw_ch
     aw_polys = [lin_poly, pk.sigma_polys[0], pk.sigma_polys[1], pk.sigma_polys[2], f_poly, h2_poly, table_poly]     # :569-577
+    # lean=False: the four PC calls of the round (both opening challenges are already drawn) as one deferred round of 16 jobs
     if not lean:
-        ck.commit_batch(aw_polys)                                                                         # :579 (the verifier rebuilds these)
+        ck.commit_begin(aw_polys)                                                                         # :579 (the verifier rebuilds these)
     from .msm import kzg_witness
     aw_witness = kzg_witness(aw_polys + list(w_polys), ch["z_challenge"], aw_ch, cv, ctx)                 # :582-591 PC::open =
     if not lean:
-        aw_opening = ck.commit_batch([aw_witness], canonical=[True])[0]                                   #   witness polynomial + its commitment
+        ck.commit_begin([aw_witness], canonical=[True])                                                   #   witness polynomial + its commitment
     saw_polys = [z_poly, w_polys[0], w_polys[1], w_polys[3], h1_poly, z2_poly, table_poly]                # :596-604
-    saw_commits = [z_commit] if lean else ck.commit_batch(saw_polys)                                      # :606
+    if not lean:
+        ck.commit_begin(saw_polys)                                                                        # :606
     zw = fr_to_mont(cv, [fr_from_mont(cv, ch["z_challenge"].reshape(1, 4))[0] * fr_from_mont(cv, np.asarray(d.group_gen()).reshape(1, 4))[0] % cv.r])[0]
     saw_witness = kzg_witness(saw_polys, zw, saw_ch, cv, ctx)                                             # :609-618
     if lean:
+        saw_commits = [z_commit]
         aw_opening, saw_opening = ck.commit_batch([aw_witness, saw_witness], canonical=[True, True])
     else:
-        saw_opening = ck.commit_batch([saw_witness], canonical=[True])[0]
+        ck.commit_begin([saw_witness], canonical=[True])
+        last = ck.round_end(16)
+        aw_opening, saw_commits, saw_opening = last[7], last[8:15], last[15]
     commitments = {"a_comm": w_commits[0], "b_comm": w_commits[1], "c_comm": w_commits[2], "d_comm": w_commits[3], "z_comm": saw_commits[0],
                    "f_comm": f_commit, "h_1_comm": h1_commit, "h_2_comm": h2_commit, "z_2_comm": z2_commit, "t_1_comm": t_commits[0],
                    "t_2_comm": t_commits[1], "t_3_comm": t_commits[2], "t_4_comm": t_commits[3]}           # :620-637

@@ -46,6 +46,9 @@ int main() {
                 if (inf && (enc[g1_b - 1] != 0x40 || enc[0] != 0)) return 15;
                 if (zk_g1_serialize_uncompressed(curve, xy.data(), inf, enc.data()) != ZK_OK) return 12;
                 if (zk_g1_deserialize_uncompressed(curve, enc.data(), xy2.data(), &inf2) != ZK_OK || inf != inf2 || (!inf && xy != xy2)) return 13;
+                // both SWFlags bits set is no encoding at all (SWFlags::from_u8 returns None), in either form
+                enc[2 * g1_b - 1] |= 0xC0;
+                if (zk_g1_deserialize_uncompressed(curve, enc.data(), xy2.data(), &inf2) == ZK_OK) return 16;
                 ++roundtrips;
             } else {
                 ++rejected;

@@ -1,5 +1,6 @@
 """Randomised cross-check of the commit paths against the CPU restatement: random lengths (odd / even / threshold
-neighbours), random batch shapes, uniform and heavily skewed scalars, table and per-window paths.
+neighbours), random batch shapes (blocking batches, host-pointer batches, deferred rounds cut at random places), uniform and
+heavily skewed scalars, table and per-window paths.
 usage: python tests/stress/stress_msm.py [seconds]   (also collected, with a short budget, by tests/test_stress_gpu.py)"""
 import os
 import sys
@@ -51,8 +52,18 @@ def run(budget: float = 120.0, seed: int = 1, ctx=None, max_log_n: int = 17):
             elif mode < 0.3:    # sparse
                 p[rng.random(ln) < 0.95] = 0
             polys.append(p)
-        if rng.random() < 0.25:
+        how = rng.random()
+        if how < 0.25:
             got = ck.commit_batch(polys)          # host-pointer batch (zk_kzg_commit_batch: staged uploads under the MSMs)
+        elif how < 0.6:
+            # deferred round (zk_kzg_round_begin_dev ... zk_kzg_round_end): the batch cut into 1..k calls at random places
+            d_polys = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+            cuts = sorted(set(int(c) for c in rng.integers(1, k + 1, size=int(rng.integers(0, 3))) if c < k))
+            lo = 0
+            for hi in cuts + [k]:
+                ck.commit_begin(d_polys[lo:hi])
+                lo = hi
+            got = ck.round_end(k)
         else:
             got = ck.commit_batch([torch.from_numpy(p.view(np.int64)).cuda() for p in polys])
         for p, g in zip(polys, got):

@@ -108,15 +108,48 @@ struct MsmGeom {
     uint32_t logG;     // level-1 segment = 2^logG buckets
     uint32_t ns;       // segments per window
     uint32_t logq;     // level-2: 2^logq segments per lane
+    // neg: a scalar k > (r - 1) / 2 is replaced by r - k and the signs of its digits are flipped (k P = (r - k)(-P)).  The
+    // replaced scalar has one bit less, which saves a whole window where the window size divides the remaining bits well:
+    // 255-bit scalars in 17-bit windows need 16 windows (the last one holds nothing but a carry), 254-bit ones exactly 15.
+    // make_geom switches it on only when it removes a window; half = (r - 1) / 2 and mod = r, little-endian 32-bit words.
+    uint32_t neg = 0;
+    uint32_t half[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t mod[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-// c-bit field of a canonical scalar (8 x u32 limbs in global memory) at bit position pos
-ZK_D uint32_t scalar_bits(const uint32_t* s, uint32_t pos, uint32_t c) {
-    uint32_t limb = pos >> 5, off = pos & 31;
-    uint64_t lo = limb < 8 ? s[limb] : 0u;
-    uint64_t hi = (limb + 1) < 8 ? s[limb + 1] : 0u;
-    uint64_t v = ((hi << 32) | lo) >> off;
+// c-bit field of a canonical scalar (8 x u32 limbs in registers: selects, no indexing) at bit position pos
+ZK_D uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t pos, uint32_t c) {
+    const uint32_t limb = pos >> 5, off = pos & 31;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((uint32_t)k == limb) lo = s[k];
+        if ((uint32_t)k == limb + 1) hi = s[k];
+    }
+    const uint64_t v = ((hi << 32) | lo) >> off;
     return (uint32_t)v & ((1u << c) - 1u);
+}
+
+// the negated-scalar rule of MsmGeom::neg: k <- r - k when k > (r - 1) / 2; returns whether it did (the digits' signs flip)
+ZK_D bool scalar_fold(uint32_t (&k)[8], const MsmGeom& g) {
+    if (!g.neg) return false;
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (!decided && k[i] != g.half[i]) {
+            gt = k[i] > g.half[i];
+            decided = true;
+        }
+    }
+    if (!gt) return false;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t d = (uint64_t)g.mod[i] - k[i] - borrow;
+        k[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+    }
+    return true;
 }
 
 // ---- counting sort of the (point, sign) references by (window, bucket), without global atomics ----
@@ -128,14 +161,17 @@ ZK_D uint32_t scalar_bits(const uint32_t* s, uint32_t pos, uint32_t c) {
 __global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, int16_t* dig) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t* s = scalars + 8 * i;
+    const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * i;
+    const uint4 a = q[0], b = q[1];
+    uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const bool flip = scalar_fold(s, g);
     uint32_t carry = 0;
     const uint32_t half = 1u << (g.c - 1);
     for (uint32_t w = 0; w < g.W; ++w) {
         uint32_t raw = scalar_bits(s, w * g.c, g.c) + carry;
         carry = raw >= half ? 1u : 0u;
         int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
-        dig[(uint64_t)w * n + i] = (int16_t)d;
+        dig[(uint64_t)w * n + i] = (int16_t)(flip ? -d : d);
     }
 }
 
@@ -608,18 +644,13 @@ __global__ void __launch_bounds__(256) psortw_digits_hist(const uint32_t* scalar
         x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
         x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
         if (MONT) x = Fr::from_mont(x);
+        const bool flip = scalar_fold(x.v, g);
         uint32_t carry = 0;
         for (uint32_t w = 0; w < g.W; ++w) {
-            const uint32_t pos = w * g.c, limb = pos >> 5, off = pos & 31;
-            uint64_t lo64 = 0, hi64 = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {      // register-resident limbs: select, do not index
-                if ((uint32_t)k == limb) lo64 = x.v[k];
-                if ((uint32_t)k == limb + 1) hi64 = x.v[k];
-            }
-            const uint32_t raw = ((uint32_t)(((hi64 << 32) | lo64) >> off) & cmask) + carry;
+            const uint32_t raw = (scalar_bits(x.v, w * g.c, g.c) & cmask) + carry;
             carry = raw >= half ? 1u : 0u;
-            const int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
+            int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
+            if (flip) d = -d;
             dig[(uint64_t)w * n + i] = d;
             if (d != 0) atomicAdd(&lc[(uint32_t)((d < 0 ? -d : d) - 1) >> lob], 1u);
         }
@@ -1574,6 +1605,21 @@ MsmGeom make_geom(uint64_t n, int c_override, uint32_t max_c = 16) {
     // the last window must never produce a carry: its largest raw value (top bits of r-1, plus the
     // incoming carry) has to stay below 2^(c-1); otherwise spend one more window
     if (modulus_minus_one_bits<FrP>((g.W - 1) * c) + 1 >= (1u << (c - 1))) g.W += 1;
+    // the same count for scalars folded to k <= (r - 1) / 2 (MsmGeom::neg): used only where it removes a window
+    {
+        uint32_t Wn = ((uint32_t)bits - 1 + c - 1) / c;
+        if (Wn == 0) Wn = 1;
+        if (modulus_minus_one_bits<FrP>((Wn - 1) * c + 1) + 1 >= (1u << (c - 1))) Wn += 1;     // ((r - 1) / 2) >> shift = (r - 1) >> (shift + 1)
+        if (Wn < g.W && FrP::N == 8) {
+            g.W = Wn;
+            g.neg = 1;
+            uint32_t w[9];
+            for (int i = 0; i < 8; ++i) w[i] = g.mod[i] = FrP::MOD(i);
+            w[8] = 0;
+            w[0] -= 1;      // r is odd
+            for (int i = 0; i < 8; ++i) g.half[i] = (w[i] >> 1) | (w[i + 1] << 31);
+        }
+    }
     g.B = 1u << (c - 1);
     g.nb = g.W * g.B;
     g.logG = c - 1 < 4 ? c - 1 : 4;
@@ -1756,7 +1802,10 @@ constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket re
 template <class Cv>
 int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     typedef typename Cv::FqU F;
-    if (window_bits == 0) window_bits = PRE_C;
+    // default window: 16 bits (16 rows, 2^15 buckets) below 2^19 points; from there on 17 bits, which scalars folded to
+    // k <= (r - 1) / 2 (MsmGeom::neg) cover in 15 windows -- one mixed addition per scalar fewer for twice the buckets to reduce
+    // (measured, profiles/r03_notes.md: 2^18 27.1 / 29.2 ms per proof at c = 16 / 17, 2^19 48.1 / 47.3, 2^20 87.4 / 85.6, 2^22 364.6 / 353.2)
+    if (window_bits == 0) window_bits = s->n >= (1u << 19) ? PRE_C + 1 : PRE_C;
     if (window_bits < PRE_C || window_bits > PRE_C_MAX) return ZK_ERR_BAD_ARG;
     MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)window_bits, PRE_C_MAX);
     const size_t pb = s->point_bytes;
@@ -1804,7 +1853,9 @@ struct PrePlan {
     uint64_t nf;
     uint32_t chunk_l, n_lanes, S;
     size_t win_bytes;
-    bool wide;          // c > 16: int32 digits, 2^(c-9) buckets per sort partition, three-level device reduction
+    bool wide;          // c > 16: int32 digits, 2^(c-9) buckets per sort partition
+    bool wide_red;      // more than 2^16 shared buckets: three-level device reduction (up to 2^16 the virtual-window reduction of the
+                        // c = 16 table serves, with virtual windows of 1024 buckets)
 };
 
 template <class Cv>
@@ -1817,17 +1868,20 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
     pl.wide = pl.g.c > 16;
+    pl.wide_red = pl.g.B > (1u << 16);
     pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
     if (pl.nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
     pl.g1 = pl.g;                                       // the sort sees ONE window of nf digits
     pl.g1.W = 1;
     pl.g1.nb = pl.g.B;
     pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows (wide: windows of 512 buckets)
-    pl.gv.W = pl.wide ? pl.g.B / WIDE_VB : PRE_VW;
+    pl.gv.W = pl.wide_red ? pl.g.B / WIDE_VB : PRE_VW;
     pl.gv.B = pl.g.B / pl.gv.W;
     pl.gv.nb = pl.g.B;
-    pl.gv.logG = pl.wide ? 2 : 3;     // 8 buckets per segment: 64 chains (one wavefront per SIMD) per virtual window; measured against 4 / 16
-    if (!pl.wide) {                                       // tuning hooks (profiles/r02_notes.md)
+    // 64 chains (one wavefront per SIMD) per virtual window: segments of 8 buckets for windows of 512 (c = 16; measured against 4 / 16),
+    // of 16 for windows of 1024 (c = 17; 64 x 16 measured against 128 x 8, and against 128 and 32 virtual windows)
+    pl.gv.logG = pl.wide_red ? 2 : pl.gv.B >= 1024 ? 4 : 3;
+    if (!pl.wide_red) {                                   // tuning hooks (profiles/r02_notes.md)
         if (const char* e = getenv("ZK_PRE_VW")) {
             const uint32_t v = (uint32_t)atoi(e);
             if (v >= 8 && v <= 512 && (v & (v - 1)) == 0 && pl.g.B % v == 0) {
@@ -1848,15 +1902,24 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     // lanes finishing early are replaced instead of idling through the tail (measured at 2^20:
     // L = 128 / 64 / 32 / 16 -> 111.8 / 110.3 / 110.8 / 162 ms per proof; 16 overloads the combine)
     pl.chunk_l = PRE_CHUNK_L;
-    while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 262144) pl.chunk_l >>= 1;
+    while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 196608) pl.chunk_l >>= 1;
     if (const char* e = getenv("ZK_CHUNK_L")) {          // tuning hook (profiles/r02_notes.md)
         const uint32_t v = (uint32_t)atoi(e);
         if (v >= 8 && v <= 1024) pl.chunk_l = v;
     }
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
+    // whole rounds of resident lanes: every lane does the same work, so 1.9 rounds take as long as 2 (15 windows of 2^20 digits
+    // at 64 per lane are 245760 lanes): round the lane count up to a multiple of a round and shorten the chunks instead
+    {
+        constexpr uint32_t ROUND = 131072;
+        if (pl.n_lanes > ROUND) {
+            pl.n_lanes = (pl.n_lanes + ROUND - 1) / ROUND * ROUND;
+            pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
+        }
+    }
     pl.S = 1;
     while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;   // 256 / 512 slabs measured slower (scans grow)
-    pl.win_bytes = pl.wide ? (size_t)4 * sizeof(PH) : (size_t)2 * pl.gv.W * sizeof(PH);
+    pl.win_bytes = pl.wide_red ? (size_t)4 * sizeof(PH) : (size_t)2 * pl.gv.W * sizeof(PH);
     int rc;
     if (!pl.wide && (rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
     if ((rc = mb.offsets.ensure((size_t)(pl.g.B + 1) * 4))) return rc;
@@ -1865,7 +1928,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
     if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
     if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
-    if (pl.wide) {
+    if (pl.wide_red) {
         const size_t n1 = pl.g.B >> WIDE_LOGG1, n2 = n1 >> WIDE_LOGK2;
         if ((rc = mb.seg.ensure(n1 * 2 * PT))) return rc;                   // level 1: (run, acc) of the 4-bucket nodes
         if ((rc = mb.seg2.ensure(n2 * 2 * PT))) return rc;                  // level 2: 16-bucket nodes
@@ -1919,7 +1982,7 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         return ZK_OK;
     }
     const bool psort = pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256;   // two-pass partition sort
-    const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16;                     // two scalars per lane
+    const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16 && !pl.g.neg;        // two scalars per lane
     const uint32_t P = pl.g1.nb >> PS_LOB;
     const uint32_t sp = psort_slab_len(n);
     uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 partition starts | P totals | scan counter
@@ -2010,7 +2073,7 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         jobs.buckets[k] = mb.buckets.p;
         jobs.q[k] = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
         jobs.seg_run[k] = mb.seg.p;
-        jobs.seg_acc[k] = (char*)mb.seg.p + (p0.wide ? (size_t)(p0.g.B >> WIDE_LOGG1) : (size_t)p0.gv.W * p0.gv.ns) * PT;
+        jobs.seg_acc[k] = (char*)mb.seg.p + (p0.wide_red ? (size_t)(p0.g.B >> WIDE_LOGG1) : (size_t)p0.gv.W * p0.gv.ns) * PT;
         // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
         // buffer (hipHostMalloc memory is device-visible): no copy launches at the tail of the call
         jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
@@ -2020,7 +2083,7 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         jobs.nbk[k] = p0.g1.nb;
     }
     // the queue counters were cleared by the job's sort (psort_hist / the memset of the fallback sort)
-    if (p0.wide) {
+    if (p0.wide_red) {
         void* d_vw[MAX_JOBS];
         void* d_seg3[MAX_JOBS];
         void* d_seg2[MAX_JOBS];
@@ -2139,7 +2202,7 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     MsmBufs* one = &mb;
     if ((rc = pre_queue_reduce<Cv>(c, &pl, &one, 1, c->pinned, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
-    if (pl.wide) pre_host_wide<Cv>(c->pinned, ilog2_floor(pl.gv.B), out_xyz);
+    if (pl.wide_red) pre_host_wide<Cv>(c->pinned, ilog2_floor(pl.gv.B), out_xyz);
     else pre_host_combine<Cv>(c->pinned, pl.gv.W, pl.gv.B, out_xyz);
     return ZK_OK;
 }
@@ -2215,7 +2278,7 @@ int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slo
     } tail_timer{host_timing, n_jobs, t0, t1};
     const char* h_win = (const char*)c->pinned;
     int rcs[MAX_JOBS] = {0};
-    if (pl[0].wide) {
+    if (pl[0].wide_red) {
         c->pool->run(n_jobs, [&](uint32_t k) {
             uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
             pre_host_wide<Cv>(h_win + (size_t)k * wb, ilog2_floor(pl[k].gv.B), xyz);

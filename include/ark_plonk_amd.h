@@ -154,11 +154,13 @@ int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t
 int zk_srs_register(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t* inf_flags, size_t n, zk_srs** out);
 int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const uint8_t* d_inf_flags, size_t n, zk_srs** out);
 /* Optional: build the table of window multiples 2^(c w) * P_i (w = 1..W-1) for this SRS, W x its
- * size in HBM (2 GiB per 2^20 BLS12-381 points at c = 16; the card has 288 GB).  MSMs over the SRS then use a
- * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged.  Idempotent. */
+ * size in HBM (1.9 GiB per 2^20 BLS12-381 points; the card has 288 GB).  MSMs over the SRS then use a
+ * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged.  Idempotent.
+ * Default window: c = 16 (16 rows) below 2^19 points, c = 17 from there on -- 15 rows for the 255-bit scalars of BLS12-381,
+ * because a scalar k > (r - 1) / 2 is treated as -(r - k): one mixed addition per scalar fewer, 2^16 buckets instead of 2^15. */
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 /* Same with the table's window c chosen: 16 (default; 16 rows, 2^15 shared buckets) .. 21.  A larger window means fewer
- * rows (13 at c = 20: 13 mixed additions per scalar instead of 16, table 13 x the SRS) but 2^(c-1) buckets to reduce.
+ * rows (15 at c = 17, 13 at c = 20: mixed additions per scalar, table rows) but 2^(c-1) buckets to reduce.
  * 0 = default, or whatever table the SRS already holds.  The table belongs to the SRS, and a content-addressed
  * zk_srs_register hands every caller that registers the same bytes the SAME handle: the first precompute wins.  A later call
  * with window_bits = 0 (zk_srs_precompute) is a no-op; one that names a different window returns ZK_ERR_UNSUPPORTED and changes

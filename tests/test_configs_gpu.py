@@ -125,7 +125,7 @@ def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
     bases_h = bases.cpu().numpy().view(np.uint64)
     rng = np.random.default_rng(7 + cid)
     polys = []
-    for ln, mode in ((n, "uniform"), (n - 1, "skew"), (8193, "sparse"), (n, "max"), (8192, "uniform")):
+    for ln, mode in ((n, "uniform"), (n - 1, "skew"), (8193, "sparse"), (n, "max"), (8192, "uniform"), (n, "half")):
         p = _rand_scalars(ln, int(rng.integers(1 << 30)), bits62=59)
         if mode == "skew":
             small = zk.curves.fr_to_mont(cid, [6, 7, cv.r - 20, 1])
@@ -134,12 +134,19 @@ def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
             p[rng.random(ln) < 0.95] = 0
         elif mode == "max":
             p[:] = zk.curves.fr_to_mont(cid, [cv.r - 1])[0]
+        elif mode == "half":
+            # around (r - 1) / 2, where the 15-window form of the c = 17 table folds k to r - k (MsmGeom::neg), and the extremes
+            h = (cv.r - 1) // 2
+            edge = [h - 1, h, h + 1, h + 2, 1, cv.r - 1, cv.r - 2, (1 << (cv.r.bit_length() - 1)), (1 << (cv.r.bit_length() - 1)) - 1, 0]
+            p[: 4 * len(edge)] = np.tile(zk.curves.fr_to_mont(cid, edge), (4, 1))
         polys.append(p)
     exp = [oracle_cpu.kzg_commit(cid, bases_h, p) for p in polys]
     d_polys = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
     for c in (16, 17, 18, 19, 20, 21):
         ck = zk.CommitterKey(bases, cid, ctx).precompute(c)
         assert ck.table_window_bits() == c and 12 <= ck.table_windows() <= 16
+        if c == 17:
+            assert ck.table_windows() == 15      # BLS12-381: 16 without the folded scalars; BN254's 254 bits fit 15 either way
         batch = ck.commit_batch(d_polys)
         single = [ck.commit(p) for p in d_polys[:2]]
         ck.close()

@@ -133,6 +133,27 @@ ZK_D uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t pos, uint32_t c) {
 // the negated-scalar rule of MsmGeom::neg: k <- r - k when k > (r - 1) / 2; returns whether it did (the digits' signs flip)
 ZK_D bool scalar_fold(uint32_t (&k)[8], const MsmGeom& g) {
     if (!g.neg) return false;
+    // the ABI asks for canonical scalars, and the fold needs k < r: an unreduced k < 2^256 is brought below r first (at most 5
+    // subtractions for a 254-bit r), so it is still multiplied as k mod r instead of silently as garbage
+#pragma unroll 1
+    for (int it = 0; it < 6; ++it) {
+        bool ge = true, dec = false;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            if (!dec && k[i] != g.mod[i]) {
+                ge = k[i] > g.mod[i];
+                dec = true;
+            }
+        }
+        if (!ge) break;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t d = (uint64_t)k[i] - g.mod[i] - br;
+            k[i] = (uint32_t)d;
+            br = (uint32_t)(d >> 63);
+        }
+    }
     bool gt = false, decided = false;
 #pragma unroll
     for (int i = 7; i >= 0; --i) {

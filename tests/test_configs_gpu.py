@@ -155,6 +155,29 @@ def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
         assert single == batch[:2]
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_folded_scalars_accept_unreduced_input(cid, ctx, oracle_cpu):
+    """The ABI asks for canonical scalars.  The 15-window form of the c = 17 table folds k to r - k, which needs k < r, so it reduces an
+    unreduced scalar first: any k < 2^256 gives (k mod r) * P."""
+    import torch
+    n = 1 << 13
+    cv = bo.CURVES[cid]
+    pw_c, _ = tau_powers(oracle_cpu, cid, n)
+    bases = srs_from_powers(ctx, cid, pw_c)
+    bases_h = bases.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(17 + cid)
+    for c, top in ((17, 256),):
+        vals = [int.from_bytes(rng.bytes(32), "little") >> (256 - top) for _ in range(n)]     # uniform below 2^top: mostly >= r
+        vals[:6] = [cv.r, cv.r + 1, 2 * cv.r - 1, 2 * cv.r, (1 << top) - 1, cv.r - 1]
+        raw = zk.curves.ints_to_limbs(vals, 4)
+        red = zk.curves.ints_to_limbs([v % cv.r for v in vals], 4)
+        exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases_h, red)
+        ck = zk.CommitterKey(bases, cid, ctx).precompute(c)
+        got = ck.msm(torch.from_numpy(raw.view(np.int64)).cuda())
+        ck.close()
+        assert got.infinity == bool(exp_inf) and np.array_equal(got.xy(), exp_xy), c
+
+
 def test_table_window_20_identity_2_20(ctx, oracle_cpu):
     import torch
     cid, n = 0, 1 << 20

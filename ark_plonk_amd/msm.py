@@ -91,8 +91,9 @@ class CommitterKey:
         return self.n
 
     def precompute(self, window_bits: int = 0):
-        """Build the window-multiples table (16x the SRS in HBM at the default window c = 16); later MSMs share one
-        bucket set.  window_bits: 0 = default, else 16 .. 21 (fewer rows = fewer additions per scalar, more buckets)."""
+        """Build the window-multiples table; later MSMs share one bucket set.  window_bits: 0 = default (c = 16, 16 rows, below 2^19
+        points; c = 17 from there on: 15 rows for 255-bit scalars, which are folded to k <= (r - 1) / 2), else 16 .. 21 (fewer rows =
+        fewer additions per scalar, more buckets to reduce)."""
         self.ctx.use_torch_stream() if _has_torch_cuda() else None
         check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
         return self

@@ -76,7 +76,7 @@ impl GpuKZG10 {
             return None;
         }
         let handle = Arc::new(SrsHandle(srs));
-        // the window table (16 rows, 2 GiB per 2^20 points); idempotent: built once per distinct SRS
+        // the window table (15 rows of 17-bit windows from 2^19 points on: 1.9 GiB per 2^20 points); idempotent: built once per distinct SRS
         let rc = unsafe { sys::zk_srs_precompute(c, srs) };
         if check(rc).is_err() {
             return None; // no table: MSMs would still work, but the key then simply takes the CPU path

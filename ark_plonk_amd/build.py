@@ -21,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-mllvm", "-pragma-unroll-threshold=1000000", "-Wpass-failed"]
 
-FIELD_HDRS = ["field.cuh", "fieldu.cuh", "curve_params.h", "zk_common.h"]
+FIELD_HDRS = ["field.cuh", "fieldu.cuh", "fields.cuh", "curve_params.h", "zk_common.h"]
 HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ecu.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]
 
 

@@ -20,6 +20,7 @@
 #include "curve_params.h"
 #include "ec.cuh"
 #include "ecu.cuh"
+#include "fields.cuh"
 
 typedef Fp<FrBls12_381Params> FrBls;
 typedef Fp<FqBls12_381Params> FqBls;
@@ -31,7 +32,7 @@ struct CurveBls {
     typedef FqBls Fq;
     typedef FrBls12_381Params FrP;
     typedef FqBls12_381Params FqP;
-    typedef Fu<FqBls12_381UParams> FqU;   // device hot-path representation (29-bit limbs)
+    typedef Fs<FqBls12_381SParams> FqU;   // device representation of the MSM base field: 13 signed 30-bit limbs (fields.cuh)
     typedef Fu<FrBls12_381UParams> FrU;
     static constexpr int ID = ZK_CURVE_BLS12_381;
 };
@@ -40,7 +41,7 @@ struct CurveBn {
     typedef FqBn Fq;
     typedef FrBn254Params FrP;
     typedef FqBn254Params FqP;
-    typedef Fu<FqBn254UParams> FqU;
+    typedef Fs<FqBn254SParams> FqU;       // 9 signed 30-bit limbs
     typedef Fu<FrBn254UParams> FrU;
     static constexpr int ID = ZK_CURVE_BN254;
 };

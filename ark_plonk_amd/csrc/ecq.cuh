@@ -80,7 +80,7 @@ ZK_D F qadd(const F& p, const F& q, uint32_t role) {
     const F m3 = F::mul(role == 0 ? d : role == 1 ? bc_u1 : m2, fsel(role == 0, m2, bc_pp));
     // round 4: role1 X3 = RR - PPP - 2QQ, Y3 = R_*(QQ - X3) - S1*PPP (one double product); role3 ZZZ3 = ZZZ1*ZZZ2*PPP
     const F bc_ppp = quad_bcast(m3, 0);
-    const F x3 = F::sub8(m2, F::add3(bc_ppp, m3, m3));
+    const F x3 = F::sub_sum3(m2, bc_ppp, m3, m3);
     const bool r1 = role == 1;
     const F m4 = F::dot2(fsel(r1, d, m2), fsel(r1, F::sub16(m3, x3), bc_ppp), fsel(r1, F::neg16(m1), F::zero()), bc_ppp);
     const F x3_from_role1 = quad_xor(x3, 1);      // shuffles stay outside role-dependent control flow

@@ -91,7 +91,7 @@ struct XYZZu {
         }
         F ppp = F::mul(pp_, pp);
         F qq = F::mul(p.x, pp);
-        o.x = F::sub8(rr, F::add3(ppp, qq, qq));
+        o.x = F::sub_sum3(rr, ppp, qq, qq);
         o.y = F::dot2(r_, F::sub16(qq, o.x), F::neg16(p.y), ppp);   // r*(qq - x3) - y1*ppp, one reduction
         o.zzz = F::mul(p.zzz, ppp);
         return o;
@@ -117,7 +117,7 @@ struct XYZZu {
         }
         F ppp = F::mul(pp_, pp);
         F qq = F::mul(u1, pp);
-        o.x = F::sub8(rr, F::add3(ppp, qq, qq));
+        o.x = F::sub_sum3(rr, ppp, qq, qq);
         o.y = F::dot2(r_, F::sub16(qq, o.x), F::neg16(s1), ppp);
         o.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
         return o;

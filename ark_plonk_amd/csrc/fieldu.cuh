@@ -97,6 +97,8 @@ struct Fu {
         normalize(t);
         return t;
     }
+    // a - (b + c + d) + 8p, b + c + d < 8p (the X3 of the addition laws; fields.cuh does it with one carry step)
+    ZK_HD static Fu sub_sum3(const Fu& a, const Fu& b, const Fu& c, const Fu& d) { return sub8(a, add3(b, c, d)); }
     ZK_HD static Fu neg16(const Fu& a) {                 // 16p - a, a < 16p
         Fu t;
 #pragma unroll

@@ -5,6 +5,7 @@
 #include <cstring>
 #include "../../ark_plonk_amd/csrc/curve_params.h"
 #include "../../ark_plonk_amd/csrc/ecu.cuh"
+#include "../../ark_plonk_amd/csrc/fields.cuh"
 
 template <class F>
 static void fu_binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -63,18 +64,27 @@ typedef Fu<FqBls12_381UParams> FqB;
 typedef Fu<FrBls12_381UParams> FrB;
 typedef Fu<FqBn254UParams> FqN;
 typedef Fu<FrBn254UParams> FrN;
+typedef Fs<FqBls12_381SParams> FqBs;     // signed 30-bit limbs (fields.cuh)
+typedef Fs<FqBn254SParams> FqNs;
 
 extern "C" {
-// field: 0 Fq-BLS, 1 Fr-BLS, 2 Fq-BN, 3 Fr-BN
+// field: 0 Fq-BLS, 1 Fr-BLS, 2 Fq-BN, 3 Fr-BN (29-bit limbs); 4 Fq-BLS, 5 Fq-BN (signed 30-bit limbs)
 void fu_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     switch (field) {
     case 0: fu_binop<FqB>(op, a, b, out); break;
     case 1: fu_binop<FrB>(op, a, b, out); break;
     case 2: fu_binop<FqN>(op, a, b, out); break;
     case 3: fu_binop<FrN>(op, a, b, out); break;
+    case 4: fu_binop<FqBs>(op, a, b, out); break;
+    case 5: fu_binop<FqNs>(op, a, b, out); break;
     }
 }
 int fu_xyzz_chain(int curve, const uint32_t* pts_xy, const uint8_t* flags, int n, uint32_t* out_xy) {
-    return curve == 0 ? xyzz_chain<FqB>(pts_xy, flags, n, out_xy) : xyzz_chain<FqN>(pts_xy, flags, n, out_xy);
+    switch (curve) {
+    case 0: return xyzz_chain<FqB>(pts_xy, flags, n, out_xy);
+    case 1: return xyzz_chain<FqN>(pts_xy, flags, n, out_xy);
+    case 2: return xyzz_chain<FqBs>(pts_xy, flags, n, out_xy);
+    default: return xyzz_chain<FqNs>(pts_xy, flags, n, out_xy);
+    }
 }
 }

@@ -16,7 +16,7 @@ SO = os.path.join(ROOT, "tests", "native", "libfu_check.so")
 
 @pytest.fixture(scope="module")
 def fu():
-    deps = [SRC] + [os.path.join(ROOT, "ark_plonk_amd", "csrc", f) for f in ("fieldu.cuh", "ecu.cuh", "curve_params.h", "zk_common.h")]
+    deps = [SRC] + [os.path.join(ROOT, "ark_plonk_amd", "csrc", f) for f in ("fieldu.cuh", "fields.cuh", "ecu.cuh", "curve_params.h", "zk_common.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++", SRC, "-o", SO])
     L = ctypes.CDLL(SO)
@@ -25,7 +25,8 @@ def fu():
     return L
 
 
-FIELDS = {0: (bo.BLS12_381.q, 12), 1: (bo.BLS12_381.r, 8), 2: (bo.BN254.q, 8), 3: (bo.BN254.r, 8)}
+FIELDS = {0: (bo.BLS12_381.q, 12), 1: (bo.BLS12_381.r, 8), 2: (bo.BN254.q, 8), 3: (bo.BN254.r, 8),
+          4: (bo.BLS12_381.q, 12), 5: (bo.BN254.q, 8)}     # 4, 5: the signed 30-bit-limb form (fields.cuh)
 
 
 def words(v, n):
@@ -36,7 +37,7 @@ def unwords(a):
     return int.from_bytes(np.ascontiguousarray(a, dtype="<u4").tobytes(), "little")
 
 
-@pytest.mark.parametrize("field", [0, 1, 2, 3])
+@pytest.mark.parametrize("field", [0, 1, 2, 3, 4, 5])
 def test_field_ops(field, fu):
     p, n = FIELDS[field]
     R = 1 << (32 * n)
@@ -53,7 +54,7 @@ def test_field_ops(field, fu):
             5: pow(x, -1, p) if x else 0, 6: (-x) % p, 7: 2 * x % p,
             8: pow(((x - y) * (2 * x + y) - x * y) % p, 2, p),
         }
-        if field in (0, 2):   # dot2 is for the base fields (reduction slack >= 12 bits)
+        if field in (0, 2, 4, 5):   # dot2 is for the base fields (reduction slack >= 12 bits)
             exp[9] = (x * y + (x - y) * (2 * x + y)) % p
             exp[10] = (x * y - y * y) % p
         wa, wb = words(xm, n), words(ym, n)   # keep the buffers alive across the call
@@ -64,9 +65,9 @@ def test_field_ops(field, fu):
             assert got == e, (field, op, hex(x), hex(y))
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_xyzz_chain_matches_affine_group_law(cid, fu):
-    cv = bo.CURVES[cid]
+    cv = bo.CURVES[cid & 1]          # 2, 3: the same curves over the signed 30-bit-limb field
     W = 2 * cv.fq_limbs
     R = cv.fq_R
     G = (cv.gx, cv.gy)

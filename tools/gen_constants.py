@@ -125,6 +125,64 @@ def unsat_struct(sname, p, nl, sat_words):
     return "\n".join(out)
 
 
+SB = 30  # signed (balanced) limb width of the MSM base-field representation (fields.cuh)
+
+
+def balanced(x, n):
+    """digits d_i of the integer x (any sign): d_i in [-2^29, 2^29) for i < n-1, the top digit takes the rest"""
+    out = []
+    for _ in range(n - 1):
+        d = x & ((1 << SB) - 1)
+        if d >= 1 << (SB - 1):
+            d -= 1 << SB
+        out.append(d)
+        x = (x - d) >> SB
+    out.append(x)
+    return out
+
+
+def signed_struct(sname, p, nl, sat_words):
+    """Parameters of the signed 30-bit-limb Montgomery representation (R' = 2^(30*nl)), fields.cuh.
+    Checks the column bound of Fs::mul / Fs::dot2 with the digits of THIS modulus: every product-scanning column must
+    stay inside a signed 64-bit accumulator."""
+    Rp = 1 << (SB * nl)
+    Rs = 1 << (32 * sat_words)
+    pd = balanced(p, nl)
+    assert sum(d << (SB * i) for i, d in enumerate(pd)) == p
+    # operands: "almost balanced" digits |d| <= 2^29 + 4, |value| < 12 p; m digits in [-2^29, 2^29)
+    A = (1 << 29) + 4
+    a = [A] * (nl - 1) + [(12 * p >> (SB * (nl - 1))) + 2]
+    m = [1 << 29] * nl
+    for k in range(2 * nl - 1):
+        ab = sum(a[i] * a[k - i] for i in range(nl) if 0 <= k - i < nl)
+        mp = sum(m[i] * abs(pd[k - i]) for i in range(nl) if 0 <= k - i < nl)
+        assert 2 * ab + mp + (1 << 36) < (1 << 63), (sname, k)      # dot2: two products + the reduction + carry + bias
+    assert Rp // p >= 512          # |a||b| / R' stays far below p/2 for |a|, |b| < 12 p: products come out in (-p, p)
+    pinv = (-pow(p, -1, 1 << SB)) % (1 << SB)
+    out = [f"struct {sname} {{"]
+    out.append(f"    static constexpr int NL = {nl};                 // signed 30-bit limbs")
+    out.append(f"    static constexpr int SAT_WORDS = {sat_words};          // 32-bit words of the arkworks layout")
+    out.append(f"    static constexpr uint32_t PINV = 0x{pinv:08x}u;     // -p^-1 mod 2^30")
+    consts = {
+        "MOD": pd,                                               # p
+        "NMOD": balanced(-p, nl),                                # -p
+        "ONE": balanced(Rp % p, nl),                             # Montgomery one (R' mod p)
+        "C_IN": balanced(Rp * Rp * pow(Rs, -1, p) % p, nl),      # x*R (arkworks form) -> x*R' : montmul by R'^2/R
+        "C_OUT": balanced(Rs % p, nl),                           # x*R' -> x*R : montmul by R
+    }
+    for cname, vals in consts.items():
+        out.append(f"    ZK_HD static constexpr int32_t {cname}(int i) {{")
+        out.append(f"        constexpr int32_t t[{nl}] = {{{', '.join(str(v) for v in vals)}}};")
+        out.append("        return t[i];")
+        out.append("    }")
+    out.append("    ZK_HD static constexpr uint32_t MODW(int i) {          // p as 32-bit words")
+    out.append(f"        constexpr uint32_t t[{sat_words}] = {{{arr(p, sat_words)}}};")
+    out.append("        return t[i];")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     o = []
     o.append("// GENERATED by tools/gen_constants.py -- do not edit. All values derived from the moduli.")
@@ -171,6 +229,9 @@ def main():
         o.append(unsat_struct(f"Fq{c['name']}UParams", q, nl_q, nq))
         o.append("")
         o.append(unsat_struct(f"Fr{c['name']}UParams", r, nl_r, nr))
+        o.append("")
+        # signed 30-bit limbs for the MSM base field: one or two limbs fewer than the 29-bit form
+        o.append(signed_struct(f"Fq{c['name']}SParams", q, -(-(q.bit_length() + 5) // SB), nq))
         o.append("")
     sys.stdout.write("\n".join(o) + "\n")
 

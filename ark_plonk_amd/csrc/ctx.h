@@ -19,8 +19,8 @@
 #include "../../include/ark_plonk_amd.h"
 #include "curve_params.h"
 #include "ec.cuh"
+#include "fieldu.cuh"
 #include "ecu.cuh"
-#include "fields.cuh"
 
 typedef Fp<FrBls12_381Params> FrBls;
 typedef Fp<FqBls12_381Params> FqBls;

@@ -1,21 +1,23 @@
-// G1 group law (a = 0) over the unsaturated field type Fu -- the device form of ec.cuh.
+// G1 group law (a = 0) over the signed-limb base field Fs (fields.cuh) -- the device form of ec.cuh.
 //
 // Same formulas as ec.cuh (madd-2008-s / add-2008-s / dbl-2008-s-1, XYZZ coordinates) with the lazy
-// reduction calculus of fieldu.cuh:
-//   * products and squares are < 2p; stored coordinates are X, Y < 10p and ZZ, ZZZ < 2p;
-//   * a difference whose subtrahend is a product (or a sum of <= 3 products) uses sub8,
-//     a difference whose subtrahend is a stored coordinate uses sub16;
-//   * Y3 = R*(Q - X3) - Y1*PPP is ONE double product with one Montgomery reduction (Fu::dot2 against
-//     16p - Y1), so Y3 < 2p;
-//   * P == +-Q is detected on the *result*: ZZ3 = ZZ1*PP is a product (< 2p), so ZZ3 == 0 mod p
-//     iff it equals 0 or p -- two compares on one limb in the common path.
+// reduction calculus of fields.cuh: limbs are signed, so a difference is just a difference, and
+//   * products and squares come out in (-p, p) with strict limbs; stored coordinates are |X| < 4p (a
+//     sum of four products, almost-balanced limbs) and Y, ZZ, ZZZ products;
+//   * every operand of a product is a product, a stored coordinate or ONE sum / difference of those
+//     (|value| < 12p, limbs re-centred by one carry step) -- the bound fields.cuh asks for;
+//   * Y3 = R*(Q - X3) - Y1*PPP is ONE double product with one Montgomery reduction (dot2 against -Y1);
+//   * P == +-Q is detected on the *result*: ZZ3 = ZZ1*PP is a product, so ZZ3 == 0 mod p iff its strict
+//     limbs are those of 0 (or +-p) -- compares on one limb in the common path.
+// The names sub8 / sub16 / neg16 are kept from the unsigned form (they said which multiple of p kept a
+// difference positive there); over Fs they are all plain limb-wise differences.
 // Infinity is ZZ = 0 with all limbs zero (only ever created explicitly).
 #pragma once
-#include "fieldu.cuh"
+#include "fields.cuh"
 
 template <class F>
 struct AffineU {
-    F x, y;  // canonical (< p) residues in the R' Montgomery domain; x = y = 0 limbs encodes "no point"
+    F x, y;  // residues in (-p, p), strict limbs, R' Montgomery domain; x = y = 0 limbs encodes "no point"
     ZK_HD bool is_null() const { return x.limbs_zero() && y.limbs_zero(); }
 };
 

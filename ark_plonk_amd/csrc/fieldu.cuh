@@ -1,4 +1,5 @@
-// Unsaturated (29-bit limb) Montgomery arithmetic for the gfx950 hot paths.
+// Unsaturated (29-bit limb) Montgomery arithmetic for the scalar field on gfx950: the NTT butterflies, the KZG witness /
+// evaluation kernels, the quotient and grand-product kernels.  (The MSM's base field uses signed 30-bit limbs: fields.cuh.)
 //
 // Why: measured on MI355X (profiles/r01_ubench_valu.txt) v_mad_u64_u32 issues in 4 cycles per
 // wave-instruction -- the same as one v_add_co/v_addc -- so in a saturated 32-bit-limb CIOS the carry
@@ -10,11 +11,10 @@
 //
 // Representation: value = sum v[i] * 2^(29 i), NL limbs, Montgomery radix R' = 2^(29 NL).
 // "Normalised" = v[i] < 2^29 for i < NL-1.  Every routine here returns normalised limbs.
-// Bounds (SLACK_BITS >= 12 fields, i.e. the base fields): mul/sqr inputs < 64p -> output < 2p.
-// sub8(a,b) = a - b + 8p needs b < 8p; sub16 needs b < 16p.
+// sub8(a,b) = a - b + 8p needs b < 8p; sub16 needs b < 16p; the callers state their bounds.
 //
-// Stands behind ark-ff 0.3 Fp384/Fp256 arithmetic inside VariableBaseMSM (commitment.rs:45) and the
-// NTT butterflies (prover.rs:196-203); arkworks-format values cross in/out through from_sat/to_sat.
+// Stands behind ark-ff 0.3 Fp256 arithmetic in the NTT butterflies (prover.rs:196-203) and the polynomial
+// kernels; arkworks-format values cross in/out through from_sat/to_sat.
 #pragma once
 #include "zk_common.h"
 
@@ -97,8 +97,6 @@ struct Fu {
         normalize(t);
         return t;
     }
-    // a - (b + c + d) + 8p, b + c + d < 8p (the X3 of the addition laws; fields.cuh does it with one carry step)
-    ZK_HD static Fu sub_sum3(const Fu& a, const Fu& b, const Fu& c, const Fu& d) { return sub8(a, add3(b, c, d)); }
     ZK_HD static Fu neg16(const Fu& a) {                 // 16p - a, a < 16p
         Fu t;
 #pragma unroll
@@ -144,45 +142,6 @@ struct Fu {
             for (int i = k - NL + 1; i < NL; ++i) {
                 if (i & 1) a1 += (uint64_t)a.v[i] * b.v[k - i];
                 else a0 += (uint64_t)a.v[i] * b.v[k - i];
-                am += (uint64_t)m[i] * P::MOD(k - i);
-            }
-            uint64_t t = a0 + a1 + am + carry;
-            r.v[k - NL] = (uint32_t)t & M;
-            carry = t >> 29;
-        }
-        r.v[NL - 1] = (uint32_t)carry;
-        return r;
-    }
-    // (a*b + c*d)/R' with ONE Montgomery reduction (saves the NL^2 m*p products of a second one).
-    // Three independent accumulator chains per column; column total < 3*NL*2^58 + carry < 2^64 (NL <= 16).
-    // Output < (a*b + c*d)/R' + p: below 2p whenever a*b + c*d < R'*p -- use only on fields with
-    // SLACK_BITS >= 12 (the base fields), where that allows e.g. 1000p * 1000p.
-    ZK_HD static Fu dot2(const Fu& a, const Fu& b, const Fu& c, const Fu& d) {
-        uint32_t m[NL];
-        Fu r;
-        uint64_t carry = 0;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            uint64_t a0 = 0, a1 = 0, am = 0;
-#pragma unroll
-            for (int i = 0; i <= k; ++i) {
-                a0 += (uint64_t)a.v[i] * b.v[k - i];
-                a1 += (uint64_t)c.v[i] * d.v[k - i];
-            }
-#pragma unroll
-            for (int i = 0; i < k; ++i) am += (uint64_t)m[i] * P::MOD(k - i);
-            uint64_t t = a0 + a1 + am + carry;
-            m[k] = ((uint32_t)t * P::PINV) & M;
-            t += (uint64_t)m[k] * P::MOD(0);
-            carry = t >> 29;
-        }
-#pragma unroll
-        for (int k = NL; k < 2 * NL - 1; ++k) {
-            uint64_t a0 = 0, a1 = 0, am = 0;
-#pragma unroll
-            for (int i = k - NL + 1; i < NL; ++i) {
-                a0 += (uint64_t)a.v[i] * b.v[k - i];
-                a1 += (uint64_t)c.v[i] * d.v[k - i];
                 am += (uint64_t)m[i] * P::MOD(k - i);
             }
             uint64_t t = a0 + a1 + am + carry;

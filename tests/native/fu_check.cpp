@@ -1,11 +1,20 @@
-// Host-side harness for the unsaturated field / lazy XYZZ code (fieldu.cuh, ecu.cuh): the same
+// Host-side harness for the unsaturated fields / lazy XYZZ code (fieldu.cuh, fields.cuh, ecu.cuh): the same
 // templates the HIP kernels instantiate, compiled with g++ so tests/test_fieldu.py can check them
 // against the big-int oracle without a GPU.
 #include <cstdint>
 #include <cstring>
 #include "../../ark_plonk_amd/csrc/curve_params.h"
+#include "../../ark_plonk_amd/csrc/fieldu.cuh"
 #include "../../ark_plonk_amd/csrc/ecu.cuh"
-#include "../../ark_plonk_amd/csrc/fields.cuh"
+
+template <class F>
+static void fs_dot2(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    F x = F::from_sat(a), y = F::from_sat(b), r;
+    if (op == 9) r = F::dot2(x, y, F::sub16(x, y), F::add3(x, x, y));       // x*y + (x - y)(2x + y) with one reduction
+    else if (op == 10) r = F::dot2(x, y, F::neg16(y), y);                   // x*y - y*y through the negated operand
+    else r = F::sub_sum3(F::mul(x, y), F::sqr(x), F::sqr(y), F::mul(x, x));  // xy - 2x^2 - y^2, one carry step
+    r.to_sat(out);
+}
 
 template <class F>
 static void fu_binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -24,12 +33,6 @@ static void fu_binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out
         r = F::sqr(F::sub8(t, F::mul(x, y)));
         break;
     }
-    case 9:  // x*y + (x - y)(2x + y) with one reduction
-        r = F::dot2(x, y, F::sub16(x, y), F::add3(x, x, y));
-        break;
-    case 10:  // x*y - y*y through the negated operand
-        r = F::dot2(x, y, F::neg16(y), y);
-        break;
     default: r = F::zero();
     }
     r.to_sat(out);
@@ -60,31 +63,22 @@ static int xyzz_chain(const uint32_t* pts_xy, const uint8_t* flags /* bit0 negat
     return fin ? 0 : 1;
 }
 
-typedef Fu<FqBls12_381UParams> FqB;
-typedef Fu<FrBls12_381UParams> FrB;
-typedef Fu<FqBn254UParams> FqN;
+typedef Fu<FrBls12_381UParams> FrB;      // 29-bit limbs (fieldu.cuh): the scalar fields
 typedef Fu<FrBn254UParams> FrN;
-typedef Fs<FqBls12_381SParams> FqBs;     // signed 30-bit limbs (fields.cuh)
+typedef Fs<FqBls12_381SParams> FqBs;     // signed 30-bit limbs (fields.cuh): the base fields
 typedef Fs<FqBn254SParams> FqNs;
 
 extern "C" {
-// field: 0 Fq-BLS, 1 Fr-BLS, 2 Fq-BN, 3 Fr-BN (29-bit limbs); 4 Fq-BLS, 5 Fq-BN (signed 30-bit limbs)
+// field: 0 Fq-BLS, 2 Fq-BN (signed 30-bit limbs); 1 Fr-BLS, 3 Fr-BN (29-bit limbs)
 void fu_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     switch (field) {
-    case 0: fu_binop<FqB>(op, a, b, out); break;
+    case 0: op >= 9 ? fs_dot2<FqBs>(op, a, b, out) : fu_binop<FqBs>(op, a, b, out); break;
     case 1: fu_binop<FrB>(op, a, b, out); break;
-    case 2: fu_binop<FqN>(op, a, b, out); break;
+    case 2: op >= 9 ? fs_dot2<FqNs>(op, a, b, out) : fu_binop<FqNs>(op, a, b, out); break;
     case 3: fu_binop<FrN>(op, a, b, out); break;
-    case 4: fu_binop<FqBs>(op, a, b, out); break;
-    case 5: fu_binop<FqNs>(op, a, b, out); break;
     }
 }
 int fu_xyzz_chain(int curve, const uint32_t* pts_xy, const uint8_t* flags, int n, uint32_t* out_xy) {
-    switch (curve) {
-    case 0: return xyzz_chain<FqB>(pts_xy, flags, n, out_xy);
-    case 1: return xyzz_chain<FqN>(pts_xy, flags, n, out_xy);
-    case 2: return xyzz_chain<FqBs>(pts_xy, flags, n, out_xy);
-    default: return xyzz_chain<FqNs>(pts_xy, flags, n, out_xy);
-    }
+    return curve == 0 ? xyzz_chain<FqBs>(pts_xy, flags, n, out_xy) : xyzz_chain<FqNs>(pts_xy, flags, n, out_xy);
 }
 }

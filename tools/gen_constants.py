@@ -221,16 +221,11 @@ def main():
         fq_s, _, _ = field_struct(f"Fq{c['name']}Params", q, "\n".join(extra))
         o.append(fq_s)
         o.append("")
-        # unsaturated (device hot path) parameters; limb counts chosen for >= 12 slack bits on Fq
-        nl_q = -(-q.bit_length() // LB)
-        while LB * nl_q - q.bit_length() < 12:
-            nl_q += 1
+        # unsaturated 29-bit limbs for the scalar field (NTT and polynomial kernels)
         nl_r = -(-r.bit_length() // LB)
-        o.append(unsat_struct(f"Fq{c['name']}UParams", q, nl_q, nq))
-        o.append("")
         o.append(unsat_struct(f"Fr{c['name']}UParams", r, nl_r, nr))
         o.append("")
-        # signed 30-bit limbs for the MSM base field: one or two limbs fewer than the 29-bit form
+        # signed 30-bit limbs for the MSM base field
         o.append(signed_struct(f"Fq{c['name']}SParams", q, -(-(q.bit_length() + 5) // SB), nq))
         o.append("")
     sys.stdout.write("\n".join(o) + "\n")

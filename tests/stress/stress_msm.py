@@ -38,7 +38,9 @@ def run(budget: float = 120.0, seed: int = 1, ctx=None, max_log_n: int = 17):
         bases_h = bases.cpu().numpy().view(np.uint64)
         ck = zk.CommitterKey(bases, cid, ctx)
         if rng.random() < 0.8:
-            ck.precompute()
+            # default window, or the forms the default only takes at 2^19 points and above: c = 17 (folded scalars on BLS12-381,
+            # int32 sort), and now and then the wide reduction (c = 18)
+            ck.precompute(int(rng.choice([0, 0, 17, 17, 18])))
         k = int(rng.integers(1, 8))
         polys = []
         for _ in range(k):

@@ -45,15 +45,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # The kernel is integer-VALU bound (SURVEY.md 8d asks for the u32-MAC rate next to the HBM fraction).
 # Instruction counts of the mixed-addition path of msm_accumulate (gfx950 ISA of this build, BLS12-381:
-# 6 products + 2 squares + 1 double product of 14 x 29-bit limbs) and the measured issue costs of
-# profiles/r01_ubench_valu.txt.
-MADD_MADS = 3542            # v_mad_u64_u32 per mixed addition
-MADD_OTHER_VALU = 1221      # and/shift/add/mul_lo around them
+# 6 products + 2 squares + 1 double product of 13 signed 30-bit limbs, csrc/fields.cuh) and the measured issue
+# costs of profiles/r01_ubench_valu.txt.
+MADD_MADS = 3055            # v_mad_i64_i32 per mixed addition
+MADD_OTHER_VALU = 1299      # 64-bit shift / add, mul_lo, digit and carry-step instructions around them
 CLOCK_HZ = 2.4e9            # MI355X max engine clock (MI355X_MICROARCH.md chip table)
 LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
 MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
-# issue cycles of one mixed addition at the kernel's 2 waves/SIMD (220 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
-MADD_CYCLES_2WAVES = 3542 * 4.77 + 126 * 4.70 + 468 * 4.45 + 627 * 2.64
+# issue cycles of one mixed addition at the kernel's 2 waves/SIMD (215 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
+MADD_CYCLES_2WAVES = 3055 * 4.77 + 117 * 4.70 + 492 * 4.45 + 690 * 2.64
 # measured on MI355X (tools/experiments/clock_probe.hip, profiles/r02_clock_probe.txt): what a stream of nothing but independent
 # v_mad_u64_u32 reaches, by HIP events, at 2 and at 8 waves per SIMD -- the nominal 16 lanes x 1024 SIMDs x 2.4 GHz is 3.93e13
 PURE_MAD_RATE_2_WAVES = 2.66e13
@@ -465,8 +465,9 @@ def main():
                 "issue_bound_mixed_adds_per_s_at_2_waves_per_simd": bound2, "frac_of_issue_bound": madds / avg_s / bound2,
                 "mads_vs_measured_pure_mad_stream_at_2_waves_per_simd": mac_s / PURE_MAD_RATE_2_WAVES,
                 "mads_vs_measured_pure_mad_stream_at_8_waves_per_simd": mac_s / PURE_MAD_RATE_8_WAVES,
-                "note": "the kernel issues 1221 other vector instructions per 3542 mads on top of this mad rate; a 3-waves-per-SIMD variant "
-                        "(166 VGPRs) was measured no faster: bound by the vector pipe at the clock the chip holds, not by occupancy (profiles/r02_notes.md)"}
+                "note": "the kernel issues 1299 other vector instructions per 3055 multiply-adds on top of this rate, and at two waves per SIMD a 64-bit "
+                        "shift or add costs what a multiply-add costs (profiles/r01_ubench_valu.txt): the count that matters is all of them "
+                        "(profiles/r03_notes.md)"}
     kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
     S = r["streams"]
     if world == 1:

@@ -1924,17 +1924,27 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     // L = 128 / 64 / 32 / 16 -> 111.8 / 110.3 / 110.8 / 162 ms per proof; 16 overloads the combine)
     pl.chunk_l = PRE_CHUNK_L;
     while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 196608) pl.chunk_l >>= 1;
+    bool tuned = false;
     if (const char* e = getenv("ZK_CHUNK_L")) {          // tuning hook (profiles/r02_notes.md)
         const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 8 && v <= 1024) pl.chunk_l = v;
+        if (v >= 8 && v <= 1024) {
+            pl.chunk_l = v;
+            tuned = true;
+        }
     }
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
     // whole rounds of resident lanes: every lane does the same work, so 1.9 rounds take as long as 2 (15 windows of 2^20 digits
-    // at 64 per lane are 245760 lanes): round the lane count up to a multiple of a round and shorten the chunks instead
+    // at 64 per lane are 245760 lanes): round the lane count up to a multiple of a round and shorten the chunks instead.
+    // Two rounds become three where the chunks stay >= 32 references: the end of the launch, where CUs wait for their last
+    // wavefronts, shortens with the chunk (2^20, c = 17: 60 -> 40 per lane, msm_accumulate -2.5 % per launch, msm_combine* +7
+    // partials per bucket instead of 5, net +0.5 .. 0.8 % proofs/s; 30 and 24 per lane give the accumulation another 1 % and
+    // the combine more than that back: profiles/r03_notes.md)
     {
         constexpr uint32_t ROUND = 131072;
         if (pl.n_lanes > ROUND) {
-            pl.n_lanes = (pl.n_lanes + ROUND - 1) / ROUND * ROUND;
+            uint32_t rounds = (pl.n_lanes + ROUND - 1) / ROUND;
+            if (!tuned && rounds == 2 && pl.nf / (3ull * ROUND) >= 32) rounds = 3;
+            pl.n_lanes = rounds * ROUND;
             pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
         }
     }

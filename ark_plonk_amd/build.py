@@ -41,7 +41,9 @@ def jobs():
         ("msm_dispatch.o", "msm_dispatch.hip", [], HOST_HDRS),
     ]
     for c in (0, 1):
-        out.append((f"msm_c{c}.o", "msm.hip", [f"-DZK_CURVE_SEL={c}"], HOST_HDRS + ["ecq.cuh"]))
+        # ARK_PLONK_AMD_MSM_FLAGS: extra compiler flags for the MSM objects only (scheduler experiments: tools/ab_bench.sh)
+        out.append((f"msm_c{c}.o", "msm.hip", [f"-DZK_CURVE_SEL={c}"] + os.environ.get("ARK_PLONK_AMD_MSM_FLAGS", "").split(),
+                    HOST_HDRS + ["ecq.cuh"]))
         for s in range(3, 10):
             out.append((f"ntt_pass_c{c}_s{s}.o", "ntt_pass_inst.hip", [f"-DZK_CURVE_SEL={c}", f"-DZK_NTT_S={s}"],
                         FIELD_HDRS + ["ntt_pass.cuh"]))

@@ -281,7 +281,7 @@ struct zk_srs {
     uint64_t digest[4] = {0, 0, 0, 0};
     int curve = 0;
     size_t n = 0;
-    void* d_xy = nullptr;   // n points in the device-internal form (2 x Fu, 29-bit limbs, padded to 16 B);
+    void* d_xy = nullptr;   // n points in the device-internal form (2 x Fs, signed 30-bit limbs, padded to 16 B);
                             // "no point" (infinity) is all-zero limbs
     size_t point_bytes = 0;
     // optional table of window multiples 2^(c*w) * P_i, w = 1 .. pre_W-1, window-major (n points each);

@@ -1,7 +1,7 @@
 // Quad-cooperative XYZZ arithmetic for the latency-bound bucket-reduction kernels.
 //
 // A point lives in 4 adjacent lanes of a wavefront; lane role r = lane & 3 holds ONE coordinate:
-//   r = 0: X    r = 1: Y    r = 2: ZZ    r = 3: ZZZ          (F = Fu<...>, 14 registers instead of 56)
+//   r = 0: X    r = 1: Y    r = 2: ZZ    r = 3: ZZZ          (F = Fs<...>, 13 registers instead of 52)
 // The 12 products + 1 double product of an addition have dependency depth 4, so the four lanes run
 // them as four rounds of ONE field product each (every lane executes the same instruction stream on
 // its own operands; operands move between the lanes of a quad with quad shuffles, no LDS, no
@@ -10,7 +10,7 @@
 // issues a v_mad_u64_u32 only every ~9.5 cycles -- latency, not throughput, is what they pay for.
 //
 // Formulas and bounds are those of ecu.cuh (add-2008-s / dbl-2008-s-1 with the lazy calculus of
-// fieldu.cuh); the rare P = +-Q case is resolved with the quad doubling / infinity.
+// fields.cuh); the rare P = +-Q case is resolved with the quad doubling / infinity.
 #pragma once
 #include "ecu.cuh"
 

@@ -19,7 +19,7 @@
 //   6. msm_win_finish LDS suffix-scan + tree reduction per (virtual) window -> window sums (arkworks layout)
 //   host: the few window sums are combined (table path: sum of 32 virtual windows; per-window path:
 //         Horner with W*c doublings) and normalised to affine.
-// Device arithmetic is the unsaturated 29-bit-limb Montgomery field of fieldu.cuh with the lazy XYZZ
+// Device arithmetic is the signed 30-bit-limb Montgomery field of fields.cuh with the lazy XYZZ
 // group law of ecu.cuh; bases are converted once, at SRS registration, into that form.
 // The group sum is order-independent, so the non-deterministic order inside a bucket (atomic
 // cursors) does not change the (canonical, affine) result.
@@ -32,7 +32,7 @@
 
 namespace {
 
-// ---- device storage of an Fu: NL limbs padded to a multiple of 4 words (16-byte vector access)
+// ---- device storage of a field element (Fs, fields.cuh): NL limbs padded to a multiple of 4 words (16-byte vector access)
 template <class F>
 struct Store {
     static constexpr int U4 = (F::NL + 3) / 4;      // uint4 per field element

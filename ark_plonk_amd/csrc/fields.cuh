@@ -63,7 +63,8 @@ struct Fs {
     }
 
     // one carry step, every limb at once: a limb keeps its balanced low 30 bits and takes the carry of the limb
-    // below (computed from that limb's value BEFORE the step).  |in| < 2^31 - 2^29  ->  |out| <= 2^29 + 2.
+    // below (computed from that limb's value BEFORE the step).  |in| < 2^31 - 2^29 (sums and differences of TWO operands)
+    // ->  |out| <= 2^29 + 2.
     ZK_HD static void normalize(Fs& t) {
         int32_t c = 0;
 #pragma unroll
@@ -72,6 +73,18 @@ struct Fs {
             const int32_t r = sx((uint32_t)x);
             t.v[i] = (uint32_t)(r + c);
             c = (x - r) >> 30;
+        }
+        t.v[NL - 1] += (uint32_t)c;
+    }
+    // the same step for limbs anywhere in int32 (sums of three or four operands): x - sx(x) can leave 32 bits there, so the
+    // carry is taken as floor(x / 2^30) + bit 29 of x -- one instruction more per limb
+    ZK_HD static void normalize_wide(Fs& t) {
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < NL - 1; ++i) {
+            const int32_t x = (int32_t)t.v[i];
+            t.v[i] = (uint32_t)(sx((uint32_t)x) + c);
+            c = (x >> 30) + (int32_t)(((uint32_t)x >> 29) & 1u);
         }
         t.v[NL - 1] += (uint32_t)c;
     }
@@ -104,7 +117,7 @@ struct Fs {
         Fs t;
 #pragma unroll
         for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] + b.v[i] + c.v[i];
-        normalize(t);
+        normalize_wide(t);
         return t;
     }
     ZK_HD static Fs sub(const Fs& a, const Fs& b) {
@@ -114,21 +127,12 @@ struct Fs {
         normalize(t);
         return t;
     }
-    // a - (b + c + d) with one carry step.  Strict operands: a limb of the raw result is in [-2^31 + 3, 2^31 - 1], where
-    // x - sx(x) can leave 32 bits, so the carry is taken as floor(x / 2^30) + bit 29 of x instead.
+    // a - (b + c + d) with one carry step.  Strict operands: a limb of the raw result is in [-2^31 + 3, 2^31 - 1].
     ZK_HD static Fs sub_sum3(const Fs& a, const Fs& b, const Fs& c, const Fs& d) {
         Fs t;
-        int32_t cy = 0;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int32_t x = (int32_t)(a.v[i] - b.v[i] - c.v[i] - d.v[i]);
-            if (i < NL - 1) {
-                t.v[i] = (uint32_t)(sx((uint32_t)x) + cy);
-                cy = (x >> 30) + (int32_t)(((uint32_t)x >> 29) & 1u);
-            } else {
-                t.v[i] = (uint32_t)(x + cy);
-            }
-        }
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] - b.v[i] - c.v[i] - d.v[i];
+        normalize_wide(t);
         return t;
     }
     // the names the group law uses with Fu (there they say which multiple of p keeps the difference positive)

@@ -68,7 +68,33 @@ typedef Fu<FrBn254UParams> FrN;
 typedef Fs<FqBls12_381SParams> FqBs;     // signed 30-bit limbs (fields.cuh): the base fields
 typedef Fs<FqBn254SParams> FqNs;
 
+// raw signed-limb operands (no conversion on the way in): the worst-case limb patterns of the column bounds of fields.cuh.
+// op 0: mul(a, b)   1: sqr(a)   2: dot2(a, b, c, d)   3: sub_sum3(a, b, c, d) (strict operands)   4: add3 / sub chains
+template <class F>
+static void fs_raw(int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, int32_t* out) {
+    F x, y, z, w, r;
+    for (int i = 0; i < F::NL; ++i) {
+        x.v[i] = (uint32_t)a[i];
+        y.v[i] = (uint32_t)b[i];
+        z.v[i] = (uint32_t)c[i];
+        w.v[i] = (uint32_t)d[i];
+    }
+    switch (op) {
+    case 0: r = F::mul(x, y); break;
+    case 1: r = F::sqr(x); break;
+    case 2: r = F::dot2(x, y, z, w); break;
+    case 3: r = F::sub_sum3(x, y, z, w); break;
+    default: r = F::sub16(F::add3(x, y, z), w); break;
+    }
+    for (int i = 0; i < F::NL; ++i) out[i] = (int32_t)r.v[i];
+}
+
 extern "C" {
+int fs_limbs(int field) { return field == 0 ? FqBs::NL : FqNs::NL; }
+void fs_raw_op(int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, int32_t* out) {
+    if (field == 0) fs_raw<FqBs>(op, a, b, c, d, out);
+    else fs_raw<FqNs>(op, a, b, c, d, out);
+}
 // field: 0 Fq-BLS, 2 Fq-BN (signed 30-bit limbs); 1 Fr-BLS, 3 Fr-BN (29-bit limbs)
 void fu_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     switch (field) {

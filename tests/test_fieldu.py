@@ -23,6 +23,7 @@ def fu():
     L = ctypes.CDLL(SO)
     L.fu_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.fu_xyzz_chain.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.fs_raw_op.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
     return L
 
 
@@ -118,3 +119,57 @@ def test_xyzz_chain_matches_affine_group_law(cid, fu):
     ]
     for seq in cases:
         assert run(seq) == expect(seq), seq
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_signed_limbs_at_the_edge_of_the_column_bound(field, fu):
+    """fields.cuh promises: operands with |limb| <= 2^29 + 2 and |value| < 12p go through mul / sqr / dot2 without leaving the signed
+    64-bit column, and come out with strict limbs in (-p, p).  Raw limb patterns (no conversion on the way in): every limb at +-(2^29 + 2)
+    in all sign combinations that matter (all equal, alternating, one against the other), the top limb at +-12p's, plus random ones."""
+    p = bo.BLS12_381.q if field == 0 else bo.BN254.q
+    nl = fu.fs_limbs(field)
+    Rp = 1 << (30 * nl)
+    E = (1 << 29) + 2
+    top = (12 * p >> (30 * (nl - 1))) - 1
+    rng = np.random.default_rng(field + 77)
+
+    def val(l):
+        return sum(int(v) << (30 * i) for i, v in enumerate(l))
+
+    def pat(kind):
+        if kind == 0:
+            l = [E] * (nl - 1) + [top]
+        elif kind == 1:
+            l = [-E] * (nl - 1) + [-top]
+        elif kind == 2:
+            l = [E if i % 2 == 0 else -E for i in range(nl - 1)] + [top]
+        elif kind == 3:
+            l = [-E if i % 2 == 0 else E for i in range(nl - 1)] + [-top]
+        else:
+            l = [int(v) for v in rng.integers(-E, E + 1, size=nl - 1)] + [int(rng.integers(-top, top + 1))]
+        return np.array(l, dtype=np.int32)
+
+    def strict(l, hi=1):
+        return all(-(1 << 29) <= int(v) < (1 << 29) for v in l[:-1]) and abs(val(l)) < hi * p
+
+    out = np.zeros(nl, dtype=np.int32)
+    kinds = [0, 1, 2, 3, 4, 4, 4]
+    for ka in kinds:
+        for kb in kinds:
+            a, b, c, d = pat(ka), pat(kb), pat(kb if ka < 4 else 4), pat(ka if kb < 4 else 4)
+            A, B, C, D = val(a), val(b), val(c), val(d)
+            fu.fs_raw_op(field, 0, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data)
+            assert strict(out) and (val(out) * Rp - A * B) % p == 0, ("mul", ka, kb)
+            fu.fs_raw_op(field, 1, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data)
+            assert strict(out) and (val(out) * Rp - A * A) % p == 0, ("sqr", ka)
+            fu.fs_raw_op(field, 2, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data)
+            assert strict(out) and (val(out) * Rp - A * B - C * D) % p == 0, ("dot2", ka, kb)
+            fu.fs_raw_op(field, 4, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data)
+            assert val(out) == A + B + C - D and all(abs(int(v)) <= E for v in out[:-1]), ("add3 / sub", ka, kb)
+    # the one-step X3: strict operands at the ends of their range
+    S = (1 << 29)
+    for sa, sb in ((S - 1, -S), (-S, S - 1), (S - 1, S - 1), (-S, -S)):
+        a = np.array([sa] * (nl - 1) + [5], dtype=np.int32)
+        b = np.array([sb] * (nl - 1) + [-3], dtype=np.int32)
+        fu.fs_raw_op(field, 3, a.ctypes.data, b.ctypes.data, b.ctypes.data, b.ctypes.data, out.ctypes.data)
+        assert val(out) == val(a) - 3 * val(b) and all(abs(int(v)) <= E for v in out[:-1]), (sa, sb)

@@ -1,7 +1,7 @@
 """Randomised cross-check of the commit paths against the CPU restatement: random lengths (odd / even / threshold
 neighbours), random batch shapes (blocking batches, host-pointer batches, deferred rounds cut at random places), uniform and
 heavily skewed scalars, table and per-window paths.
-usage: python tests/stress/stress_msm.py [seconds]   (also collected, with a short budget, by tests/test_stress_gpu.py)"""
+usage: [SEED=..] [MAX_LOG_N=17] python tests/stress/stress_msm.py [seconds]   (also collected, with a short budget, by tests/test_stress_gpu.py)"""
 import os
 import sys
 import time
@@ -82,4 +82,5 @@ def run(budget: float = 120.0, seed: int = 1, ctx=None, max_log_n: int = 17):
 
 
 if __name__ == "__main__":
-    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(os.environ.get("SEED", "1")))
+    # MAX_LOG_N=21 reaches the sizes where the table defaults to 17-bit windows and msm_accumulate to three rounds of lanes
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(os.environ.get("SEED", "1")), max_log_n=int(os.environ.get("MAX_LOG_N", "17")))

@@ -488,7 +488,7 @@ ZK_D uint32_t scan256_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
 // references (sign<<31 | window<<26 | index, as msm_scatter writes them) + their low bucket bits -> partition order.
 // A tile of PS_STILE digits is ordered by partition in LDS first (packed: position in the tile, sign, low bits,
 // partition), so the 8-byte records leave as runs of consecutive addresses, one run per partition and tile.
-constexpr uint32_t PS_STILE = 16384;   // 16 digits per lane
+constexpr uint32_t PS_STILE = 8192;   // 8 digits per lane
 __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t P, const uint32_t* cursors,
                                                       const uint32_t* part_start, uint32_t* stage_ref, uint8_t* stage_lo) {
     constexpr uint32_t PER = PS_STILE / PS_T, LOM = (1u << PS_LOB) - 1u;
@@ -573,6 +573,21 @@ ZK_D uint32_t scan128_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
     if (t >= 64 && t < 128) inc += *tmp;
     return inc - v;
 }
+// counts of the keys key[i], i = first, first + PS_T, ... < end, into the LDS table cnt.  Eight loads in flight per lane: written
+// as a plain loop the compiler keeps ONE (load, wait, LDS atomic) per iteration, and the pass over a partition's ~60 keys per
+// lane was sixty memory round trips in a row -- most of the kernel's time.
+template <class K>
+ZK_D void count_keys(const K* key, uint32_t first, uint32_t end, uint32_t* cnt) {
+    uint32_t i = first;
+    for (; i + 7 * PS_T < end; i += 8 * PS_T) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = key[i + k * PS_T];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&cnt[v[k]], 1u);
+    }
+    for (; i < end; i += PS_T) atomicAdd(&cnt[key[i]], 1u);
+}
 __global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, const uint8_t* stage_lo, const uint32_t* part_start, uint32_t P,
                                                     uint32_t* entries, uint32_t* offsets) {
     constexpr uint32_t NB = 1u << PS_LOB, PER = PS_TILE / PS_T;
@@ -583,7 +598,7 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, c
     const uint32_t s = part_start[p], e = part_start[p + 1];
     if (t < NB) cnt[t] = 0;
     __syncthreads();
-    for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage_lo[i]], 1u);
+    count_keys(stage_lo, s + t, e, cnt);
     __syncthreads();
     {
         const uint32_t ex = scan128_excl(t < NB ? cnt[t] : 0u, t, &stmp);
@@ -788,7 +803,7 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
     const uint32_t s = part_start[p], e = part_start[p + 1];
     for (uint32_t j = t; j < NB; j += PS_T) cnt[j] = 0;
     __syncthreads();
-    for (uint32_t i = s + t; i < e; i += PS_T) atomicAdd(&cnt[stage_lo[i]], 1u);
+    count_keys(stage_lo, s + t, e, cnt);
     __syncthreads();
     // exclusive scan of cnt[0 .. NB): lane t owns counters [t*K, (t+1)*K)
     auto scan_counts = [&](uint32_t* dst, uint32_t add, bool with_total) {
@@ -809,6 +824,22 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
     scan_counts(cur, s, false);
     for (uint32_t j = t; j < NB; j += PS_T) offsets[p * NB + j] = cur[j];
     if (p == P - 1 && t == 0) offsets[P * NB] = e;
+    // the tile after the current one is requested while the current one is counted, scanned and placed: its 16 references and
+    // keys per lane sit in registers across the barriers instead of costing a memory round trip at the top of every tile
+    uint32_t nr[PER];
+    uint16_t nk[PER];
+    auto fetch = [&](uint32_t base) {
+        const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) {
+                nr[k] = stage_ref[base + i];
+                nk[k] = stage_lo[base + i];
+            }
+        }
+    };
+    if (s < e) fetch(s);
     for (uint32_t base = s; base < e; base += PS_TILE) {
         const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;
         __syncthreads();
@@ -818,12 +849,14 @@ __global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, 
         uint16_t vk[PER];
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
+            vr[k] = nr[k];
+            vk[k] = nk[k];
+        }
+        if (base + PS_TILE < e) fetch(base + PS_TILE);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = k * PS_T + t;
-            if (i < m) {
-                vr[k] = stage_ref[base + i];
-                vk[k] = stage_lo[base + i];
-                atomicAdd(&cnt[vk[k]], 1u);
-            }
+            if (i < m) atomicAdd(&cnt[vk[k]], 1u);
         }
         __syncthreads();
         scan_counts(toff, 0u, true);

@@ -709,11 +709,28 @@ __global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint6
     const uint64_t hi = lo + sp < n ? lo + sp : n;
     const uint32_t len = (uint32_t)(hi - lo);
     const uint32_t total_digits = W * len;
+    // the digits of the tile after the current one are requested while the current one is counted and placed
+    int32_t nd[PER];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t q = base + k * PS_T + t;
+            nd[k] = 0;
+            if (q < total_digits) {
+                const uint32_t w = q / len, ii = q - w * len;
+                nd[k] = dig[(uint64_t)w * n + lo + ii];
+            }
+        }
+    };
+    if (total_digits) fetch(0);
     for (uint32_t base = 0; base < total_digits; base += PS_STILE) {
-        const uint32_t m = total_digits - base < PS_STILE ? total_digits - base : PS_STILE;
         __syncthreads();
         if (t < 256) cnt[t] = 0;
         __syncthreads();
+        int32_t vd[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) vd[k] = nd[k];
+        if (base + PS_STILE < total_digits) fetch(base + PS_STILE);
         uint32_t pk[PER];
         uint16_t pl[PER];
 #pragma unroll
@@ -721,16 +738,13 @@ __global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint6
             const uint32_t i = k * PS_T + t;
             pk[k] = 0xffffffffu;
             pl[k] = 0;
-            if (i < m) {
-                const uint32_t q = base + i, w = q / len, ii = q - w * len;
-                const int32_t d = dig[(uint64_t)w * n + lo + ii];
-                if (d != 0) {
-                    const uint32_t neg = d < 0 ? 1u : 0u;
-                    const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
-                    pk[k] = i | (neg << 14) | ((b >> lob) << 15);
-                    pl[k] = (uint16_t)(b & LOM);
-                    atomicAdd(&cnt[b >> lob], 1u);
-                }
+            const int32_t d = vd[k];      // 0 past the end of the slab
+            if (d != 0) {
+                const uint32_t neg = d < 0 ? 1u : 0u;
+                const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
+                pk[k] = i | (neg << 14) | ((b >> lob) << 15);
+                pl[k] = (uint16_t)(b & LOM);
+                atomicAdd(&cnt[b >> lob], 1u);
             }
         }
         __syncthreads();

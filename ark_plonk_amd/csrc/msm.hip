@@ -500,25 +500,39 @@ __global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64
     const uint64_t hi = lo + sp < n ? lo + sp : n;
     const uint32_t len = (uint32_t)(hi - lo);
     const uint32_t total_digits = W * len;           // the slab: W windows x len scalars, visited window-major
+    // the digits of the tile after the current one are requested while the current one is counted and placed
+    int32_t nd[PER];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t q = base + k * PS_T + t;
+            nd[k] = 0;
+            if (q < total_digits) {
+                const uint32_t w = q / len, ii = q - w * len;
+                nd[k] = dig[(uint64_t)w * n + lo + ii];
+            }
+        }
+    };
+    if (total_digits) fetch(0);
     for (uint32_t base = 0; base < total_digits; base += PS_STILE) {
-        const uint32_t m = total_digits - base < PS_STILE ? total_digits - base : PS_STILE;
         __syncthreads();
         if (t < 256) cnt[t] = 0;
         __syncthreads();
+        int32_t vd[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) vd[k] = nd[k];
+        if (base + PS_STILE < total_digits) fetch(base + PS_STILE);
         uint32_t pk[PER];
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = k * PS_T + t;
             pk[k] = 0xffffffffu;
-            if (i < m) {
-                const uint32_t q = base + i, w = q / len, ii = q - w * len;
-                const int32_t d = dig[(uint64_t)w * n + lo + ii];
-                if (d != 0) {
-                    const uint32_t neg = d < 0 ? 1u : 0u;
-                    const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
-                    pk[k] = i | (neg << 14) | ((b & LOM) << 15) | ((b >> PS_LOB) << 22);
-                    atomicAdd(&cnt[b >> PS_LOB], 1u);
-                }
+            const int32_t d = vd[k];      // 0 past the end of the slab
+            if (d != 0) {
+                const uint32_t neg = d < 0 ? 1u : 0u;
+                const uint32_t b = (uint32_t)((neg ? -d : d) - 1);
+                pk[k] = i | (neg << 14) | ((b & LOM) << 15) | ((b >> PS_LOB) << 22);
+                atomicAdd(&cnt[b >> PS_LOB], 1u);
             }
         }
         __syncthreads();
@@ -607,6 +621,17 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, c
     __syncthreads();
     if (t < NB) offsets[p * NB + t] = cur[t];
     if (p == P - 1 && t == 0) offsets[P * NB] = e;
+    // the tile after the current one is requested while the current one is counted, scanned and placed
+    uint2 nv[PER];
+    auto fetch = [&](uint32_t base) {
+        const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * PS_T + t;
+            if (i < m) nv[k] = make_uint2(stage_ref[base + i], stage_lo[base + i]);
+        }
+    };
+    if (s < e) fetch(s);
     for (uint32_t base = s; base < e; base += PS_TILE) {
         const uint32_t m = e - base < PS_TILE ? e - base : PS_TILE;   // references in this tile
         __syncthreads();
@@ -614,12 +639,12 @@ __global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, c
         __syncthreads();
         uint2 v[PER];
 #pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) v[k] = nv[k];
+        if (base + PS_TILE < e) fetch(base + PS_TILE);
+#pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = k * PS_T + t;
-            if (i < m) {
-                v[k] = make_uint2(stage_ref[base + i], stage_lo[base + i]);
-                atomicAdd(&cnt[v[k].y], 1u);
-            }
+            if (i < m) atomicAdd(&cnt[v[k].y], 1u);
         }
         __syncthreads();
         {

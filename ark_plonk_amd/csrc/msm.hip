@@ -1310,11 +1310,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const uint32_t w = live ? id / g.ns : 0, sg = live ? id % g.ns : 0;
     const uint32_t G = 1u << g.logG;
     F run = F::zero(), acc = F::zero();
-#pragma unroll 1
-    for (int i = (int)G - 1; i >= 0; --i) {
+    // the bucket of the NEXT step (its two offsets, then its coordinate: two dependent round trips) is requested before the two
+    // additions of the current one; at one to two wavefronts per SIMD nothing else would hide them
+    auto bucket = [&](int i) -> F {
         const uint32_t bi = w * g.B + sg * G + (uint32_t)i;
         F v = F::zero();
         if (live && (!offsets || offsets[bi + 1] != offsets[bi])) v = ld_coord<F>(buckets, bi, role);
+        return v;
+    };
+    F nv = bucket((int)G - 1);
+#pragma unroll 1
+    for (int i = (int)G - 1; i >= 0; --i) {
+        const F v = nv;
+        if (i > 0) nv = bucket(i - 1);
         run = qadd<F>(run, v, role);
         acc = qadd<F>(acc, run, role);
     }

@@ -113,6 +113,7 @@ SYMBOLS = {
     "zk_kzg_commit_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
     "zk_kzg_round_begin_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
     "zk_kzg_open_begin_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),
+    "zk_kzg_round_reduce": (c_int, [c_void_p]),
     "zk_kzg_round_end": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_end_partial": (c_int, [c_void_p, c_u32, c_void_p]),
     "zk_kzg_round_pending": (c_int, [c_void_p, ctypes.POINTER(c_u32)]),

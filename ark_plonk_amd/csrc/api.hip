@@ -187,6 +187,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         for (int i = 0; i < 16; ++i) c->mb[i].release();
         for (int i = 0; i < 16; ++i)
             if (c->ev_job[i]) (void)hipEventDestroy(c->ev_job[i]);
+        if (c->round_ev) (void)hipEventDestroy(c->round_ev);
         if (c->pinned) (void)hipHostFree(c->pinned);
         if (c->pinned_small) (void)hipHostFree(c->pinned_small);
         zk_io_release(c);
@@ -806,11 +807,14 @@ int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* c
 static void round_clear(zk_ctx* c) {
     c->pend_n = 0;
     c->pend_srs = nullptr;
+    c->pend_reduced = false;
+    c->round_reduced = 0;
 }
 
 // jobs [0, n_jobs) appended to the open round; inputs on the device
 static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds) {
     if (c->pend_n && c->pend_srs != s) return ZK_ERR_BAD_ARG;
+    if (c->pend_reduced) return ZK_ERR_PENDING;          // zk_kzg_round_reduce closed the round to new jobs: zk_kzg_round_end first
     if (c->pend_n + n_jobs > 16) return ZK_ERR_UNSUPPORTED;
     for (uint32_t k = 0; k < n_jobs; ++k)
         if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
@@ -870,6 +874,7 @@ int zk_kzg_open_begin_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* co
     if (!c || !s || s->device != c->device || !z_mont || !challenge_mont || (n_polys && (!d_polys || !lens))) return ZK_ERR_BAD_ARG;
     Guard g(c);
     SrsRead rl(s->mu);
+    if (c->pend_reduced) return ZK_ERR_PENDING;
     if (c->pend_n >= 16) return ZK_ERR_UNSUPPORTED;
     void* d_w = nullptr;
     size_t wlen = 0;
@@ -926,6 +931,28 @@ static int round_end_locked(zk_ctx* c, uint32_t n_expected, uint64_t* out_xyz, u
     }
     round_clear(c);
     return rc;
+}
+
+int zk_kzg_round_reduce(zk_ctx* c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (c->pend_n == 0 || c->pend_reduced) return ZK_OK;
+    zk_srs* s = c->pend_srs;
+    uint32_t slots[16], nq = 0;
+    size_t qlens[16];
+    for (uint32_t k = 0; k < c->pend_n; ++k)
+        if (c->pend[k].queued) {
+            slots[nq] = k;
+            qlens[nq] = c->pend[k].n;
+            ++nq;
+        }
+    if (nq) {
+        SrsRead rl(s->mu);
+        int rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens);
+        if (rc) return rc;
+    }
+    c->pend_reduced = true;
+    return ZK_OK;
 }
 
 int zk_kzg_round_end(zk_ctx* c, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {

@@ -264,6 +264,9 @@ struct zk_ctx {
         uint8_t inf = 0;
     };
     uint32_t pend_n = 0;
+    bool pend_reduced = false;      // zk_kzg_round_reduce ran: the round takes no further jobs, zk_kzg_round_end only waits
+    hipEvent_t round_ev = nullptr;  // recorded behind the reduction kernels of a round (msm_batch_pre_reduce)
+    uint32_t round_reduced = 0;     // jobs whose reductions are queued behind round_ev (0: none)
     zk_srs* pend_srs = nullptr;
     PendingJob pend[16];
 };
@@ -328,6 +331,7 @@ int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const*
 // jobs in slots[0 .. n_jobs) with one launch per reduction kernel, wait once, combine on the host
 int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                             const uint8_t* kinds = nullptr, const std::function<int(uint32_t)>* before_job = nullptr);
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens);
 int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
                           uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);

@@ -2351,12 +2351,12 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
     return ZK_OK;
 }
 
-// slots[k]: the buffer set job k was queued into; lens[k]: its length (the plan is a pure function of the SRS and the length)
+// slots[k]: the buffer set job k was queued into; lens[k]: its length (the plan is a pure function of the SRS and the length).
+// The end comes in two steps so that a caller may put other work of the stream (transforms that do not depend on this round's
+// results) BEHIND the reductions before it waits: `reduce` queues the reduction kernels and an event, `end` waits for that event
+// only -- the work queued in between runs while the host combines the window sums and normalises.
 template <class Cv>
-int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz /* n_jobs x 3L */,
-                      uint64_t* out_xy /* optional: n_jobs x 2L affine */, uint8_t* out_inf /* optional flags */) {
-    typedef typename Cv::Fq Fq;
-    constexpr int L64 = Fq::N / 2;
+int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
@@ -2368,13 +2368,32 @@ int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slo
         if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k]))) return rc;    // buffers already large enough: no allocation
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
     }
-    const size_t wb = pl[0].win_bytes;
-    if ((rc = ensure_pinned(c, wb * MAX_JOBS))) return rc;
+    if ((rc = ensure_pinned(c, pl[0].win_bytes * MAX_JOBS))) return rc;
     hipStream_t st = c->stream;
     if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st))) return rc;
+    if (!c->round_ev) ZK_HIP_TRY(hipEventCreateWithFlags(&c->round_ev, hipEventDisableTiming));
+    ZK_HIP_TRY(hipEventRecord(c->round_ev, st));
+    c->round_reduced = n_jobs;
+    return ZK_OK;
+}
+
+template <class Cv>
+int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz /* n_jobs x 3L */,
+                      uint64_t* out_xy /* optional: n_jobs x 2L affine */, uint8_t* out_inf /* optional flags */) {
+    typedef typename Cv::Fq Fq;
+    constexpr int L64 = Fq::N / 2;
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    int rc;
+    if (c->round_reduced != n_jobs && (rc = msm_batch_pre_reduce<Cv>(c, s, n_jobs, slots, lens))) return rc;
+    c->round_reduced = 0;
+    PrePlan pl[MAX_JOBS];
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[slots[k]], pl[k]))) return rc;
+    const size_t wb = pl[0].win_bytes;
     static const bool host_timing = getenv("ZK_HOST_TIMING") != nullptr;      // diagnostic: where the host tail of a round goes
     const auto t0 = std::chrono::steady_clock::now();
-    ZK_HIP_TRY(hipStreamSynchronize(st));
+    ZK_HIP_TRY(hipEventSynchronize(c->round_ev));
     const auto t1 = std::chrono::steady_clock::now();
     struct TailTimer {
         bool on;
@@ -2535,6 +2554,9 @@ int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void
 int ZK_SYM(msm_batch_pre_begin_dev)(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                                     const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
     return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+}
+int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
+    return msm_batch_pre_reduce<CurveSel>(c, s, n_jobs, slots, lens);
 }
 int ZK_SYM(msm_batch_pre_end_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
                                   uint64_t* out_xy, uint8_t* out_inf) {

@@ -14,6 +14,7 @@
                                const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job); \
     int msm_batch_pre_begin_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, \
                                      const uint8_t* kinds, const std::function<int(uint32_t)>* before_job);                \
+    int msm_batch_pre_reduce_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens);      \
     int msm_batch_pre_end_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz, \
                                    uint64_t* out_xy, uint8_t* out_inf);
 DECLS(_c0)
@@ -69,6 +70,11 @@ int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_pol
                             const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
     if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_begin_dev_c0(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
     if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_begin_dev_c1(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+    return ZK_ERR_BAD_ARG;
+}
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_reduce_dev_c0(c, s, n_jobs, slots, lens);
+    if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_reduce_dev_c1(c, s, n_jobs, slots, lens);
     return ZK_ERR_BAD_ARG;
 }
 int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz, uint64_t* out_xy,

@@ -258,6 +258,12 @@ class CommitterKey:
         check(lib().zk_kzg_round_pending(self.ctx.handle, ctypes.byref(n)), "zk_kzg_round_pending")
         return n.value
 
+    def round_reduce(self):
+        """Queue the round's reduction kernels now (optional): the round takes no further jobs, and `round_end` then waits for these
+        kernels only, so work queued on the stream in between -- transforms that do not depend on this round's results -- runs while
+        the host finishes the round."""
+        check(lib().zk_kzg_round_reduce(self.ctx.handle), "zk_kzg_round_reduce")
+
     def round_end(self, n_jobs: int | None = None) -> list:
         """Close the round: one G1Affine per job, in submission order."""
         L = self.curve.fq_limbs

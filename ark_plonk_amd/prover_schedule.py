@@ -49,7 +49,8 @@ class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
-                 ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True):
+                 ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
+                 hoist: bool = True):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -74,6 +75,12 @@ class ProofSchedule:
         self.fuse_round5 = fuse_round5
         # eleven PC calls, five host waits: see the module docstring.  False = every call blocks (the drop-in shape).
         self.defer_calls = defer_calls
+        # hoist: transforms whose inputs do not depend on a round's challenge are queued BEHIND that round's reductions, before the
+        # host waits for them (zk_kzg_round_reduce): the sigma ffts (prover-key data, permutation/mod.rs:671-674) behind round 1, the
+        # public-input and L_1 iffts (pi.rs:115, quotient_poly.rs:325) behind round 2, the twelve coset ffts of the quotient round
+        # (quotient_poly.rs:72-120: wires, z, z_2, f, table, h_1, h_2 are all committed before alpha is drawn) behind round 3.  Same
+        # transforms, same sizes, same batches; they run while the host combines the window sums, normalises and hashes.
+        self.hoist = hoist
         self._pending = []          # per open call: ("q", n_jobs) queued in the ABI's round | ("r", [points]) already computed
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
@@ -214,6 +221,14 @@ class ProofSchedule:
         self.ck.open_begin(polys, self.z_mont, self.chi_mont)
         self._pending.append(("q", 1))
 
+    def _hoisting(self):
+        return self.hoist and not self._immediate()
+
+    def _round_reduce(self):
+        """Queue the open round's reductions now; what is launched until `_round_end` runs behind them, under the host's part."""
+        if not self._immediate() and any(kind == "q" for kind, _ in self._pending):
+            self.ck.round_reduce()
+
     def _round_end(self):
         """Close the open round: the points of every call since the last close, in call order."""
         pend, self._pending = self._pending, []
@@ -310,7 +325,13 @@ class ProofSchedule:
         else:
             for i in range(4):
                 c[i] = d.ifft(self.evals[i])
-        out += self._commit_round(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
+        hoist = self._hoisting()
+        sig = None
+        self._round_begin(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
+        if hoist:
+            self._round_reduce()
+            sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]     # of round 3
+        out += self._round_end()
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         t_ev, f_ev, h1_ev, h2_ev = self.aux_evals[0:4]
         if self.lookup_round2:
@@ -329,9 +350,14 @@ class ProofSchedule:
             c[7] = d.ifft(h2_ev)                      # h2
         self._round_begin([c[6]], labels=["h1"])              # two PC::commit calls of one polynomial each (prover.rs:312-317)
         self._round_begin([c[7]], labels=["h2"])
+        if hoist:
+            self._round_reduce()
+            c[10] = d.ifft(self.aux_evals[6])     # pi   (of round 3)
+            c[11] = d.ifft(self.aux_evals[7])     # l1   (of round 4)
         out += self._round_end()                              # f, h_1, h_2 enter the transcript before beta is drawn (prover.rs:320)
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
-        sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
+        if sig is None:
+            sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
         if self.grand_products:
             from . import permutation
@@ -342,17 +368,25 @@ class ProofSchedule:
             z2_evals = permutation.lookup_permutation_evals(self.ctx, self.cv, f_ev, t_ev, h1_ev, h2_ev, self.chi_mont, self.z_mont)  # delta, epsilon
         c[9] = d.ifft(z2_evals)                   # z2
         self._round_begin([c[9]], labels=["z2"])              # prover.rs:387
-        out += self._round_end()                              # z, z_2 enter the transcript before alpha is drawn (prover.rs:398)
-        c[10] = d.ifft(self.aux_evals[6])         # pi
-        # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
-        c[11] = d.ifft(self.aux_evals[7])         # l1
         names = ("l1", "z", "w_l", "w_r", "w_o", "w_4", "z2", "f", "table", "h1", "h2", "pi")
-        qpolys = (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])
-        if self.ntt_batch:
-            d4.batch(2, qpolys, outs=[self.cos[name] for name in names])          # coset_fft, n coefficients zero-extended to 4n
-        else:
-            for name, poly in zip(names, qpolys):
-                d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)
+
+        def quotient_coset_ffts():
+            qpolys = (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])
+            if self.ntt_batch:
+                d4.batch(2, qpolys, outs=[self.cos[name] for name in names])          # coset_fft, n coefficients zero-extended to 4n
+            else:
+                for name, poly in zip(names, qpolys):
+                    d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)
+
+        if hoist:
+            self._round_reduce()
+            quotient_coset_ffts()                             # of round 4: none of the twelve inputs depends on alpha
+        out += self._round_end()                              # z, z_2 enter the transcript before alpha is drawn (prover.rs:398)
+        # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
+        if not hoist:
+            c[10] = d.ifft(self.aux_evals[6])         # pi
+            c[11] = d.ifft(self.aux_evals[7])         # l1
+            quotient_coset_ffts()
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
         quot = self.quot

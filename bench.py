@@ -212,6 +212,9 @@ def parse_args():
                          "whether the 29 commitments of each leg equal the headline's (commitments_match* fields)")
     ap.add_argument("--check", dest="check", action="store_true", help="(default) see --no-check")
     ap.set_defaults(check=True)
+    ap.add_argument("--no-hoist", action="store_true",
+                    help="launch every transform where the reference calls it, instead of queueing those that do not depend on a round's "
+                         "challenge behind that round's reductions (zk_kzg_round_reduce) before the host waits")
     ap.add_argument("--block-every-call", action="store_true",
                     help="the headline schedule blocks in each of its eleven PC calls (what an unchanged Prover::prove does) instead of "
                          "collecting f|h1|h2, z|z2 and the last round's four calls once per group (zk_kzg_round_begin_dev ... zk_kzg_round_end)")
@@ -295,7 +298,7 @@ def main():
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
                 kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, lookup_round2=glue, fuse_round5=args.fuse_round5,
-                          data=args.data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls)
+                          data=args.data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls, hoist=not args.no_hoist)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
@@ -493,7 +496,11 @@ def main():
                                 "zk_kzg_open_begin_dev and are collected by one zk_kzg_round_end per group: 5 host waits per proof, identical points "
                                 "(`blocking_calls` leg: every call blocking)"),
                    "ntt_calls": "one zk_ntt_dev per transform" if args.no_ntt_batch else
-                                "adjacent independent transforms as zk_ntt_batch_dev (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts), the rest single"},
+                                "adjacent independent transforms as zk_ntt_batch_dev (4 wire iffts | h1,h2 | 4 sigma ffts | 12 coset ffts), the rest single"
+                                + ("" if (args.no_hoist or args.block_every_call or args.dedup) else
+                                   "; transforms whose inputs do not depend on a round's challenge are queued behind that round's reductions before the "
+                                   "host waits (zk_kzg_round_reduce): sigma ffts behind round 1, pi / L_1 iffts behind round 2, the twelve coset ffts "
+                                   "behind round 3 -- same transforms, sizes and batches (--no-hoist: the reference's call order)")},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_note": "each of the W digits of a scalar gathers its own 128-B row of the window table instead of re-deriving "

@@ -209,6 +209,9 @@ class CommitterKey {
         }
         check(zk_kzg_open_begin_dev(ctx_->handle(), h_, k, ptrs.data(), lens.data(), z_mont, challenge_mont), "zk_kzg_open_begin_dev");
     }
+    // optional: queue the round's reductions now; what the caller launches on the stream until round_end() (transforms that do
+    // not depend on this round's results) runs behind them, while round_end() does the host part
+    void round_reduce() const { check(zk_kzg_round_reduce(ctx_->handle()), "zk_kzg_round_reduce"); }
     std::vector<G1Affine> round_end() const {
         const int L = fq_limbs(curve_);
         uint32_t k = 0;

@@ -57,6 +57,8 @@ int main(int argc, char** argv) {
         ck.commit_begin({&d_coeffs});
         zk::DeviceVec d_again = dom.transform(ZK_NTT_IFFT, d_ev);      // a transform queued while the round is open
         ck.commit_begin({&d_again});
+        ck.round_reduce();                                               // reductions queued; the next transform runs under the host's part
+        zk::DeviceVec d_under = dom.transform(ZK_NTT_FFT, d_coeffs);
         auto deferred = ck.round_end();
         std::printf("deferred_round %s\n", (deferred.size() == 2 && deferred[0].xy == single.xy && deferred[1].xy == single.xy) ? "ok" : "MISMATCH");
         // the unchanged caller's PC::commit(ck, polys): host vectors, one call for the whole slice (prover.rs:213)

@@ -251,11 +251,17 @@ int zk_kzg_round_batch_partial_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, co
  * other device builders may run).  Jobs that do not take the window-table path (no table, fewer than 2^13 elements) and,
  * with the commitment cache on, all jobs are computed at begin.  zk_kzg_open_begin_dev is zk_kzg_open_dev as a job of the
  * round (witness polynomial built at once, its MSM deferred).  zk_kzg_round_end_partial returns Jacobian partials (n_jobs x
- * 3L limbs) for a sharded SRS; zk_kzg_round_abort drops an open round (waits for the queued kernels). */
+ * 3L limbs) for a sharded SRS; zk_kzg_round_abort drops an open round (waits for the queued kernels).
+ * zk_kzg_round_reduce (optional) queues the round's reduction kernels and returns: the round takes no further jobs, and
+ * zk_kzg_round_end then waits for those kernels only -- whatever the caller queues on the stream in between (transforms that
+ * do not depend on this round's results: prover.rs would have the sigma ffts of permutation/mod.rs:671-674 behind f | h_1 |
+ * h_2, the coset ffts of quotient_poly.rs:72-120 behind z | z_2) runs while the host combines the window sums, normalises
+ * and hashes the results into the transcript, instead of the GPU idling through that. */
 int zk_kzg_round_begin_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens,
                            const uint8_t* kinds);
 int zk_kzg_open_begin_dev(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
                           const uint64_t* z_mont, const uint64_t* challenge_mont);
+int zk_kzg_round_reduce(zk_ctx* ctx);
 int zk_kzg_round_end(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
 int zk_kzg_round_end_partial(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xyz);
 int zk_kzg_round_pending(zk_ctx* ctx, uint32_t* n_jobs);

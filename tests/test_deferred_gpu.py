@@ -159,3 +159,51 @@ def test_schedule_deferred_equals_blocking(ctx, log_n):
     assert pa == pb
     assert b.run_once(proof_id=1) == a.run_once(proof_id=1)
     ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_round_reduce_lets_other_work_run_under_the_host_tail(ctx, cid):
+    """zk_kzg_round_reduce queues the reductions and closes the round to new jobs; transforms launched before zk_kzg_round_end run
+    behind them; the points are those of the plain round, the transforms' results those of the same calls made alone."""
+    import torch
+    cv = zk.get_curve(cid)
+    n = 1 << 14
+    ck = _ck(ctx, cv, n).precompute()
+    p = _polys(n, 4, 23)
+    if cid == 1:
+        for t in p:
+            t[:, 3] >>= 2                   # BN254: keep the Montgomery residues below r
+    dom = zk.GeneralEvaluationDomain.new(n, cv, ctx)
+    exp = ck.commit_batch(p[:3])
+    exp_fft = dom.fft(p[3]).clone()
+    ck.round_reduce()                        # no open round: a no-op
+    assert ck.commit_begin(p[:2]) == 2
+    assert ck.commit_begin([p[2]]) == 3
+    ck.round_reduce()
+    ck.round_reduce()                        # twice is once
+    with pytest.raises(_lib.ZkError) as e:   # the round takes no further jobs ...
+        ck.commit_begin([p[3]])
+    assert e.value.code == _lib.ZK_ERR_PENDING
+    with pytest.raises(_lib.ZkError) as e:   # ... and the blocking calls stay refused until it is collected
+        ck.commit(p[3])
+    assert e.value.code == _lib.ZK_ERR_PENDING
+    got_fft = dom.fft(p[3])                  # queued behind the reductions, runs while round_end's host part works
+    assert ck.round_pending() == 3
+    got = ck.round_end()
+    assert got == exp
+    torch.cuda.synchronize()
+    assert torch.equal(got_fft, exp_fft)
+    # the next round starts clean
+    assert ck.commit_begin([p[3]]) == 1
+    assert ck.round_end() == [ck.commit(p[3])]
+
+
+def test_schedule_with_hoisted_transforms_gives_the_same_commitments(ctx):
+    cv = zk.get_curve(0)
+    log_n = 13
+    n = 1 << log_n
+    ck = _ck(ctx, cv, n, seed=9).precompute()
+    a = ProofSchedule(log_n, ctx, ck, cv, hoist=True).run_once(0)
+    b = ProofSchedule(log_n, ctx, ck, cv, hoist=False).run_once(0)
+    c = ProofSchedule(log_n, ctx, ck, cv, defer_calls=False).run_once(0)
+    assert a == b == c and len(a) == 29

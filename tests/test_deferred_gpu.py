@@ -196,6 +196,22 @@ def test_round_reduce_lets_other_work_run_under_the_host_tail(ctx, cid):
     # the next round starts clean
     assert ck.commit_begin([p[3]]) == 1
     assert ck.round_end() == [ck.commit(p[3])]
+    # a reduced round refuses a wrong count and stays collectable; an aborted one leaves the ctx usable; a round of jobs that were
+    # computed at begin (below the table threshold) has nothing to reduce
+    ck.commit_begin(p[:2])
+    ck.round_reduce()
+    with pytest.raises(_lib.ZkError) as e:
+        ck.round_end(3)
+    assert e.value.code == _lib.ZK_ERR_BAD_ARG and ck.round_pending() == 2
+    assert ck.round_end(2) == exp[:2]
+    ck.commit_begin(p[:3])
+    ck.round_reduce()
+    ck.round_abort()
+    assert ck.round_pending() == 0 and ck.commit_batch(p[:3]) == exp
+    short = [t[:500] for t in p[:2]]
+    ck.commit_begin(short)
+    ck.round_reduce()
+    assert ck.round_end() == [ck.commit(t) for t in short]
 
 
 def test_schedule_with_hoisted_transforms_gives_the_same_commitments(ctx):

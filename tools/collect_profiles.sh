@@ -15,6 +15,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 BENCH="bench.py --steps 3 --warmup 1 --extra-legs off --streams-leg 0 --no-cpu-baseline"
 PMCB="bench.py --steps 1 --warmup 1 --extra-legs off --streams-leg 0 --no-cpu-baseline --no-check"
 commit=$(cat .git_head 2>/dev/null || echo unknown)
+# a discarded run first: the first minute of a session runs at other clocks than the rest (a traced run at the very start read 3.5 % above
+# the bench line that followed it)
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --extra-legs off --streams-leg 0 --no-cpu-baseline > "$out/warmup.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- python3 $BENCH > "$out/trace.log" 2>&1 || exit 1
 python3 tools/summarize_rocprof.py "$out/trace" "profiles/${tag}_bench_n20" "rocprofv3 --kernel-trace --stats -- python3 $BENCH" > "$out/trace_summary.txt"
 python3 tools/trace_idle.py "$out/trace" >> "profiles/${tag}_bench_n20.md"

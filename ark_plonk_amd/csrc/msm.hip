@@ -427,44 +427,34 @@ __global__ void __launch_bounds__(PS_T) psort_hist(const int16_t* dig, uint64_t 
     for (uint32_t j = threadIdx.x; j < P; j += PS_T) hist[(uint64_t)j * PS_SLABS + blockIdx.x] = lc[j];
 }
 
+ZK_D uint32_t scan1024_excl(uint32_t v, uint32_t t, uint32_t* tmp);
+
 // per partition: exclusive scan of its PS_SLABS slab counts in place (coalesced); the workgroup that finishes
 // last (a counter, no waiting) then scans the P (<= 256) partition totals into part_start[0..P].
-// `counter` must be 0 on entry (psort_hist clears it) and is left 0.
+// `counter` must be 0 on entry (psort_hist clears it) and is left 0.  Both scans are wave shuffles plus one LDS step
+// (scan1024_excl): as twenty-barrier Hillis-Steele loops over LDS this kernel was 13 us of every MSM's sort.
 __global__ void __launch_bounds__(PS_SLABS) psort_scan(uint32_t* hist, uint32_t* part_total, uint32_t P, uint32_t* part_start,
                                                        uint32_t* counter) {
-    __shared__ uint32_t part[PS_SLABS];
+    static_assert(PS_SLABS == 1024, "scan1024_excl");
+    __shared__ uint32_t tmp[16];
     __shared__ uint32_t last_block;
     const uint32_t t = threadIdx.x;
     uint32_t* row = hist + (uint64_t)blockIdx.x * PS_SLABS;
     const uint32_t v = row[t];
-    part[t] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < PS_SLABS; d <<= 1) {
-        uint32_t o = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += o;
-        __syncthreads();
-    }
-    row[t] = part[t] - v;
+    const uint32_t ex = scan1024_excl(v, t, tmp);
+    row[t] = ex;
     if (t == PS_SLABS - 1) {
-        part_total[blockIdx.x] = part[t];
+        part_total[blockIdx.x] = ex + v;
         __threadfence();
         last_block = atomicAdd(counter, 1u) == P - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!last_block) return;
     const uint32_t tv = t < P ? ((volatile uint32_t*)part_total)[t] : 0u;
-    part[t] = tv;
-    __syncthreads();
-    for (uint32_t d = 1; d < PS_SLABS; d <<= 1) {
-        uint32_t o = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += o;
-        __syncthreads();
-    }
-    if (t < P) part_start[t] = part[t] - tv;
+    const uint32_t ex2 = scan1024_excl(tv, t, tmp);
+    if (t < P) part_start[t] = ex2;
     if (t == PS_SLABS - 1) {
-        part_start[P] = part[t];
+        part_start[P] = ex2 + tv;
         *counter = 0;
     }
 }

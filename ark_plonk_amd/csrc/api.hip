@@ -805,6 +805,7 @@ int zk_kzg_round_batch_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* c
 // ctx lock held.  Entry points that would reuse the buffer sets of queued jobs refuse while a round is open (ZK_ERR_PENDING).
 
 static void round_clear(zk_ctx* c) {
+    for (int k = 0; k < 16; ++k) c->mb[k].stage_of_job = 0;
     c->pend_n = 0;
     c->pend_srs = nullptr;
     c->pend_reduced = false;
@@ -907,6 +908,9 @@ static int round_end_locked(zk_ctx* c, uint32_t n_expected, uint64_t* out_xyz, u
     if (nq) {
         SrsRead rl(s->mu);
         rc = msm_batch_pre_end_dev(c, s, nq, slots, qlens, q_xyz, out_xy ? q_xy : nullptr, q_inf);
+        // a failure before the wait (a plan, the pinned buffer) leaves the round's kernels in flight: they still read the caller's
+        // inputs and the SRS, which the header lets the caller free once this call has returned
+        if (rc) (void)hipStreamSynchronize(c->stream);
     }
     uint32_t q = 0;
     for (uint32_t k = 0; k < n && !rc; ++k) {

@@ -164,6 +164,8 @@ struct DevBuf {
 
 struct MsmBufs {
     DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, seg2, seg3, win, tmp, scalars, stage, upload;
+    int stage_of_job = 0;   // table-path job living in this set: 0 none, 1 digits queued (placement + accumulation wait for the round's
+                            // merged launches), 2 accumulated (reductions pending) -- msm_batch_pre_begin / _reduce
     void release() {
         DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg2, &seg3, &win, &tmp, &scalars, &stage, &upload};
         for (DevBuf* b : all) b->release();

@@ -117,6 +117,41 @@ struct MsmGeom {
     uint32_t mod[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// The kernels behind a prover round take up to 16 jobs (blockIdx.y, or a block-range table): the MSMs of one round are
+// sorted, accumulated and reduced by ONE launch of each kernel, so that launch gaps, partly filled last rounds of wavefronts and
+// the latency of the dependent-addition chains are paid once per round instead of once per MSM.
+constexpr int MAX_JOBS = 16;
+// one job of the batched partition-sort kernels (psort_scan / psort(w)_scatter / psort(w)_final)
+struct SJob {
+    const void* dig;        // digits [W][n]: int16 (c = 16) or int32 (c > 16)
+    uint64_t n;             // scalars
+    uint32_t sp, pad;       // scalars per slab
+    uint32_t* hist;         // [P][PS_SLABS] slab counts -> cursors
+    uint32_t* part_start;   // P + 1 partition starts
+    uint32_t* part_total;   // P
+    uint32_t* counter;
+    uint32_t* stage_ref;    // references in partition order ...
+    void* stage_lo;         // ... and their low bucket bits (uint8 / uint16)
+    uint32_t* entries;      // references in bucket order
+    uint32_t* offsets;      // bucket starts, offsets[nb] = references in the list
+};
+struct SJobs {
+    SJob j[MAX_JOBS];
+};
+// one job of the merged accumulation launch: workgroups [blk0, next job's blk0) sum this job's list
+struct AJob {
+    const uint32_t* entries;
+    const uint32_t* offsets;
+    void* buckets;
+    void* part_pt;
+    uint64_t tab_off;
+    uint32_t L0, n_lanes, blk0, pad;
+};
+struct AJobs {
+    AJob j[MAX_JOBS];
+    uint32_t n;
+};
+
 // c-bit field of a canonical scalar (8 x u32 limbs in registers: selects, no indexing) at bit position pos
 ZK_D uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t pos, uint32_t c) {
     const uint32_t limb = pos >> 5, off = pos & 31;
@@ -433,9 +468,12 @@ ZK_D uint32_t scan1024_excl(uint32_t v, uint32_t t, uint32_t* tmp);
 // last (a counter, no waiting) then scans the P (<= 256) partition totals into part_start[0..P].
 // `counter` must be 0 on entry (psort_hist clears it) and is left 0.  Both scans are wave shuffles plus one LDS step
 // (scan1024_excl): as twenty-barrier Hillis-Steele loops over LDS this kernel was 13 us of every MSM's sort.
-__global__ void __launch_bounds__(PS_SLABS) psort_scan(uint32_t* hist, uint32_t* part_total, uint32_t P, uint32_t* part_start,
-                                                       uint32_t* counter) {
+__global__ void __launch_bounds__(PS_SLABS) psort_scan(SJobs jobs, uint32_t P) {
     static_assert(PS_SLABS == 1024, "scan1024_excl");
+    uint32_t* hist = jobs.j[blockIdx.y].hist;
+    uint32_t* part_total = jobs.j[blockIdx.y].part_total;
+    uint32_t* part_start = jobs.j[blockIdx.y].part_start;
+    uint32_t* counter = jobs.j[blockIdx.y].counter;
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t last_block;
     const uint32_t t = threadIdx.x;
@@ -479,9 +517,16 @@ ZK_D uint32_t scan256_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
 // A tile of PS_STILE digits is ordered by partition in LDS first (packed: position in the tile, sign, low bits,
 // partition), so the 8-byte records leave as runs of consecutive addresses, one run per partition and tile.
 constexpr uint32_t PS_STILE = 8192;   // 8 digits per lane
-__global__ void __launch_bounds__(PS_T) psort_scatter(const int16_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t P, const uint32_t* cursors,
-                                                      const uint32_t* part_start, uint32_t* stage_ref, uint8_t* stage_lo) {
+__global__ void __launch_bounds__(PS_T) psort_scatter(SJobs jobs, uint32_t W, uint32_t P) {
     constexpr uint32_t PER = PS_STILE / PS_T, LOM = (1u << PS_LOB) - 1u;
+    const SJob& J = jobs.j[blockIdx.y];
+    const int16_t* dig = (const int16_t*)J.dig;
+    const uint64_t n = J.n;
+    const uint32_t sp = J.sp;
+    const uint32_t* cursors = J.hist;
+    const uint32_t* part_start = J.part_start;
+    uint32_t* stage_ref = J.stage_ref;
+    uint8_t* stage_lo = (uint8_t*)J.stage_lo;
     __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
     __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | low bits << 15 | partition << 22
     const uint32_t t = threadIdx.x;
@@ -592,9 +637,14 @@ ZK_D void count_keys(const K* key, uint32_t first, uint32_t end, uint32_t* cnt) 
     }
     for (; i < end; i += PS_T) atomicAdd(&cnt[key[i]], 1u);
 }
-__global__ void __launch_bounds__(PS_T) psort_final(const uint32_t* stage_ref, const uint8_t* stage_lo, const uint32_t* part_start, uint32_t P,
-                                                    uint32_t* entries, uint32_t* offsets) {
+__global__ void __launch_bounds__(PS_T) psort_final(SJobs jobs, uint32_t P) {
     constexpr uint32_t NB = 1u << PS_LOB, PER = PS_TILE / PS_T;
+    const SJob& J = jobs.j[blockIdx.y];
+    const uint32_t* stage_ref = J.stage_ref;
+    const uint8_t* stage_lo = (const uint8_t*)J.stage_lo;
+    const uint32_t* part_start = J.part_start;
+    uint32_t* entries = J.entries;
+    uint32_t* offsets = J.offsets;
     __shared__ uint32_t cnt[NB], cur[NB], toff[NB + 1], stmp;
     __shared__ uint32_t sorted[PS_TILE];
     __shared__ uint8_t skey[PS_TILE];
@@ -711,9 +761,16 @@ __global__ void __launch_bounds__(256) psortw_digits_hist(const uint32_t* scalar
 }
 
 
-__global__ void __launch_bounds__(PS_T) psortw_scatter(const int32_t* dig, uint64_t n, uint32_t W, uint32_t sp, uint32_t lob, const uint32_t* cursors,
-                                                       const uint32_t* part_start, uint32_t* stage_ref, uint16_t* stage_lo) {
+__global__ void __launch_bounds__(PS_T) psortw_scatter(SJobs jobs, uint32_t W, uint32_t lob) {
     constexpr uint32_t PER = PS_STILE / PS_T;
+    const SJob& J = jobs.j[blockIdx.y];
+    const int32_t* dig = (const int32_t*)J.dig;
+    const uint64_t n = J.n;
+    const uint32_t sp = J.sp;
+    const uint32_t* cursors = J.hist;
+    const uint32_t* part_start = J.part_start;
+    uint32_t* stage_ref = J.stage_ref;
+    uint16_t* stage_lo = (uint16_t*)J.stage_lo;
     const uint32_t LOM = (1u << lob) - 1u;
     __shared__ uint32_t cnt[256], toff[257], gcur[256], stmp[4];
     __shared__ uint32_t rec[PS_STILE];       // k (14 bits) | neg << 14 | partition << 15
@@ -816,9 +873,14 @@ ZK_D uint32_t scan1024_excl(uint32_t v, uint32_t t, uint32_t* tmp) {
 }
 
 // one workgroup per partition, NB = 2^lob buckets; dynamic LDS: cnt[NB] | cur[NB] | toff[NB + 1] | tmp[16] | sorted[PS_TILE] | skey[PS_TILE] (u16)
-__global__ void __launch_bounds__(PS_T) psortw_final(const uint32_t* stage_ref, const uint16_t* stage_lo, const uint32_t* part_start, uint32_t P,
-                                                     uint32_t lob, uint32_t* entries, uint32_t* offsets) {
+__global__ void __launch_bounds__(PS_T) psortw_final(SJobs jobs, uint32_t P, uint32_t lob) {
     extern __shared__ uint32_t lds[];
+    const SJob& J = jobs.j[blockIdx.y];
+    const uint32_t* stage_ref = J.stage_ref;
+    const uint16_t* stage_lo = (const uint16_t*)J.stage_lo;
+    const uint32_t* part_start = J.part_start;
+    uint32_t* entries = J.entries;
+    uint32_t* offsets = J.offsets;
     constexpr uint32_t PER = PS_TILE / PS_T;
     const uint32_t NB = 1u << lob;
     const uint32_t K = NB > PS_T ? NB / PS_T : 1u;       // counters per lane in the scans
@@ -995,9 +1057,22 @@ __global__ void __launch_bounds__(128) msm_accumulate(const uint32_t* entries, c
     accumulate_chunk<F, PRE>(t, entries, offsets, nb, bases, buckets, part_pt, L, n_lanes, tab_stride, tab_off);
 }
 
-// The reduction kernels take up to 16 jobs (blockIdx.y): the MSMs of one prover round are reduced by
-// ONE launch of each kernel, so the latency of the dependent-addition chains is paid once per round.
-constexpr int MAX_JOBS = 16;
+// The accumulations of a round's jobs as ONE launch over the window table: a launch ends with CUs waiting for their last
+// wavefronts (every lane does the same work, so the waves of the last round of resident lanes finish within a fraction of a
+// chunk of each other and the chip idles for that fraction), and a launch per job pays that at the end of every job.  Here the
+// lanes of job k+1 follow those of job k without a gap: only the LAST job of the launch is cut into short chunks (several rounds
+// of resident lanes), the others get one long chunk per resident lane -- a third of the chunk-edge partials for msm_combine*.
+template <class F>
+__global__ void __launch_bounds__(128) msm_accumulate_batch(AJobs jobs, uint32_t nb, const void* bases, uint64_t tab_stride) {
+    uint32_t k = 0;
+    while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].blk0) ++k;       // uniform: scalar registers
+    const AJob& J = jobs.j[k];
+    const uint32_t t = (blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
+    if (t >= J.n_lanes) return;
+    accumulate_chunk<F, true>(t, J.entries, J.offsets, nb, bases, J.buckets, J.part_pt, J.L0, J.n_lanes, tab_stride, J.tab_off);
+}
+
+// The reduction kernels take up to 16 jobs (blockIdx.y), like the sort and the accumulation (MAX_JOBS above).
 constexpr int MAX_RJOBS = 32;     // the last level of the wide reduction reduces two arrays (S_v, T_v) per job
 struct RJobs {
     const void* part_pt[MAX_RJOBS];
@@ -1323,10 +1398,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 }
 
 // msm_win_finish for logq == 0 (one segment per chain): 4 * ns lanes per workgroup, ns <= 256
-template <class F>
 // raw != 0: the two sums stay on the device in the internal point form (the "buckets" of the next reduction level);
 // raw == 0: arkworks layout for the host, as msm_win_finish.
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_win_finish_q(RJobs jobs, MsmGeom g, uint32_t raw) {
+// MAXT = lanes per workgroup the instance is built for.  512 (up to 128 chains: every launch of the window-table path) leaves the
+// register file to two wavefronts per SIMD and nothing spills; built for 1024 lanes -- four wavefronts per SIMD, 128 registers --
+// the same code spilled 162 registers to 332 bytes of scratch per lane (the form every launch used before round 4; only the
+// per-window path's 256-chain geometry still needs it).
+template <class F, int MAXT>
+__global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT / 256, MAXT / 256))) msm_win_finish_q(RJobs jobs, MsmGeom g, uint32_t raw) {
     extern __shared__ uint4 sh[];
     const void* seg_run = jobs.seg_run[blockIdx.y];
     const void* seg_acc = jobs.seg_acc[blockIdx.y];
@@ -1485,12 +1564,32 @@ __global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, ui
 }
 
 // ---------------------------------------------------------------------------------------- host side
+// msm_win_finish_q with `chains` (a power of two <= 256) chains of four lanes per workgroup
+template <class F>
+int launch_win_finish_q(dim3 grid, uint32_t chains, hipStream_t st, const RJobs& jobs, const MsmGeom& g, uint32_t raw) {
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    const size_t shmem = (size_t)chains * PT;
+    if (chains <= 128) {
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((msm_win_finish_q<F, 512>), grid, dim3(4 * chains), shmem, st, jobs, g, raw);
+    } else if (chains <= 256) {
+        if (shmem > 48 * 1024)
+            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((msm_win_finish_q<F, 1024>), grid, dim3(4 * chains), shmem, st, jobs, g, raw);
+    } else {
+        return ZK_ERR_UNSUPPORTED;
+    }
+    return ZK_OK;
+}
+
 // combine + segmented reduction of n_jobs MSMs that share the geometry (nb buckets, reduction geometry gr)
 template <class F>
 int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st, bool queues_cleared = false) {
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
+    int rc;
     if (!queues_cleared)
         for (uint32_t k = 0; k < n_jobs; ++k) ZK_HIP_TRY(hipMemsetAsync(jobs.q[k], 0, 8, st));
     // quad-cooperative kernels where the geometry allows (one segment per chain, <= 256 chains per window)
@@ -1526,9 +1625,7 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
         uint32_t chains = 1;
         while (chains < gr.ns) chains <<= 1;
         size_t shmem = (size_t)chains * PT;
-        if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(gr.W, n_jobs), dim3(4 * chains), shmem, st, jobs, gr, 0u);
+        if ((rc = launch_win_finish_q<F>(dim3(gr.W, n_jobs), chains, st, jobs, gr, 0u))) return rc;
     } else {
         unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
@@ -1559,6 +1656,7 @@ int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb
                       char* h_out, size_t h_stride, hipStream_t st) {
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     ProfScope ps(c, "msm_reduce", st);
+    int rc;
     const uint32_t VW = nb / WIDE_VB;
     if (VW == 0 || VW > 2048) return ZK_ERR_UNSUPPORTED;
     {   // chunk-edge partials -> buckets (queues cleared by the job's sort)
@@ -1610,10 +1708,7 @@ int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb
         j3.win_t[k] = (uint32_t*)((char*)d_vw[k] + (size_t)VW * PT);
     }
     {
-        const size_t shmem = (size_t)WIDE_CHAINS * PT;
-        if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(VW, n_jobs), dim3(4 * WIDE_CHAINS), shmem, st, j3, gv, 1u);
+        if ((rc = launch_win_finish_q<F>(dim3(VW, n_jobs), WIDE_CHAINS, st, j3, gv, 1u))) return rc;
     }
     MsmGeom g4;           // level 4: the VW pairs (S_v, T_v) of every job
     memset(&g4, 0, sizeof g4);
@@ -1641,10 +1736,7 @@ int queue_reduce_wide(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb
         hipLaunchKernelGGL(msm_seg_reduce_q<F>, dim3(sblocks, 2 * n_jobs), dim3(256), 0, st, j4, g4);
         uint32_t chains = 1;
         while (chains < g4.ns) chains <<= 1;
-        size_t shmem = (size_t)chains * PT;
-        if (shmem > 48 * 1024)
-            ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_win_finish_q<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(msm_win_finish_q<F>, dim3(1, 2 * n_jobs), dim3(4 * chains), shmem, st, j4, g4, 0u);
+        if ((rc = launch_win_finish_q<F>(dim3(1, 2 * n_jobs), chains, st, j4, g4, 0u))) return rc;
     }
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
@@ -1949,8 +2041,10 @@ struct PrePlan {
                         // c = 16 table serves, with virtual windows of 1024 buckets)
 };
 
+// long_chunks: the job is followed by another one inside a merged accumulation launch (msm_accumulate_batch): one round of
+// resident lanes with one long chunk each instead of several rounds of short ones.  The buffers are sized for the larger plan.
 template <class Cv>
-int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
+int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long_chunks = false) {
     typedef typename Cv::Fq Fq;
     typedef typename Cv::FqU F;
     typedef XYZZ<Fq> PH;
@@ -2008,14 +2102,29 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     // Two rounds become three where the chunks stay >= 32 references: the end of the launch, where CUs wait for their last
     // wavefronts, shortens with the chunk (2^20, c = 17: 60 -> 40 per lane, msm_accumulate -2.5 % per launch, msm_combine* +7
     // partials per bucket instead of 5, net +0.5 .. 0.8 % proofs/s; 30 and 24 per lane give the accumulation another 1 % and
-    // the combine more than that back: profiles/r03_notes.md)
+    // the combine more than that back: profiles/r03_notes.md).  A job that is not the last one of a merged launch has no end of
+    // its own: one round (ZK_LONG_ROUNDS: tuning hook), a third of the partials.
+    uint32_t max_lanes = pl.n_lanes;
     {
         constexpr uint32_t ROUND = 131072;
         if (pl.n_lanes > ROUND) {
             uint32_t rounds = (pl.n_lanes + ROUND - 1) / ROUND;
             if (!tuned && rounds == 2 && pl.nf / (3ull * ROUND) >= 32) rounds = 3;
-            pl.n_lanes = rounds * ROUND;
-            pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
+            // never below 16 references per lane: sizes just above one round (n ~ 1.4e5 at c = 16) would otherwise get 262144 lanes
+            // of 9, and chunks that short overload msm_combine* (measured at 2^20: 16 per lane cost 162 ms per proof against 110)
+            const uint32_t l_r = (uint32_t)((pl.nf + (uint64_t)rounds * ROUND - 1) / ((uint64_t)rounds * ROUND));
+            if (l_r >= 16) {
+                pl.n_lanes = rounds * ROUND;
+                pl.chunk_l = l_r;
+            }
+            max_lanes = pl.n_lanes;
+            if (long_chunks) {
+                const char* le = getenv("ZK_LONG_ROUNDS");
+                const uint32_t long_rounds = le ? (uint32_t)atoi(le) : 1u;
+                const uint32_t lr = long_rounds < 1 ? 1u : long_rounds > rounds ? rounds : long_rounds;
+                pl.n_lanes = lr * ROUND;
+                pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
+            }
         }
     }
     pl.S = 1;
@@ -2027,7 +2136,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     if ((rc = mb.tmp.ensure((size_t)pl.nf * (pl.wide ? 4 : 2)))) return rc;
     if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
     if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
-    if ((rc = mb.part_pt.ensure((size_t)pl.n_lanes * 2 * PT))) return rc;
+    if ((rc = mb.part_pt.ensure((size_t)max_lanes * 2 * PT))) return rc;
     if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
     if (pl.wide_red) {
         const size_t n1 = pl.g.B >> WIDE_LOGG1, n2 = n1 >> WIDE_LOGK2;
@@ -2042,61 +2151,48 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl) {
     return ZK_OK;
 }
 
+// The sort of a table-path job comes in two pieces.  `pre_queue_digits` is the only kernel that reads the caller's scalars
+// (digits + the slab counts of the 256 partitions; into_repr of a commit's Montgomery coefficients fused in): it is queued when
+// the job is submitted, so the input vector is consumed in stream order at the call, as before.  `pre_queue_sort_rest` -- scan,
+// partition scatter, final placement -- takes the jobs of a round as ONE launch per kernel (blockIdx.y = job).
+inline bool pre_psort16(const PrePlan& pl) { return !pl.wide && pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256; }
+
 template <class Cv>
-int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scalars, size_t n, hipStream_t st, bool mont = false) {
-    uint32_t* hist = (uint32_t*)mb.counts.p;
-    uint32_t* bsum = hist + (size_t)pl.S * pl.g.B;
-    uint32_t* offsets = (uint32_t*)mb.offsets.p;
-    int16_t* dig = (int16_t*)mb.tmp.p;
-    uint32_t* entries = (uint32_t*)mb.entries.p;
+int pre_queue_digits(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scalars, size_t n, hipStream_t st, bool mont) {
     ProfScope ps(c, "msm_sort", st);
-    const int T = 256;
-    unsigned blocks = (unsigned)((n + T - 1) / T);
     typedef typename Cv::Fr FrS;
+    const int T = 256;
+    const uint32_t sp = psort_slab_len(n);
+    int rc;
     if (pl.wide) {
         const uint32_t lob = pl.g.c - 9, P = 256;
-        const uint32_t sp = psort_slab_len(n);
         uint32_t* part_start = (uint32_t*)mb.part_key.p;
         uint32_t* part_total = part_start + P + 1;
         uint32_t* scan_counter = part_total + P;
         uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
-        int rc = mb.stage.ensure((size_t)pl.nf * 6);
-        if (rc) return rc;
+        if ((rc = mb.stage.ensure((size_t)pl.nf * 6))) return rc;
         if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
-        hist = (uint32_t*)mb.counts.p;
+        uint32_t* hist = (uint32_t*)mb.counts.p;
         int32_t* dig32 = (int32_t*)mb.tmp.p;
         if (mont) hipLaunchKernelGGL((psortw_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
                                      lob, dig32, hist, scan_counter, combine_q);
         else hipLaunchKernelGGL((psortw_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
                                 lob, dig32, hist, scan_counter, combine_q);
-        hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
-        uint32_t* stage_ref = (uint32_t*)mb.stage.p;
-        uint16_t* stage_lo = (uint16_t*)((char*)mb.stage.p + (size_t)pl.nf * 4);
-        hipLaunchKernelGGL(psortw_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, (const int32_t*)dig32, (uint64_t)n, pl.g.W, sp, lob, hist, part_start,
-                           stage_ref, stage_lo);
-        const uint32_t NB = 1u << lob;
-        const size_t lds = ((size_t)3 * NB + 1 + 16 + PS_TILE) * 4 + (size_t)PS_TILE * 2;
-        ZK_HIP_TRY(hipFuncSetAttribute((const void*)psortw_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(psortw_final, dim3(P), dim3(PS_T), lds, st, (const uint32_t*)stage_ref, (const uint16_t*)stage_lo, part_start, P, lob, entries,
-                           offsets);
         ZK_HIP_TRY(hipGetLastError());
         return ZK_OK;
     }
-    const bool psort = pl.g1.nb % (1u << PS_LOB) == 0 && (pl.g1.nb >> PS_LOB) <= 256;   // two-pass partition sort
+    if (!pre_psort16(pl)) return ZK_ERR_UNSUPPORTED;     // the table windows are 16 .. 21 bits: 2^15 buckets = 256 partitions of 128
+    int16_t* dig = (int16_t*)mb.tmp.p;
     const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16 && !pl.g.neg;        // two scalars per lane
     const uint32_t P = pl.g1.nb >> PS_LOB;
-    const uint32_t sp = psort_slab_len(n);
     uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 partition starts | P totals | scan counter
     uint32_t* part_total = part_start + P + 1;
     uint32_t* scan_counter = part_total + P;
     uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
-    if (psort) {
-        int rc = mb.stage.ensure((size_t)pl.nf * 5);
-        if (rc) return rc;
-        if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
-        hist = (uint32_t*)mb.counts.p;
-    }
-    if (pairs && psort && P == 256) {
+    if ((rc = mb.stage.ensure((size_t)pl.nf * 5))) return rc;
+    if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
+    uint32_t* hist = (uint32_t*)mb.counts.p;
+    if (pairs && P == 256) {
         // digits and the per-slab partition counts in one kernel
         if (mont) hipLaunchKernelGGL((psort_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp,
                                      dig, hist, scan_counter, combine_q);
@@ -2110,50 +2206,93 @@ int pre_queue_sort(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_scal
         } else {
             const void* canon = d_scalars;
             if (mont) {   // odd length: separate into_repr pass, then the one-scalar-per-lane kernel
-                int rc = mb.scalars.ensure(n * 32);
-                if (rc) return rc;
+                if ((rc = mb.scalars.ensure(n * 32))) return rc;
                 if ((rc = fr_convert_stream(c, Cv::ID, d_scalars, n, mb.scalars.p, st))) return rc;
                 canon = mb.scalars.p;
             }
+            unsigned blocks = (unsigned)((n + T - 1) / T);
             hipLaunchKernelGGL(msm_digits, dim3(blocks), dim3(T), 0, st, (const uint32_t*)canon, (uint64_t)n, pl.g, dig);
         }
-        if (psort)
-            hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, (uint64_t)n, pl.g.W, sp, P, hist, scan_counter, combine_q);
+        hipLaunchKernelGGL(psort_hist, dim3(PS_SLABS), dim3(PS_T), P * 4, st, dig, (uint64_t)n, pl.g.W, sp, P, hist, scan_counter, combine_q);
     }
-    if (psort) {
-        hipLaunchKernelGGL(psort_scan, dim3(P), dim3(PS_SLABS), 0, st, hist, part_total, P, part_start, scan_counter);
-        uint32_t* stage_ref = (uint32_t*)mb.stage.p;                       // references | their low bucket bits (nf bytes)
-        uint8_t* stage_lo = (uint8_t*)mb.stage.p + (size_t)pl.nf * 4;
-        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS), dim3(PS_T), 0, st, dig, (uint64_t)n, pl.g.W, sp, P, hist, part_start, stage_ref, stage_lo);
-        hipLaunchKernelGGL(psort_final, dim3(P), dim3(PS_T), 0, st, (const uint32_t*)stage_ref, (const uint8_t*)stage_lo, part_start, P, entries,
-                           offsets);
-        ZK_HIP_TRY(hipGetLastError());
-        return ZK_OK;
-    }
-    size_t lds = (size_t)pl.g.B * 4;
-    if (lds > 48 * 1024) {
-        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ZK_HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    ZK_HIP_TRY(hipMemsetAsync((uint32_t*)mb.part_key.p + PRE_Q_OFF, 0, 8, st));   // combine queue counters (see pre_queue_reduce)
-    hipLaunchKernelGGL(msm_hist, dim3(pl.S, 1), dim3(1024), lds, st, dig, pl.nf, pl.g1, pl.S, hist);
-    const unsigned nblk = (pl.g1.nb + 1023) / 1024;
-    hipLaunchKernelGGL(msm_scan1, dim3(nblk), dim3(1024), 0, st, hist, pl.g1, pl.S, bsum);
-    hipLaunchKernelGGL(msm_scan2, dim3(1), dim3(1024), 0, st, bsum, nblk);
-    hipLaunchKernelGGL(msm_scan3, dim3(nblk), dim3(1024), 0, st, hist, pl.g1, pl.S, bsum, offsets);
-    hipLaunchKernelGGL(msm_scatter, dim3(pl.S, 1), dim3(1024), lds, st, dig, pl.nf, pl.g1, pl.S, hist, entries, (uint32_t)n);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
 
+// jobs of one SRS (same window geometry); lens[k] scalars in job k
 template <class Cv>
-int pre_queue_accumulate(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, zk_srs* s, size_t base_offset, hipStream_t st) {
+int pre_queue_sort_rest(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, const size_t* lens, uint32_t n_jobs, hipStream_t st) {
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    ProfScope ps(c, "msm_sort", st);
+    const PrePlan& p0 = pls[0];
+    const uint32_t P = p0.wide ? 256u : p0.g1.nb >> PS_LOB;
+    SJobs sj;
+    memset(&sj, 0, sizeof sj);
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        MsmBufs& mb = *mbs[k];
+        SJob& J = sj.j[k];
+        J.dig = mb.tmp.p;
+        J.n = lens[k];
+        J.sp = psort_slab_len(lens[k]);
+        J.hist = (uint32_t*)mb.counts.p;
+        J.part_start = (uint32_t*)mb.part_key.p;
+        J.part_total = J.part_start + P + 1;
+        J.counter = J.part_total + P;
+        J.stage_ref = (uint32_t*)mb.stage.p;
+        J.stage_lo = (char*)mb.stage.p + (size_t)pls[k].nf * 4;
+        J.entries = (uint32_t*)mb.entries.p;
+        J.offsets = (uint32_t*)mb.offsets.p;
+    }
+    hipLaunchKernelGGL(psort_scan, dim3(P, n_jobs), dim3(PS_SLABS), 0, st, sj, P);
+    if (p0.wide) {
+        const uint32_t lob = p0.g.c - 9;
+        hipLaunchKernelGGL(psortw_scatter, dim3(PS_SLABS, n_jobs), dim3(PS_T), 0, st, sj, p0.g.W, lob);
+        const uint32_t NB = 1u << lob;
+        const size_t lds = ((size_t)3 * NB + 1 + 16 + PS_TILE) * 4 + (size_t)PS_TILE * 2;
+        ZK_HIP_TRY(hipFuncSetAttribute((const void*)psortw_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(psortw_final, dim3(P, n_jobs), dim3(PS_T), lds, st, sj, P, lob);
+    } else {
+        hipLaunchKernelGGL(psort_scatter, dim3(PS_SLABS, n_jobs), dim3(PS_T), 0, st, sj, p0.g.W, P);
+        hipLaunchKernelGGL(psort_final, dim3(P, n_jobs), dim3(PS_T), 0, st, sj, P);
+    }
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// the accumulations of n_jobs sorted jobs as ONE launch (msm_accumulate_batch); tab_offs[k] = base_offset of job k
+template <class Cv>
+int pre_queue_accumulate(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, const size_t* lens, const size_t* tab_offs, uint32_t n_jobs, zk_srs* s,
+                         hipStream_t st) {
     typedef typename Cv::FqU F;
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     ProfScope ps(c, "msm_accumulate", st);
-    const int T = 128;
-    unsigned blocks = (pl.n_lanes + T - 1) / T;
-    hipLaunchKernelGGL((msm_accumulate<F, true>), dim3(blocks), dim3(T), 0, st, (const uint32_t*)mb.entries.p, (const uint32_t*)mb.offsets.p,
-                       pl.g1.nb, s->d_xy, mb.buckets.p, mb.part_pt.p, pl.chunk_l, pl.n_lanes, (uint64_t)s->n, (uint64_t)base_offset);
+    const uint32_t T = 128;
+    AJobs aj;
+    memset(&aj, 0, sizeof aj);
+    aj.n = n_jobs;
+    uint64_t blocks = 0, points = 0;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        MsmBufs& mb = *mbs[k];
+        AJob& J = aj.j[k];
+        J.entries = (const uint32_t*)mb.entries.p;
+        J.offsets = (const uint32_t*)mb.offsets.p;
+        J.buckets = mb.buckets.p;
+        J.part_pt = mb.part_pt.p;
+        J.tab_off = tab_offs ? tab_offs[k] : 0;
+        J.L0 = pls[k].chunk_l;
+        J.n_lanes = pls[k].n_lanes;
+        J.blk0 = (uint32_t)blocks;
+        blocks += (pls[k].n_lanes + T - 1) / T;
+        points += lens[k];
+    }
+    if (blocks >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+    if (c->profiling) {      // units of the scope above: bench.py prices a launch by the points it processed
+        c->prof["msm_accumulate_jobs"].launches += n_jobs;
+        c->prof["msm_accumulate_points"].launches += points;
+    }
+    hipLaunchKernelGGL(msm_accumulate_batch<F>, dim3((unsigned)blocks), dim3(T), 0, st, aj, pls[0].g1.nb, s->d_xy, (uint64_t)s->n);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
@@ -2298,9 +2437,10 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     int rc = pre_plan<Cv>(c, s, n, mb, pl);
     if (rc) return rc;
     if ((rc = ensure_pinned(c, pl.win_bytes * MAX_JOBS))) return rc;
-    if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_scalars, n, c->stream))) return rc;
-    if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, base_offset, c->stream))) return rc;
     MsmBufs* one = &mb;
+    if ((rc = pre_queue_digits<Cv>(c, pl, mb, d_scalars, n, c->stream, false))) return rc;
+    if ((rc = pre_queue_sort_rest<Cv>(c, &pl, &one, &n, 1, c->stream))) return rc;
+    if ((rc = pre_queue_accumulate<Cv>(c, &pl, &one, &n, &base_offset, 1, s, c->stream))) return rc;
     if ((rc = pre_queue_reduce<Cv>(c, &pl, &one, 1, c->pinned, c->stream))) return rc;
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     if (pl.wide_red) pre_host_wide<Cv>(c->pinned, ilog2_floor(pl.gv.B), out_xyz);
@@ -2312,15 +2452,24 @@ template <class Fq>
 int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 
 // A batch of commitments over the same SRS (the polynomials of one prover round): Montgomery
-// coefficients in, Jacobian results out.  Every job has its own buffer set; the jobs' sorts and
-// accumulations are queued back to back and their combine / segmented-reduction steps run as ONE
-// launch per kernel (job = blockIdx.y), so the dependent-addition chains of the reduction are paid
-// once per round instead of once per MSM.  Everything stays on the ctx stream: overlapping
-// neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md).
+// coefficients in, Jacobian results out.  Every job has its own buffer set and every step is ONE launch per kernel
+// for all the jobs of the round (job = blockIdx.y, or a block range of the merged accumulation): the sort's placement
+// passes, the accumulation, the combine / segmented-reduction steps.  Everything stays on the ctx stream: overlapping
+// neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md, r02_notes.md).
 //
-// The batch comes in two halves so that a round may be OPENED by several calls and closed by one
-// (zk_kzg_round_begin_dev / zk_kzg_round_end): `begin` queues sort + accumulate of its jobs into the buffer
-// sets c->mb[slot0 ..], `end` reduces every open job in one launch per kernel, waits once and finishes on the host.
+// The batch comes in pieces so that a round may be OPENED by several calls and closed by one
+// (zk_kzg_round_begin_dev / zk_kzg_round_end):
+//   begin   per job: the digit kernel -- the only reader of the caller's vector -- into the buffer set c->mb[slot] (stage 1).
+//           With a `before_job` hook (the host-pointer batch uploads job k there, so that the upload of job k+1 runs under the
+//           accumulation of job k) the job's whole sort and its own accumulation launch follow at once (stage 2).
+//   reduce  the placement passes and ONE accumulation launch for every stage-1 job, then the reductions of all jobs, an event.
+//   end     waits for that event and finishes on the host.
+// ZK_MSM_MERGE=0 (A/B hook): every job is sorted and accumulated by its own launches at begin, as before round 4.
+static bool msm_merge_enabled() {      // read at every call: tools/ab_proof.py alternates it inside one process
+    const char* e = getenv("ZK_MSM_MERGE");
+    return !(e && atoi(e) == 0);
+}
+
 template <class Cv>
 int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                         const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
@@ -2329,22 +2478,29 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
     if (slot0 + n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
     hipStream_t st = c->stream;
+    const bool defer = msm_merge_enabled() && !before_job;
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[slot0 + k];
         PrePlan pl;
         if ((rc = pre_plan<Cv>(c, s, lens[k], mb, pl))) return rc;
         const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
         if (before_job && (rc = (*before_job)(k))) return rc;
-        if ((rc = pre_queue_sort<Cv>(c, pl, mb, d_coeffs[k], lens[k], st, mont))) return rc;
-        if ((rc = pre_queue_accumulate<Cv>(c, pl, mb, s, 0, st))) return rc;
+        if ((rc = pre_queue_digits<Cv>(c, pl, mb, d_coeffs[k], lens[k], st, mont))) return rc;
+        mb.stage_of_job = 1;
+        if (defer) continue;
+        MsmBufs* one = &mb;
+        if ((rc = pre_queue_sort_rest<Cv>(c, &pl, &one, &lens[k], 1, st))) return rc;
+        if ((rc = pre_queue_accumulate<Cv>(c, &pl, &one, &lens[k], nullptr, 1, s, st))) return rc;
+        mb.stage_of_job = 2;
     }
     return ZK_OK;
 }
 
-// slots[k]: the buffer set job k was queued into; lens[k]: its length (the plan is a pure function of the SRS and the length).
+// slots[k]: the buffer set job k was queued into; lens[k]: its length (the plan is a function of the SRS, the length and whether
+// the job is followed by another one in the merged accumulation launch).
 // The end comes in two steps so that a caller may put other work of the stream (transforms that do not depend on this round's
-// results) BEHIND the reductions before it waits: `reduce` queues the reduction kernels and an event, `end` waits for that event
-// only -- the work queued in between runs while the host combines the window sums and normalises.
+// results) BEHIND the reductions before it waits: `reduce` queues everything up to the reduction kernels and an event, `end` waits
+// for that event only -- the work queued in between runs while the host combines the window sums and normalises.
 template <class Cv>
 int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
     if (n_jobs == 0) return ZK_OK;
@@ -2352,15 +2508,37 @@ int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* 
     int rc;
     PrePlan pl[MAX_JOBS];
     MsmBufs* mbs[MAX_JOBS];
+    uint32_t last_deferred = n_jobs;
     for (uint32_t k = 0; k < n_jobs; ++k) {
         if (slots[k] >= (uint32_t)MAX_JOBS) return ZK_ERR_BAD_ARG;
         mbs[k] = &c->mb[slots[k]];
-        if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k]))) return rc;    // buffers already large enough: no allocation
+        if (mbs[k]->stage_of_job == 0) return ZK_ERR_BAD_ARG;       // never submitted
+        if (mbs[k]->stage_of_job == 1) last_deferred = k;
+    }
+    PrePlan dpl[MAX_JOBS];
+    MsmBufs* dmb[MAX_JOBS];
+    size_t dlen[MAX_JOBS];
+    uint32_t nd = 0;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        const bool deferred = mbs[k]->stage_of_job == 1;
+        if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k], deferred && k != last_deferred))) return rc;    // buffers already large enough: no allocation
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
+        if (deferred) {
+            dpl[nd] = pl[k];
+            dmb[nd] = mbs[k];
+            dlen[nd] = lens[k];
+            ++nd;
+        }
     }
     if ((rc = ensure_pinned(c, pl[0].win_bytes * MAX_JOBS))) return rc;
     hipStream_t st = c->stream;
+    if (nd) {
+        if ((rc = pre_queue_sort_rest<Cv>(c, dpl, dmb, dlen, nd, st))) return rc;
+        if ((rc = pre_queue_accumulate<Cv>(c, dpl, dmb, dlen, nullptr, nd, s, st))) return rc;
+        for (uint32_t k = 0; k < nd; ++k) dmb[k]->stage_of_job = 2;
+    }
     if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st))) return rc;
+    for (uint32_t k = 0; k < n_jobs; ++k) mbs[k]->stage_of_job = 0;
     if (!c->round_ev) ZK_HIP_TRY(hipEventCreateWithFlags(&c->round_ev, hipEventDisableTiming));
     ZK_HIP_TRY(hipEventRecord(c->round_ev, st));
     c->round_reduced = n_jobs;

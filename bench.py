@@ -348,7 +348,9 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        prof = {"msm_accumulate": ctx.profile_get("msm_accumulate")}
+        prof = {"msm_accumulate": ctx.profile_get("msm_accumulate"),
+                # units of those launches: since round 4 ONE msm_accumulate_batch launch sums every MSM of a round (2 .. 16 jobs)
+                "msm_accumulate_jobs": ctx.profile_get("msm_accumulate_jobs"), "msm_accumulate_points": ctx.profile_get("msm_accumulate_points")}
         msms_run = lanes[0]["sched"].msms_run        # of the last timed proof (the digest run below repeats proof 0)
         kb = 0
         if not args.no_profile:
@@ -439,7 +441,13 @@ def main():
     ntt_ms, ntt_n = r["prof"]["ntt_pass"]
     sort_ms, _ = r["prof"]["msm_sort"]
     red_ms, _ = r["prof"]["msm_reduce"]
-    alg_bytes = (32.0 + 16.0 * cv.fq_limbs) * r["points_per_launch"]   # 32 B scalar + packed affine base (96 B BLS12-381), once
+    # algorithmic bytes of the launches timed: 32 B scalar + packed affine base (96 B BLS12-381) per point, once.
+    # A launch of the dominant kernel sums the jobs of one prover round (4 | 3 | 2 | 4 | 16 MSMs at the headline schedule), so the
+    # units come from the library's own counters of the scope: points and jobs the timed launches processed.
+    acc_jobs = r["prof"]["msm_accumulate_jobs"][1] or acc_n
+    acc_points = r["prof"]["msm_accumulate_points"][1] or acc_n * r["points_per_launch"]
+    launch_points = acc_points / max(acc_n, 1)                                     # average points per launch
+    alg_bytes = (32.0 + 16.0 * cv.fq_limbs) * launch_points
     avg_s = (acc_ms / max(acc_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if acc_n else 0.0
     traffic, traffic_source = None, None
@@ -459,7 +467,7 @@ def main():
     valu = None
     W = r["windows"]
     if acc_n and W and cv.curve_id == 0:
-        madds = float(W) * r["points_per_launch"]             # one mixed addition per (window, point) on the table path
+        madds = float(W) * launch_points                      # one mixed addition per (window, point) on the table path
         mac_s = madds * MADD_MADS / avg_s
         peak_mac_s = LANES * CLOCK_HZ / MAD_CYCLES_FULL
         bound2 = LANES * CLOCK_HZ / MADD_CYCLES_2WAVES
@@ -506,11 +514,16 @@ def main():
                      "traffic_note": "each of the W digits of a scalar gathers its own 128-B row of the window table instead of re-deriving "
                                      "2^(c w) P: HBM bytes traded for doublings, by design",
                      "avg_launch_ms": avg_s * 1e3, "launches": int(acc_n), "alg_bytes_per_launch": alg_bytes,
+                     "msms_per_launch": acc_jobs / max(acc_n, 1), "points_per_launch": launch_points,
+                     "ms_per_msm": acc_ms / max(acc_jobs, 1),
+                     "launch_note": "one msm_accumulate_batch launch sums every MSM of a prover round (job = a block range); achieved = 128 B x the "
+                                    "points the timed launches processed / their HIP-event time",
                      "valu": valu},
         # rank 0's kernels: G1 additions the reference's Pippenger would have issued / time in the MSM kernels
         "msm_g1_adds_per_s": ((29 * kb * ark_adds(n, sbits)) / msm_total_s * (1 if (main_sharded or world == 1) else world)
                               if (msm_total_s and not args.dedup) else None),
         "msm_ms_per_proof": msm_total_s / kb * 1e3,
+        "msm_breakdown_ms_per_proof": {"accumulate": bacc_ms / kb, "sort": sort_ms / kb, "reduce": red_ms / kb},
         "ntt_GBps": (r["ntt_bytes"] * kb) / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
         "ntt_ms_per_proof": ntt_ms / kb,
         "breakdown_note": f"msm_* / ntt_* are per-kernel-scope HIP-event times of {kb} extra proofs run right after the timed region with every scope on; "

@@ -151,6 +151,77 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
     return out
 
 
+class PowerSampler:
+    """Socket power and shader clock of the card the process runs on, from the amdgpu hwmon files (plain sysfs reads, no GPU call),
+    sampled by a thread while a leg runs.  A box shows the hwmon of every card of its host: the card is the one whose power moved
+    most.  Used by the `power` leg only -- never inside the timed region of `value`."""
+
+    WANT = ("power1_average", "power1_input", "freq1_input", "temp2_input")
+
+    def __init__(self, period_s: float = 0.004):
+        import glob
+        self.hw = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            files = {k: os.path.join(d, k) for k in self.WANT + ("power1_cap",) if os.path.exists(os.path.join(d, k))}
+            if "freq1_input" in files and ("power1_average" in files or "power1_input" in files):
+                self.hw.append((d, files))
+        self.period = period_s
+        self.rows = []
+        self._stop = None
+        self._th = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                row = [time.perf_counter()]
+                for _, files in self.hw:
+                    pw = self._read(files.get("power1_average", files.get("power1_input", "")))
+                    row += [pw, self._read(files["freq1_input"]), self._read(files["temp2_input"]) if "temp2_input" in files else None]
+                self.rows.append(row)
+                time.sleep(self.period)
+
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._th.join()
+
+    def summary(self, t0: float, t1: float):
+        if not self.hw or not self.rows:
+            return None
+        best, span = None, -1.0
+        for h in range(len(self.hw)):
+            v = [r[1 + 3 * h] for r in self.rows if r[1 + 3 * h] is not None]
+            if v and max(v) - min(v) > span:
+                best, span = h, max(v) - min(v)
+        if best is None:
+            return None
+        sel = [r for r in self.rows if t0 <= r[0] <= t1]
+        pw = sorted(r[1 + 3 * best] / 1e6 for r in sel if r[1 + 3 * best] is not None)
+        fq = sorted(r[2 + 3 * best] / 1e6 for r in sel if r[2 + 3 * best] is not None)
+        tj = [r[3 + 3 * best] / 1e3 for r in sel if r[3 + 3 * best] is not None]
+        if not pw or not fq:
+            return None
+        cap = self._read(self.hw[best][1].get("power1_cap", ""))
+        return {"socket_power_w": {"mean": sum(pw) / len(pw), "median": pw[len(pw) // 2], "max": pw[-1]},
+                "sclk_mhz": {"mean": sum(fq) / len(fq), "median": fq[len(fq) // 2], "min": fq[0], "max": fq[-1]},
+                "junction_c_max": max(tj) if tj else None, "power_cap_w": cap / 1e6 if cap else None, "samples": len(sel),
+                "hwmon": self.hw[best][0], "cards_seen": len(self.hw)}
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -278,7 +349,8 @@ def main():
         return hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in points)).hexdigest()
 
     def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps, log_n: int = args.log_n, precompute: bool = not args.no_precompute,
-                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False, defer_calls: bool = not args.block_every_call):
+                     dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False, defer_calls: bool = not args.block_every_call,
+                     data: str = args.data):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
         n_streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
         streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
@@ -298,7 +370,7 @@ def main():
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
                 kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, lookup_round2=glue, fuse_round5=args.fuse_round5,
-                          data=args.data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls, hoist=not args.no_hoist)
+                          data=data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls, hoist=not args.no_hoist)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
                 else:
@@ -529,6 +601,26 @@ def main():
         "breakdown_note": f"msm_* / ntt_* are per-kernel-scope HIP-event times of {kb} extra proofs run right after the timed region with every scope on; "
                           "inside the timed region only msm_accumulate carries events (roofline)",
     }
+    # the second kernel family north_star names: the NTT passes, against the same HBM roofline (2 * 32 * N bytes per transform)
+    if ntt_ms:
+        ntt_ach = (r["ntt_bytes"] * kb) / (ntt_ms * 1e-3) / 1e9
+        ntt_traffic, ntt_src = None, None
+        ntt_pmc = os.path.join(ROOT, "profiles", "pmc_ntt.json")
+        if os.path.exists(ntt_pmc) and not main_sharded and log_n == 20 and cv.curve_id == 0:
+            try:
+                pm = json.load(open(ntt_pmc))
+                ntt_traffic = pm.get("hbm_bytes_per_proof")
+                ntt_src = {"file": "profiles/pmc_ntt.json", "collected": pm.get("collected"), "commit": pm.get("commit")}
+            except Exception:
+                ntt_traffic = None
+        line["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_mid<S> / ntt_pass_final<S>: every pass of the 31 transforms of a proof (17 of 2^%d, 14 of 2^%d)" % (log_n, log_n + 2),
+                                "achieved": ntt_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_ach / HBM_PEAK_GBS,
+                                "alg_bytes_per_proof": r["ntt_bytes"], "ms_per_proof": ntt_ms / kb, "calls_timed": int(ntt_n),
+                                "traffic": ntt_traffic, "traffic_unit": "HBM bytes per proof (all NTT passes)", "traffic_source": ntt_src,
+                                "timing": f"HIP events around every zk_ntt(_batch)_dev call of {kb} proofs run right after the timed region (the scopes "
+                                          "of the timed region itself carry msm_accumulate only)",
+                                "note": "three passes per transform: the vector crosses HBM three times and every mid pass also reads a pass-boundary "
+                                        "twiddle table of the vector's size; the passes are vector-issue bound (DESIGN.md 4.1), not HBM bound"}
     if args.grand_products:
         gp_ms, gp_n = r["prof"]["grand_product"]
         line["config"]["workload"] += " + z and z2 grand products on device"
@@ -544,6 +636,10 @@ def main():
         line["config"]["parallelism"] += f", {S} concurrent proof streams per GPU (kernel times below overlap other streams' work)"
     if args.check:
         line["commitments_sha256"] = r["digest"]
+
+    def acc_per_msm(rr):
+        a_ms, a_n = rr["prof"]["msm_accumulate"]
+        return a_ms / max(rr["prof"]["msm_accumulate_jobs"][1] or a_n, 1)
 
     def leg(name, fn):
         """an extra leg never takes the headline down; every rank agrees on its outcome first"""
@@ -570,11 +666,51 @@ def main():
         def blocking_leg():
             k2 = max(2, min(steps, 5))
             rb = timed_region(False, 1, k2, warmup=1, defer_calls=False)
-            b_ms, b_n = rb["prof"]["msm_accumulate"]
-            return {"proofs_per_s": k2 / rb["dt"], "ms_per_proof": rb["dt"] / k2 * 1e3, "steps": k2, "accumulate_avg_launch_ms": b_ms / max(b_n, 1),
+            return {"proofs_per_s": k2 / rb["dt"], "ms_per_proof": rb["dt"] / k2 * 1e3, "steps": k2, "accumulate_ms_per_msm": acc_per_msm(rb),
                     "what": "the same 29 MSMs with every one of the eleven PC calls blocking (zk_kzg_round_batch_dev per call), as an unchanged Prover::prove issues them",
                     "commitments_match": (rb["digest"] == r["digest"]) if args.check else None}
         leg("blocking_calls", blocking_leg)
+    if world == 1 and S == 1 and extra and args.data == "uniform" and not (args.dedup or args.grand_products or args.quotient):
+        def benchcircuit_leg():
+            # SURVEY.md 8d config 2's "realistic" vector on this very binary: wire columns as benches/plonk.rs' BenchCircuit builds them
+            # (composer.rs:493-548: periodic {6, 7, -20, 1} / {-20, 6, 7, 0} rows + 3 blinding rows, zero-padded) -- data-independence
+            k2 = 3
+            rc_ = timed_region(False, 1, k2, warmup=1, data="benchcircuit")
+            return {"proofs_per_s": k2 / rc_["dt"], "ms_per_proof": rc_["dt"] / k2 * 1e3, "steps": k2, "accumulate_ms_per_msm": acc_per_msm(rc_),
+                    "vs_uniform": (k2 / rc_["dt"]) / value, "commitments_sha256": rc_["digest"],
+                    "what": "--data benchcircuit: the same schedule over BenchCircuit-shaped wire columns (benches/plonk.rs:53-62); other inputs as in the headline"}
+        leg("data_benchcircuit", benchcircuit_leg)
+    if world == 1 and S == 1 and extra:
+        def power_leg():
+            # what bounds the step: socket power and shader clock while the headline schedule runs (hwmon, sampled by a host thread;
+            # a separate leg so that the sampler never runs inside the timed region of `value`)
+            n_ = 1 << log_n
+            ckq = zk.CommitterKey(build_srs(ctx, cv, n_, 0, n_, torch), cv, ctx)
+            if not args.no_precompute:
+                ckq.precompute(args.table_window)
+            sch = ProofSchedule(log_n, ctx, ckq, cv, defer_calls=not args.block_every_call, hoist=not args.no_hoist, ntt_batch=not args.no_ntt_batch)
+            k2 = max(12, min(4 * steps, 40))
+            with PowerSampler() as ps:
+                time.sleep(0.25)
+                for _ in range(2):
+                    sch.run_once()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k2):
+                    sch.run_once()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                time.sleep(0.1)
+            ckq.close()
+            out = ps.summary(t0, t1)
+            if out is None:
+                return {"error": "no amdgpu hwmon files readable on this host"}
+            out.update({"proofs": k2, "proofs_per_s_while_sampled": k2 / (t1 - t0),
+                        "joules_per_proof": out["socket_power_w"]["mean"] * (t1 - t0) / k2,
+                        "what": "amdgpu hwmon (power1_average|power1_input, freq1_input = sclk) every ~4 ms over a run of the headline schedule: the "
+                                "card holds its sustained power limit, not its 2.4 GHz peak clock, under msm_accumulate (profiles/r04_notes.md)"})
+            return out
+        leg("power", power_leg)
     if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
         def drop_in_leg():
             d = drop_in_region(max(2, min(steps, 3)))
@@ -688,8 +824,7 @@ def main():
             def nopre_leg():
                 k2 = max(2, min(steps, 3))
                 r4 = timed_region(False, 1, k2, precompute=False, warmup=1)
-                a_ms, a_n = r4["prof"]["msm_accumulate"]
-                return {"proofs_per_s": k2 / r4["dt"], "ms_per_proof": r4["dt"] / k2 * 1e3, "accumulate_avg_launch_ms": a_ms / max(a_n, 1),
+                return {"proofs_per_s": k2 / r4["dt"], "ms_per_proof": r4["dt"] / k2 * 1e3, "accumulate_ms_per_msm": acc_per_msm(r4),
                         "path": "per-window buckets, host Horner; bases read once per window, no 128-B row gathers of a table",
                         "commitments_match": (r4["digest"] == r["digest"]) if args.check else None}
             leg("no_precompute", nopre_leg)
@@ -699,10 +834,9 @@ def main():
         def shard_leg(lg):
             def run():
                 rs = timed_region(True, log_n=lg)
-                sa_ms, sa_n = rs["prof"]["msm_accumulate"]
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
                      "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per group of PC calls (5 per proof; 11 with --block-every-call)",
-                     "points_per_rank": rs["points_per_launch"], "accumulate_avg_launch_ms": sa_ms / max(sa_n, 1),
+                     "points_per_rank": rs["points_per_launch"], "accumulate_ms_per_msm": acc_per_msm(rs),
                      "commitments_sha256": rs["digest"]}
                 if lg == log_n:
                     d["speedup_vs_one_gpu_replica"] = (dt / steps) / (rs["dt"] / steps)

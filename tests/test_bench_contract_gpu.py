@@ -42,6 +42,15 @@ def test_bench_json_contract():
     assert d["full_proof"]["lean"]["same_proof_bytes"] is True and d["full_proof"]["lean"]["three_in_flight"]["same_proof_bytes"] is True
     assert d["with_device_glue"]["proofs_per_s"] > 0 and d["with_device_glue"]["lookup_round2_ms_per_proof"] > 0
     assert rf["valu"]["mixed_adds_per_scalar"] == 16 and "traffic_source" in rf
+    # one accumulation launch per group of PC calls: the line says how many MSMs / points an average launch held
+    assert rf["msms_per_launch"] >= 1 and abs(rf["alg_bytes_per_launch"] - 128.0 * rf["points_per_launch"]) < 1e-3 and rf["ms_per_msm"] > 0
+    # the NTT passes against the same roofline (north_star names both kernels), the BenchCircuit-shaped data on this binary, the power leg
+    rn = d["roofline_ntt"]
+    assert rn["bound"] == "hbm" and rn["peak"] == 8000.0 and rn["achieved"] > 0 and abs(rn["frac"] - rn["achieved"] / rn["peak"]) < 1e-12
+    assert rn["alg_bytes_per_proof"] == 17 * 64 * (1 << 13) + 14 * 64 * (1 << 15) and "traffic" in rn
+    bc = d["data_benchcircuit"]
+    assert bc["proofs_per_s"] > 0 and len(bc["commitments_sha256"]) == 64 and bc["commitments_sha256"] != d["commitments_sha256"]
+    assert "power" in d and ("socket_power_w" in d["power"] or "error" in d["power"])
 
 
 def test_bench_default_metric_is_baselines():

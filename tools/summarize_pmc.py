@@ -36,13 +36,36 @@ def main():
         o.write(f"command: `{cmd}`\n\n| kernel | launches | FETCH_SIZE raw | x2 (gfx950 correction) | WRITE_SIZE | HBM bytes per launch |\n|---|---|---|---|---|---|\n")
         for k, c, f, w in rows[:16]:
             o.write("| `%s` | %d | %.0f | %.0f | %.0f | %.3e |\n" % (k[:70], c, f, 2 * f, w, (2 * f + w) * 1024))
+    here = os.path.dirname(os.path.abspath(__file__))
+    commit = "unknown"
+    try:
+        commit = open(os.path.join(here, "..", ".git_head")).read().strip() or "unknown"
+    except OSError:
+        pass
+    import datetime
+    collected = f"{datetime.date.today().isoformat()}, 1x MI355X (gpurun box), tools/collect_profiles.sh {os.path.basename(out).split('_')[0]}: the same session as " \
+                f"{os.path.basename(out).split('_')[0]}_bench_n20.md / _pmc_sq.md / _pmc_clock.md (one discarded run first)"
     for k, c, f, w in rows:
         if "msm_accumulate" in k:
-            json.dump({"kernel": "msm_accumulate", "launches": c, "fetch_size_kib_raw": f, "write_size_kib": w,
+            # since round 4 one launch (msm_accumulate_batch) sums every MSM of a prover round: 5 launches and 29 MSMs per proof at the headline
+            # schedule, so the per-launch average below goes with bench.py's per-launch average of algorithmic bytes (the same launch mix)
+            json.dump({"kernel": k.split("(")[0].replace("void (anonymous namespace)::", "")[:60], "launches": c, "fetch_size_kib_raw": f, "write_size_kib": w,
                        "hbm_bytes_per_launch": (2 * f + w) * 1024,
                        "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `{cmd}`; per-launch averages; "
-                               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as read."},
+                               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as read.",
+                       "collected": collected, "commit": commit},
                       open(os.path.join(os.path.dirname(out), "pmc_msm_accumulate.json"), "w"), indent=1)
+            # the NTT passes of the same run, per proof: proofs = accumulate launches / launches per proof (ZK_ACC_LAUNCHES_PER_PROOF, default 5)
+            per_proof = int(os.environ.get("ZK_ACC_LAUNCHES_PER_PROOF", "5"))
+            proofs = max(1, c // per_proof)
+            tot = sum((2 * ff + ww) * 1024 * cc for kk, cc, ff, ww in rows if "ntt_pass" in kk)
+            json.dump({"kernels": "ntt_pass_mid<S> / ntt_pass_final<S>, every launch of the run", "proofs_in_run": proofs,
+                       "hbm_bytes_per_proof": tot / proofs,
+                       "alg_bytes_per_proof_n20": 17 * 2 * 32 * (1 << 20) + 14 * 2 * 32 * (1 << 22),
+                       "note": f"sum over the NTT pass kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB x launches, divided by the {proofs} proofs of `{cmd}` "
+                               "(counted from the accumulate launches); separate --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md",
+                       "collected": collected, "commit": commit},
+                      open(os.path.join(os.path.dirname(out), "pmc_ntt.json"), "w"), indent=1)
             break
     print(open(out + ".md").read())
 

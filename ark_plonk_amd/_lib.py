@@ -94,6 +94,8 @@ SYMBOLS = {
     "zk_srs_precompute": (c_int, [c_void_p, c_void_p]),
     "zk_srs_precompute_ex": (c_int, [c_void_p, c_void_p, c_u32]),
     "zk_srs_table_info": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
+    "zk_srs_precompute_rows": (c_int, [c_void_p, c_void_p, c_u32, c_u32, c_u32]),
+    "zk_srs_table_rows": (c_int, [c_void_p, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "zk_srs_retain": (c_int, [c_void_p]),
     "zk_srs_free": (None, [c_void_p]),
     "zk_srs_len": (c_size_t, [c_void_p]),
@@ -117,6 +119,10 @@ SYMBOLS = {
     "zk_kzg_round_end": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_end_partial": (c_int, [c_void_p, c_u32, c_void_p]),
     "zk_kzg_round_pending": (c_int, [c_void_p, ctypes.POINTER(c_u32)]),
+    "zk_partial_dev_bytes": (c_size_t, [c_int]),
+    "zk_kzg_round_reduce_partial_dev": (c_int, [c_void_p, c_void_p]),
+    "zk_kzg_round_end_partial_dev": (c_int, [c_void_p, c_u32, c_void_p]),
+    "zk_g1_sum_partials_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_abort": (c_int, [c_void_p]),
     "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),

@@ -63,6 +63,16 @@ void host_parallel_for(uint32_t n, const std::function<void(uint32_t)>& fn) {
 namespace {
 
 inline int fq_limbs64(int curve) { return curve == ZK_CURVE_BLS12_381 ? 6 : curve == ZK_CURVE_BN254 ? 4 : 0; }
+// Montgomery one of the base field, arkworks layout (u64 limbs)
+inline void fq_one_sat(int curve, uint64_t* out) {
+    if (curve == ZK_CURVE_BLS12_381) {
+        const FqBls o = FqBls::one();
+        memcpy(out, o.v, 48);
+    } else {
+        const FqBn o = FqBn::one();
+        memcpy(out, o.v, 32);
+    }
+}
 
 struct Guard {
     zk_ctx* c;
@@ -351,7 +361,7 @@ static size_t g_srs_idle_limit = (size_t)32 << 30;   // bytes of UNREFERENCED ca
 static uint64_t g_srs_hits = 0, g_srs_misses = 0;
 
 typedef std::shared_lock<std::shared_mutex> SrsReadLock;
-static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->pre_W ? s->pre_W : 1); }
+static size_t srs_bytes(const zk_srs* s) { return s->n * s->point_bytes * (s->d_pre ? 1 + s->pre_rows : s->pre_W ? s->pre_W : 1); }
 
 static void srs_destroy(zk_srs* s) {
     if (s->d_xy) {
@@ -360,6 +370,7 @@ static void srs_destroy(zk_srs* s) {
         if (prev != s->device) (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();     // kernels of any ctx may still read the bases
         (void)hipFree(s->d_xy);
+        if (s->d_pre) (void)hipFree(s->d_pre);
         if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     }
     delete s;
@@ -473,15 +484,28 @@ int zk_srs_register(zk_ctx* c, int curve_id, const uint64_t* bases_xy, const uin
     return srs_register_host(c, curve_id, bases_xy, inf_flags, n, out, n != 0);
 }
 
-int zk_srs_precompute_ex(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
+int zk_srs_precompute_rows(zk_ctx* c, zk_srs* s, uint32_t window_bits, uint32_t first_window, uint32_t window_stride) {
     if (!c || !s || s->device != c->device) return ZK_ERR_BAD_ARG;
     if (window_bits != 0 && (window_bits < 16 || window_bits > 21)) return ZK_ERR_BAD_ARG;
+    if (window_stride == 0 || first_window >= window_stride) return ZK_ERR_BAD_ARG;
     Guard g(c);
     std::unique_lock<std::shared_mutex> wl(s->mu);   // no MSM of any ctx is reading or enqueueing on this SRS
     if (s->n == 0) return ZK_OK;
-    if (s->pre_W) return (window_bits == 0 || window_bits == s->pre_c) ? ZK_OK : ZK_ERR_UNSUPPORTED;   // one table per SRS: the first precompute wins
+    if (s->pre_W)                                    // one table per SRS: the first precompute wins
+        return ((window_bits == 0 || window_bits == s->pre_c) && first_window == s->pre_w0 && window_stride == s->pre_wstep) ? ZK_OK : ZK_ERR_UNSUPPORTED;
     ZK_HIP_TRY(hipDeviceSynchronize());               // ... and none it enqueued earlier is still running
-    return msm_precompute_dev(c, s, window_bits);
+    return msm_precompute_dev(c, s, window_bits, first_window, window_stride);
+}
+
+int zk_srs_precompute_ex(zk_ctx* c, zk_srs* s, uint32_t window_bits) { return zk_srs_precompute_rows(c, s, window_bits, 0, 1); }
+
+int zk_srs_table_rows(zk_srs* s, uint32_t* first_window, uint32_t* window_stride, uint32_t* rows) {
+    if (!s) return ZK_ERR_BAD_ARG;
+    SrsReadLock rl(s->mu);
+    if (first_window) *first_window = s->pre_w0;
+    if (window_stride) *window_stride = s->pre_wstep;
+    if (rows) *rows = s->pre_rows;
+    return ZK_OK;
 }
 
 int zk_srs_precompute(zk_ctx* c, zk_srs* s) { return zk_srs_precompute_ex(c, s, 0); }
@@ -551,6 +575,17 @@ static int msm_partial_locked(zk_ctx* c, zk_srs* s, size_t base_offset, const vo
     int rc = srs_slice(s, base_offset, n, &d_bases);
     if (rc) return rc;
     if (s->pre_W && n >= ZK_PRE_MIN_N && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
+    if (s->pre_wstep > 1 && s->pre_w0 != 0) {
+        // window-sharded table: what the MSM entry points of this SRS return is the rank's PARTIAL, and the ranks' partials add up, so a
+        // vector that does not take the table path is computed (whole, per-window path) by the owner of window 0 only; here: infinity
+        const int L = fq_limbs64(s->curve);
+        uint64_t one[6];
+        fq_one_sat(s->curve, one);
+        memcpy(out_xyz, one, sizeof(uint64_t) * L);
+        memcpy(out_xyz + L, one, sizeof(uint64_t) * L);
+        memset(out_xyz + 2 * L, 0, sizeof(uint64_t) * L);
+        return ZK_OK;
+    }
     return msm_run_dev(c, s->curve, d_bases, d_scalars, n, out_xyz);
 }
 
@@ -809,6 +844,7 @@ static void round_clear(zk_ctx* c) {
     c->pend_n = 0;
     c->pend_srs = nullptr;
     c->pend_reduced = false;
+    c->pend_partials = nullptr;
     c->round_reduced = 0;
 }
 
@@ -892,6 +928,7 @@ static int round_end_locked(zk_ctx* c, uint32_t n_expected, uint64_t* out_xyz, u
     const uint32_t n = c->pend_n;
     zk_srs* s = c->pend_srs;
     if (n != n_expected) return ZK_ERR_BAD_ARG;          // the round stays open
+    if (c->pend_partials) return ZK_ERR_PENDING;         // reduced towards the device (zk_kzg_round_reduce_partial_dev): close it with _end_partial_dev
     if (n == 0) return ZK_OK;
     const int L = fq_limbs64(s->curve);
     uint32_t slots[16], nq = 0;
@@ -957,6 +994,78 @@ int zk_kzg_round_reduce(zk_ctx* c) {
     }
     c->pend_reduced = true;
     return ZK_OK;
+}
+
+// ---- the same round closed with its partials left ON THE DEVICE (multi-GPU exchange without a host hop)
+size_t zk_partial_dev_bytes(int curve_id) { return msm_partial_dev_bytes(curve_id); }
+
+// ctx lock held: queues everything up to every job's partial at d_out + k * zk_partial_dev_bytes (k = submission order)
+static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out) {
+    zk_srs* s = c->pend_srs;
+    const size_t pb = msm_partial_dev_bytes(s->curve);
+    uint32_t slots[16], nq = 0;
+    size_t qlens[16];
+    void* outs[16];
+    for (uint32_t k = 0; k < c->pend_n; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (pj.queued) {
+            slots[nq] = k;
+            qlens[nq] = pj.n;
+            outs[nq] = (char*)d_out + (size_t)k * pb;
+            ++nq;
+        } else if (!pj.have_xyz) {
+            return ZK_ERR_UNSUPPORTED;         // the commitment cache holds affine points only
+        }
+    }
+    if (nq) {
+        SrsRead rl(s->mu);
+        int rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens, outs);
+        if (rc) return rc;
+    }
+    // jobs computed at submission (vectors too short for the table path): their host Jacobian, converted, goes up in one small copy each
+    for (uint32_t k = 0; k < c->pend_n; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (pj.queued) continue;
+        unsigned char tmp[512];
+        if (pb > sizeof tmp) return ZK_ERR_UNSUPPORTED;
+        int rc = g1_jacobian_to_partial_host(s->curve, pj.xyz, tmp);
+        if (rc) return rc;
+        ZK_HIP_TRY(hipMemcpyAsync((char*)d_out + (size_t)k * pb, tmp, pb, hipMemcpyHostToDevice, c->stream));   // pageable source: staged before the call returns
+    }
+    c->pend_reduced = true;
+    c->pend_partials = d_out;
+    return ZK_OK;
+}
+
+int zk_kzg_round_reduce_partial_dev(zk_ctx* c, void* d_out) {
+    if (!c || !d_out) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (c->pend_n == 0) return ZK_OK;
+    if (c->pend_reduced) return c->pend_partials == d_out ? ZK_OK : ZK_ERR_PENDING;
+    return round_reduce_partial_dev_locked(c, d_out);
+}
+
+int zk_kzg_round_end_partial_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) {
+    if (!c || (n_jobs && !d_out)) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (c->pend_n != n_jobs) return ZK_ERR_BAD_ARG;           // the round stays open
+    if (n_jobs == 0) return ZK_OK;
+    int rc = ZK_OK;
+    if (!c->pend_reduced) rc = round_reduce_partial_dev_locked(c, d_out);
+    else if (c->pend_partials != d_out) rc = ZK_ERR_PENDING;    // reduced towards the host (zk_kzg_round_reduce) or towards another buffer
+    if (rc == ZK_ERR_PENDING || rc == ZK_ERR_UNSUPPORTED) return rc;   // nothing was queued by this call: the round stays open for the host form
+    if (rc) (void)hipStreamSynchronize(c->stream);          // as round_end_locked: kernels of the round may still read the inputs
+    round_clear(c);
+    return rc;
+}
+
+int zk_g1_sum_partials_dev(zk_ctx* c, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    if (n_jobs == 0) return ZK_OK;
+    if (!c || !d_partials || !out_xy || ranks == 0) return ZK_ERR_BAD_ARG;
+    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;               // the pinned buffer belongs to the open round
+    return g1_sum_partials_dev(c, curve_id, d_partials, ranks, n_jobs, out_xy, out_inf);
 }
 
 int zk_kzg_round_end(zk_ctx* c, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {

@@ -267,6 +267,7 @@ struct zk_ctx {
     };
     uint32_t pend_n = 0;
     bool pend_reduced = false;      // zk_kzg_round_reduce ran: the round takes no further jobs, zk_kzg_round_end only waits
+    void* pend_partials = nullptr;  // ... as zk_kzg_round_reduce_partial_dev: the jobs' partials are (being) written there, on the device
     hipEvent_t round_ev = nullptr;  // recorded behind the reduction kernels of a round (msm_batch_pre_reduce)
     uint32_t round_reduced = 0;     // jobs whose reductions are queued behind round_ev (0: none)
     zk_srs* pend_srs = nullptr;
@@ -291,8 +292,13 @@ struct zk_srs {
     size_t point_bytes = 0;
     // optional table of window multiples 2^(c*w) * P_i, w = 1 .. pre_W-1, window-major (n points each);
     // with it all windows of an MSM share ONE bucket set (no per-window reduction, no host doublings)
+    // Window-sharded table (zk_srs_precompute_rows: one rank of a multi-GPU MSM owns the windows first, first + stride, ...): the rows
+    // live in d_pre (pre_rows x n points, row j = 2^(c (first + j stride)) P_i) and d_xy stays the plain SRS; with the whole table
+    // (stride 1) d_pre is null and d_xy IS the table, row 0 being the SRS itself.
     void* d_pre = nullptr;
-    uint32_t pre_c = 0, pre_W = 0;
+    uint32_t pre_c = 0, pre_W = 0;         // window bits, windows of a full-width scalar (all ranks' rows together)
+    uint32_t pre_rows = 0, pre_w0 = 0, pre_wstep = 1;
+    const void* table() const { return d_pre ? d_pre : d_xy; }
 };
 
 // profiling helpers (ctx mutex held by caller)
@@ -321,7 +327,7 @@ int fr_mul_dev(zk_ctx* c, int curve, const void* a, const void* b, size_t n, voi
 int msm_run_dev(zk_ctx* c, int curve, const void* d_bases_xy, const void* d_scalars, size_t n, uint64_t* out_xyz);
 int msm_fixed_base_dev(zk_ctx* c, int curve, const void* d_scalars, size_t n, void* d_out_xy);
 // window-multiples table of an SRS (see zk_srs::d_pre) and the MSM that uses it
-int msm_precompute_dev(zk_ctx* c, zk_srs* s, uint32_t window_bits /* 0 = default (16); 16 .. 21 */);
+int msm_precompute_dev(zk_ctx* c, zk_srs* s, uint32_t window_bits /* 0 = default (16); 16 .. 21 */, uint32_t first_window = 0, uint32_t window_stride = 1);
 int msm_run_pre_dev(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz);
 // a batch of commitments over one SRS, queued back to back; the host blocks once per result
 // out_xy / out_inf (optional): also normalise every result to affine (n_polys x 2L limbs, n_polys flags)
@@ -333,7 +339,11 @@ int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const*
 // jobs in slots[0 .. n_jobs) with one launch per reduction kernel, wait once, combine on the host
 int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                             const uint8_t* kinds = nullptr, const std::function<int(uint32_t)>* before_job = nullptr);
-int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens);
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr);
+// multi-GPU exchange on the device: a partial = one point in the internal XYZZ form
+size_t msm_partial_dev_bytes(int curve);
+int g1_sum_partials_dev(zk_ctx* c, int curve, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
+int g1_jacobian_to_partial_host(int curve, const uint64_t* xyz, void* out);
 int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
                           uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);

@@ -115,6 +115,16 @@ struct MsmGeom {
     uint32_t neg = 0;
     uint32_t half[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t mod[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Window-sharded table (one rank of a multi-GPU MSM owns the windows w0, w0 + wstep, ...): the digit kernels walk all Wt windows of
+    // the scalar -- the carries run through every window -- and keep the digits of the owned ones as rows 0 .. W-1 of the digit array;
+    // everything behind them sees an MSM of W windows.  Whole table: Wt = W, w0 = 0, wstep = 1.
+    uint32_t Wt = 0, w0 = 0, wstep = 1;
+    ZK_HD bool owns(uint32_t w, uint32_t& row) const {
+        if (w < w0) return false;
+        const uint32_t d = w - w0;
+        row = d / wstep;
+        return d == row * wstep && row < W;
+    }
 };
 
 // The kernels behind a prover round take up to 16 jobs (blockIdx.y, or a block-range table): the MSMs of one round are
@@ -223,11 +233,13 @@ __global__ void msm_digits(const uint32_t* scalars, uint64_t n, MsmGeom g, int16
     const bool flip = scalar_fold(s, g);
     uint32_t carry = 0;
     const uint32_t half = 1u << (g.c - 1);
-    for (uint32_t w = 0; w < g.W; ++w) {
+    for (uint32_t w = 0; w < g.Wt; ++w) {
         uint32_t raw = scalar_bits(s, w * g.c, g.c) + carry;
         carry = raw >= half ? 1u : 0u;
         int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
-        dig[(uint64_t)w * n + i] = (int16_t)(flip ? -d : d);
+        uint32_t row;
+        // (the int16 store cannot hold -(-32768): make_geom never folds scalars at c = 16, see the assert there)
+        if (g.owns(w, row)) dig[(uint64_t)row * n + i] = (int16_t)(flip ? -d : d);
     }
 }
 
@@ -747,12 +759,14 @@ __global__ void __launch_bounds__(256) psortw_digits_hist(const uint32_t* scalar
         if (MONT) x = Fr::from_mont(x);
         const bool flip = scalar_fold(x.v, g);
         uint32_t carry = 0;
-        for (uint32_t w = 0; w < g.W; ++w) {
+        for (uint32_t w = 0; w < g.Wt; ++w) {
             const uint32_t raw = (scalar_bits(x.v, w * g.c, g.c) & cmask) + carry;
             carry = raw >= half ? 1u : 0u;
             int32_t d = carry ? (int32_t)raw - (int32_t)(1u << g.c) : (int32_t)raw;
             if (flip) d = -d;
-            dig[(uint64_t)w * n + i] = d;
+            uint32_t row;
+            if (!g.owns(w, row)) continue;
+            dig[(uint64_t)row * n + i] = d;
             if (d != 0) atomicAdd(&lc[(uint32_t)((d < 0 ? -d : d) - 1) >> lob], 1u);
         }
     }
@@ -1564,6 +1578,10 @@ __global__ void __launch_bounds__(128) g1_fixed_base(const uint32_t* scalars, ui
 }
 
 // ---------------------------------------------------------------------------------------- host side
+int ensure_pinned(zk_ctx* c, size_t bytes);
+template <class Fq>
+XYZZ<Fq> jac_to_xyzz(const uint64_t* xyz);
+
 // msm_win_finish_q with `chains` (a power of two <= 256) chains of four lanes per workgroup
 template <class F>
 int launch_win_finish_q(dim3 grid, uint32_t chains, hipStream_t st, const RJobs& jobs, const MsmGeom& g, uint32_t raw) {
@@ -1585,7 +1603,8 @@ int launch_win_finish_q(dim3 grid, uint32_t chains, hipStream_t st, const RJobs&
 
 // combine + segmented reduction of n_jobs MSMs that share the geometry (nb buckets, reduction geometry gr)
 template <class F>
-int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st, bool queues_cleared = false) {
+int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, const MsmGeom& gr, hipStream_t st, bool queues_cleared = false,
+                 uint32_t raw = 0 /* 1: the window sums stay in the internal point form (device buffers), quad geometry only */) {
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     ProfScope ps(c, "msm_reduce", st);
     const int T = 128;
@@ -1625,8 +1644,9 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
         uint32_t chains = 1;
         while (chains < gr.ns) chains <<= 1;
         size_t shmem = (size_t)chains * PT;
-        if ((rc = launch_win_finish_q<F>(dim3(gr.W, n_jobs), chains, st, jobs, gr, 0u))) return rc;
+        if ((rc = launch_win_finish_q<F>(dim3(gr.W, n_jobs), chains, st, jobs, gr, raw))) return rc;
     } else {
+        if (raw) return ZK_ERR_UNSUPPORTED;
         unsigned sblocks = (gr.W * gr.ns + T - 1) / T;
         hipLaunchKernelGGL(msm_seg_reduce<F>, dim3(sblocks, n_jobs), dim3(T), 0, st, jobs, gr);
         size_t shmem = 256 * PT;
@@ -1793,7 +1813,10 @@ MsmGeom make_geom(uint64_t n, int c_override, uint32_t max_c = 16) {
         uint32_t Wn = ((uint32_t)bits - 1 + c - 1) / c;
         if (Wn == 0) Wn = 1;
         if (modulus_minus_one_bits<FrP>((Wn - 1) * c + 1) + 1 >= (1u << (c - 1))) Wn += 1;     // ((r - 1) / 2) >> shift = (r - 1) >> (shift + 1)
-        if (Wn < g.W && FrP::N == 8) {
+        // Folded scalars flip the digits' signs, and -(-2^(c-1)) does not fit the int16 digits of the c <= 16 paths at c = 16: the
+        // fold is taken only below 16 bits or with the int32 digits of the wide path (c > 16).  (No supported curve asks for it at
+        // c = 16 -- 16 windows either way for 254- and 255-bit scalars -- so this only guards a third curve or a changed rule.)
+        if (Wn < g.W && FrP::N == 8 && c != 16) {
             g.W = Wn;
             g.neg = 1;
             uint32_t w[9];
@@ -1803,6 +1826,7 @@ MsmGeom make_geom(uint64_t n, int c_override, uint32_t max_c = 16) {
             for (int i = 0; i < 8; ++i) g.half[i] = (w[i] >> 1) | (w[i + 1] << 31);
         }
     }
+    g.Wt = g.W;
     g.B = 1u << (c - 1);
     g.nb = g.W * g.B;
     g.logG = c - 1 < 4 ? c - 1 : 4;
@@ -1930,29 +1954,35 @@ int msm_run(zk_ctx* c, const void* d_bases, const void* d_scalars, size_t n, uin
 // and the running product of the ZZZ in `scratch`, RB x n x 3 field elements), ONE inversion of the product, and a backward sweep
 // that peels off every 1/ZZZ_j (Montgomery's trick along the chain): 6 products per row + 1/RB of an inversion on top of the doublings.
 constexpr uint32_t CHAIN_RB = 32;
+// rows: table rows this launch computes, written at table rows out0, out0 + 1, ...; the chain starts from the point src[i] and
+// takes d0 doublings to the first computed row and dstep between rows.  Whole table: src = row 0 (the SRS itself), out0 = 1,
+// d0 = dstep = c.  Window-sharded table (rows first, first + stride, ...): d0 = c * first (row 0 is the copy of the SRS when
+// first = 0, so out0 = 1 and d0 = dstep there), dstep = c * stride.
 template <class F>
-__global__ void __launch_bounds__(128) msm_precompute(void* table, uint64_t n, uint32_t c, uint32_t W, void* scratch) {
+__global__ void __launch_bounds__(128) msm_precompute(void* table, const void* src, uint64_t n, uint32_t d0, uint32_t dstep, uint32_t rows, uint32_t out0,
+                                                      void* scratch) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int U4 = Store<F>::U4;
     uint4* base = reinterpret_cast<uint4*>(table);
     uint4* scr = reinterpret_cast<uint4*>(scratch);
-    auto row = [&](uint32_t r) { return base + ((uint64_t)r * n + i) * (2 * U4); };
+    auto row = [&](uint32_t r) { return base + ((uint64_t)(out0 + r) * n + i) * (2 * U4); };
     auto sc = [&](uint32_t j, uint32_t which) { return scr + (((uint64_t)j * n + i) * 3 + which) * U4; };     // 0 ZZ, 1 ZZZ, 2 prefix product
-    AffineU<F> p = ld_affine<F>(table, i);
+    AffineU<F> p = ld_affine<F>(src, i);
     if (p.is_null()) {
-        for (uint32_t r = 1; r < W; ++r) {
+        for (uint32_t r = 0; r < rows; ++r) {
             st_fu<F>(row(r), F::zero());
             st_fu<F>(row(r) + U4, F::zero());
         }
         return;
     }
     XYZZu<F> acc = XYZZu<F>::from_affine(p);
-    for (uint32_t r0 = 1; r0 < W; r0 += CHAIN_RB) {
-        const uint32_t m = W - r0 < CHAIN_RB ? W - r0 : CHAIN_RB;
+    for (uint32_t r0 = 0; r0 < rows; r0 += CHAIN_RB) {
+        const uint32_t m = rows - r0 < CHAIN_RB ? rows - r0 : CHAIN_RB;
         F prefix = F::one();
         for (uint32_t j = 0; j < m; ++j) {
-            for (uint32_t k = 0; k < c; ++k) acc = XYZZu<F>::dbl(acc);   // a point of odd prime order never doubles to infinity
+            const uint32_t nd = r0 + j == 0 ? d0 : dstep;
+            for (uint32_t k = 0; k < nd; ++k) acc = XYZZu<F>::dbl(acc);   // a point of odd prime order never doubles to infinity
             st_fu<F>(row(r0 + j), acc.x);
             st_fu<F>(row(r0 + j) + U4, acc.y);
             st_fu<F>(sc(j, 0), acc.zz);
@@ -1983,7 +2013,7 @@ constexpr uint32_t PRE_VW = 64;       // virtual windows for the final bucket re
                                       // (256 registers per lane; with 32 windows the 1024-lane workgroup spilled at 128)
 
 template <class Cv>
-int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
+int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits, uint32_t w0, uint32_t wstep) {
     typedef typename Cv::FqU F;
     // default window: 16 bits (16 rows, 2^15 buckets) below 2^19 points; from there on 17 bits, which scalars folded to
     // k <= (r - 1) / 2 (MsmGeom::neg) cover in 15 windows -- one mixed addition per scalar fewer for twice the buckets to reduce
@@ -1991,24 +2021,31 @@ int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
     if (window_bits == 0) window_bits = s->n >= (1u << 19) ? PRE_C + 1 : PRE_C;
     if (window_bits < PRE_C || window_bits > PRE_C_MAX) return ZK_ERR_BAD_ARG;
     MsmGeom g = make_geom<typename Cv::FrP>(1u << 20, (int)window_bits, PRE_C_MAX);
+    if (wstep == 0 || w0 >= wstep || w0 >= g.W) return ZK_ERR_BAD_ARG;
+    const uint32_t rows = (g.W - w0 + wstep - 1) / wstep;         // windows w0, w0 + wstep, ... < W
+    const bool whole = wstep == 1;
     const size_t pb = s->point_bytes;
     void* tab = nullptr;
     void* scratch = nullptr;
-    if (hipMalloc(&tab, (size_t)g.W * s->n * pb) != hipSuccess) {
+    if (hipMalloc(&tab, (size_t)rows * s->n * pb) != hipSuccess) {
         (void)hipGetLastError();
         return ZK_ERR_OOM;
     }
-    const uint32_t rb = g.W - 1 < CHAIN_RB ? g.W - 1 : CHAIN_RB;
+    // row 0 is a copy of the SRS when the first owned window is window 0; the chain computes the others
+    const uint32_t out0 = w0 == 0 ? 1u : 0u, chain_rows = rows - out0;
+    const uint32_t rb = chain_rows < CHAIN_RB ? chain_rows : CHAIN_RB;
     if (hipMalloc(&scratch, (size_t)(rb ? rb : 1) * s->n * 3 * (pb / 2)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(tab);
         return ZK_ERR_OOM;
     }
-    hipError_t e = hipMemcpyAsync(tab, s->d_xy, s->n * pb, hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess) {
+    hipError_t e = hipSuccess;
+    if (w0 == 0) e = hipMemcpyAsync(tab, s->d_xy, s->n * pb, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && chain_rows) {
         const int T = 128;
         unsigned blocks = (unsigned)((s->n + T - 1) / T);
-        hipLaunchKernelGGL(msm_precompute<F>, dim3(blocks), dim3(T), 0, c->stream, tab, (uint64_t)s->n, g.c, g.W, scratch);
+        hipLaunchKernelGGL(msm_precompute<F>, dim3(blocks), dim3(T), 0, c->stream, tab, (const void*)s->d_xy, (uint64_t)s->n,
+                           w0 == 0 ? g.c * wstep : g.c * w0, g.c * wstep, chain_rows, out0, scratch);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -2018,10 +2055,17 @@ int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits) {
         zk_note_hip_error(e, "msm_precompute", __FILE__, __LINE__);
         return ZK_ERR_HIP;
     }
-    (void)hipFree(s->d_xy);
-    s->d_xy = tab;      // row 0 of the table is the SRS itself
+    if (whole) {
+        (void)hipFree(s->d_xy);
+        s->d_xy = tab;      // row 0 of the table is the SRS itself
+    } else {
+        s->d_pre = tab;     // the rank's rows; d_xy stays the plain SRS (vectors too short for the table path)
+    }
     s->pre_c = g.c;
     s->pre_W = g.W;
+    s->pre_rows = rows;
+    s->pre_w0 = w0;
+    s->pre_wstep = wstep;
     return ZK_OK;
 }
 
@@ -2052,6 +2096,10 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
     pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
+    pl.g.w0 = s->pre_w0;                                // a window-sharded table: this rank's rows only (W of the Wt windows)
+    pl.g.wstep = s->pre_wstep;
+    pl.g.W = s->pre_rows;
+    pl.g.nb = pl.g.W * pl.g.B;
     pl.wide = pl.g.c > 16;
     pl.wide_red = pl.g.B > (1u << 16);
     pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
@@ -2146,7 +2194,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
         if ((rc = mb.seg3.ensure((size_t)4 * 256 * PT))) return rc;         // level 4: (run, acc) of <= 256 segments for each of S, T
     } else {
         if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
-        if ((rc = mb.win.ensure(pl.win_bytes))) return rc;
+        if ((rc = mb.win.ensure(pl.win_bytes > (size_t)2 * pl.gv.W * PT ? pl.win_bytes : (size_t)2 * pl.gv.W * PT))) return rc;   // SAT or internal form
     }
     return ZK_OK;
 }
@@ -2183,7 +2231,7 @@ int pre_queue_digits(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_sc
     }
     if (!pre_psort16(pl)) return ZK_ERR_UNSUPPORTED;     // the table windows are 16 .. 21 bits: 2^15 buckets = 256 partitions of 128
     int16_t* dig = (int16_t*)mb.tmp.p;
-    const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16 && !pl.g.neg;        // two scalars per lane
+    const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16 && pl.g.Wt == 16 && !pl.g.neg;        // two scalars per lane
     const uint32_t P = pl.g1.nb >> PS_LOB;
     uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 partition starts | P totals | scan counter
     uint32_t* part_total = part_start + P + 1;
@@ -2292,20 +2340,24 @@ int pre_queue_accumulate(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, con
         c->prof["msm_accumulate_jobs"].launches += n_jobs;
         c->prof["msm_accumulate_points"].launches += points;
     }
-    hipLaunchKernelGGL(msm_accumulate_batch<F>, dim3((unsigned)blocks), dim3(T), 0, st, aj, pls[0].g1.nb, s->d_xy, (uint64_t)s->n);
+    hipLaunchKernelGGL(msm_accumulate_batch<F>, dim3((unsigned)blocks), dim3(T), 0, st, aj, pls[0].g1.nb, s->table(), (uint64_t)s->n);
     ZK_HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
 
 // fused reduction of the jobs mbs[0..n_jobs) (same geometry) + read-back of their virtual-window sums
 // into h_win (n_jobs x win_bytes)
+// d_partials (optional, n_jobs pointers): instead of the virtual-window sums going to the host, every job's whole sum
+//   sum_v S_v + B_v sum_v v T_v  is formed on the device (one more msm_win_finish_q launch over the VW pairs of each job) and left
+// at d_partials[k] as ONE point in the internal XYZZ form (zk_partial_dev_bytes): the multi-GPU exchange reads it from there.
 template <class Cv>
-int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_t n_jobs, void* h_win, hipStream_t st) {
+int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_t n_jobs, void* h_win, hipStream_t st, void* const* d_partials = nullptr) {
     typedef typename Cv::FqU F;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     RJobs jobs;
     memset(&jobs, 0, sizeof jobs);
     const PrePlan& p0 = pls[0];
+    if (d_partials && p0.wide_red) return ZK_ERR_UNSUPPORTED;     // tables with c >= 18 finish on the host (queue_reduce_wide)
     for (uint32_t k = 0; k < n_jobs; ++k) {
         MsmBufs& mb = *mbs[k];
         jobs.part_pt[k] = mb.part_pt.p;
@@ -2316,8 +2368,13 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         jobs.seg_acc[k] = (char*)mb.seg.p + (p0.wide_red ? (size_t)(p0.g.B >> WIDE_LOGG1) : (size_t)p0.gv.W * p0.gv.ns) * PT;
         // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
         // buffer (hipHostMalloc memory is device-visible): no copy launches at the tail of the call
-        jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
-        jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
+        if (d_partials) {
+            jobs.win_s[k] = (uint32_t*)mb.win.p;                                            // S_v | T_v, internal form, on the device
+            jobs.win_t[k] = (uint32_t*)((char*)mb.win.p + (size_t)p0.gv.W * PT);
+        } else {
+            jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
+            jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
+        }
         jobs.L[k] = pls[k].chunk_l;
         jobs.lanes[k] = pls[k].n_lanes;
         jobs.nbk[k] = p0.g1.nb;
@@ -2334,8 +2391,106 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         }
         return queue_reduce_wide<F>(c, jobs, n_jobs, p0.g1.nb, d_vw, d_seg3, d_seg2, (char*)h_win, p0.win_bytes, st);
     }
-    return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
+    if (!d_partials) return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
+    int rc = queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true, 1u);
+    if (rc) return rc;
+    // the VW pairs of a job as one "window" of VW chains: R_u = T_u, Y_u = S_u, Z = sum_u S_u + B_v * sum_u u T_u
+    uint32_t chains = 1;
+    while (chains < p0.gv.W) chains <<= 1;
+    if (chains != p0.gv.W || chains > 128) return ZK_ERR_UNSUPPORTED;
+    MsmGeom gf;
+    memset(&gf, 0, sizeof gf);
+    gf.W = 1;
+    gf.ns = p0.gv.W;
+    gf.logG = ilog2_floor(p0.gv.B);
+    RJobs jf;
+    memset(&jf, 0, sizeof jf);
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        jf.seg_acc[k] = jobs.win_s[k];
+        jf.seg_run[k] = jobs.win_t[k];
+        jf.win_s[k] = (uint32_t*)d_partials[k];
+        jf.win_t[k] = nullptr;
+    }
+    ProfScope ps(c, "msm_reduce", st);
+    if ((rc = launch_win_finish_q<F>(dim3(1, n_jobs), chains, st, jf, gf, 1u))) return rc;
+    ZK_HIP_TRY(hipGetLastError());
+    return ZK_OK;
 }
+
+// sum over the ranks of every job's device partial (ranks x n_jobs points as the all-gather leaves them) -> n_jobs points,
+// arkworks layout, straight into pinned host memory: one quad per job, ranks - 1 dependent additions
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) g1_sum_partials_q(const void* parts, uint32_t ranks, uint32_t n_jobs, uint32_t* out_sat) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = tid >> 2, role = tid & 3;
+    const bool live = k < n_jobs;                  // no early exit: wave shuffles inside qadd
+    F acc = F::zero();
+#pragma unroll 1
+    for (uint32_t r = 0; r < ranks; ++r) acc = qadd<F>(acc, live ? ld_coord<F>(parts, (uint64_t)r * n_jobs + k, role) : F::zero(), role);
+    const bool inf = quad_is_inf(acc, role);
+    if (live) {
+        uint32_t* o = out_sat + (size_t)k * 4 * F::SAT + role * F::SAT;
+        if (inf) {
+            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        } else {
+            acc.to_sat(o);
+        }
+    }
+}
+
+template <class Cv>
+int sum_partials_dev(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    typedef typename Cv::Fq Fq;
+    typedef typename Cv::FqU F;
+    typedef XYZZ<Fq> PH;
+    constexpr int L64 = Fq::N / 2;
+    if (n_jobs == 0) return ZK_OK;
+    if (ranks == 0 || ranks > 4096 || n_jobs > 4096) return ZK_ERR_BAD_ARG;
+    int rc = ensure_pinned(c, (size_t)n_jobs * sizeof(PH) > (size_t)MAX_JOBS * 4096 ? (size_t)n_jobs * sizeof(PH) : (size_t)MAX_JOBS * 4096);
+    if (rc) return rc;
+    const unsigned blocks = (n_jobs * 4 + 255) / 256;
+    hipLaunchKernelGGL(g1_sum_partials_q<F>, dim3(blocks), dim3(256), 0, c->stream, d_parts, (uint32_t)ranks, n_jobs, (uint32_t*)c->pinned);
+    ZK_HIP_TRY(hipGetLastError());
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    const PH* h = (const PH*)c->pinned;
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        Affine<Fq> a;
+        uint64_t* xy = out_xy + (size_t)k * 2 * L64;
+        if (!h[k].to_affine(a)) {
+            const Fq one = Fq::one();
+            memset(xy, 0, sizeof(uint64_t) * L64);
+            memcpy(xy + L64, one.v, sizeof(uint64_t) * L64);        // GroupAffine::zero() = (0, 1, infinity)
+            if (out_inf) out_inf[k] = 1;
+        } else {
+            memcpy(xy, a.x.v, sizeof(uint64_t) * L64);
+            memcpy(xy + L64, a.y.v, sizeof(uint64_t) * L64);
+            if (out_inf) out_inf[k] = 0;
+        }
+    }
+    return ZK_OK;
+}
+
+// a host Jacobian point (X, Y, Z: what the blocking entry points return) in the device partial form, for jobs of a round that
+// were computed at submission (vectors too short for the table path)
+template <class Cv>
+void jacobian_to_partial_host(const uint64_t* xyz, void* out) {
+    typedef typename Cv::Fq Fq;
+    typedef typename Cv::FqU F;
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    constexpr int L64 = Fq::N / 2;
+    memset(out, 0, PT);
+    Fq Z;
+    memcpy(Z.v, xyz + 2 * L64, sizeof(uint64_t) * L64);
+    if (Z.is_zero()) return;                       // infinity: all limbs zero
+    const XYZZ<Fq> p = jac_to_xyzz<Fq>(xyz);
+    const Fq* co[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+    for (int r = 0; r < 4; ++r) {
+        const F v = F::canonical_lt2p(F::from_sat((const uint32_t*)co[r]->v));
+        uint32_t* w = (uint32_t*)out + (size_t)r * Store<F>::WORDS;
+        for (int i = 0; i < F::NL; ++i) w[i] = (uint32_t)v.v[i];
+    }
+}
+
 
 // wide reduction: h = [sum_v S_v (as win: unused), sum_v S_v (tot) | K = sum_v (v+1) T_v, sum_v T_v]; buckets per virtual window = 2^log_bv
 template <class Cv>
@@ -2502,7 +2657,7 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
 // results) BEHIND the reductions before it waits: `reduce` queues everything up to the reduction kernels and an event, `end` waits
 // for that event only -- the work queued in between runs while the host combines the window sums and normalises.
 template <class Cv>
-int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
+int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
@@ -2537,7 +2692,7 @@ int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* 
         if ((rc = pre_queue_accumulate<Cv>(c, dpl, dmb, dlen, nullptr, nd, s, st))) return rc;
         for (uint32_t k = 0; k < nd; ++k) dmb[k]->stage_of_job = 2;
     }
-    if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st))) return rc;
+    if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st, d_partials))) return rc;
     for (uint32_t k = 0; k < n_jobs; ++k) mbs[k]->stage_of_job = 0;
     if (!c->round_ev) ZK_HIP_TRY(hipEventCreateWithFlags(&c->round_ev, hipEventDisableTiming));
     ZK_HIP_TRY(hipEventRecord(c->round_ev, st));
@@ -2709,7 +2864,9 @@ int ZK_SYM(msm_convert_bases_dev)(zk_ctx* c, const void* d_xy_sat, const uint8_t
     return ZK_OK;
 }
 
-int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s, uint32_t window_bits) { return msm_precompute_run<CurveSel>(c, s, window_bits); }
+int ZK_SYM(msm_precompute_dev)(zk_ctx* c, zk_srs* s, uint32_t window_bits, uint32_t w0, uint32_t wstep) {
+    return msm_precompute_run<CurveSel>(c, s, window_bits, w0, wstep);
+}
 
 int ZK_SYM(msm_run_pre_dev)(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars, size_t n, uint64_t* out_xyz) {
     return msm_run_pre<CurveSel>(c, s, base_offset, d_scalars, n, out_xyz);
@@ -2723,9 +2880,14 @@ int ZK_SYM(msm_batch_pre_begin_dev)(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32
                                     const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
     return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
 }
-int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens) {
-    return msm_batch_pre_reduce<CurveSel>(c, s, n_jobs, slots, lens);
+int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials) {
+    return msm_batch_pre_reduce<CurveSel>(c, s, n_jobs, slots, lens, d_partials);
 }
+size_t ZK_SYM(msm_partial_dev_bytes)() { return (size_t)4 * Store<CurveSel::FqU>::WORDS * 4; }
+int ZK_SYM(g1_sum_partials_dev)(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    return sum_partials_dev<CurveSel>(c, d_parts, ranks, n_jobs, out_xy, out_inf);
+}
+void ZK_SYM(g1_jacobian_to_partial_host)(const uint64_t* xyz, void* out) { jacobian_to_partial_host<CurveSel>(xyz, out); }
 int ZK_SYM(msm_batch_pre_end_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
                                   uint64_t* out_xy, uint8_t* out_inf) {
     return msm_batch_pre_end<CurveSel>(c, s, n_jobs, slots, lens, out_xyz, out_xy, out_inf);

@@ -90,13 +90,25 @@ class CommitterKey:
     def __len__(self):
         return self.n
 
-    def precompute(self, window_bits: int = 0):
+    def precompute(self, window_bits: int = 0, rows=None):
         """Build the window-multiples table; later MSMs share one bucket set.  window_bits: 0 = default (c = 16, 16 rows, below 2^19
         points; c = 17 from there on: 15 rows for 255-bit scalars, which are folded to k <= (r - 1) / 2), else 16 .. 21 (fewer rows =
-        fewer additions per scalar, more buckets to reduce)."""
+        fewer additions per scalar, more buckets to reduce).
+        rows = (g, G): the multi-GPU form sharded by WINDOWS -- this rank builds only the rows of the windows g, g + G, ... of the
+        whole SRS, and every MSM / commit over the key returns the rank's partial (zk_srs_precompute_rows)."""
         self.ctx.use_torch_stream() if _has_torch_cuda() else None
-        check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
+        if rows is None:
+            check(lib().zk_srs_precompute_ex(self.ctx.handle, self._h, int(window_bits)), "zk_srs_precompute_ex")
+        else:
+            g, G = rows
+            check(lib().zk_srs_precompute_rows(self.ctx.handle, self._h, int(window_bits), int(g), int(G)), "zk_srs_precompute_rows")
         return self
+
+    def table_rows(self):
+        """(first_window, window_stride, rows) of the table this key holds: (0, 1, windows) for a whole table."""
+        a, b, r = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib().zk_srs_table_rows(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(r)), "zk_srs_table_rows")
+        return a.value, b.value, r.value
 
     def table_windows(self) -> int:
         """rows of the window table = mixed additions per scalar on the shared-bucket path (0: no table)."""
@@ -280,6 +292,34 @@ class CommitterKey:
         out = np.zeros((max(k, 1), 3 * L), dtype=np.uint64)
         check(lib().zk_kzg_round_end_partial(self.ctx.handle, k, ptr_of(out)), "zk_kzg_round_end_partial")
         return out[:k]
+
+    def partial_dev_words(self) -> int:
+        """int64 words of one device-side partial (zk_partial_dev_bytes / 8)."""
+        return lib().zk_partial_dev_bytes(self.curve.curve_id) // 8
+
+    def round_reduce_partial_dev(self, d_out):
+        """`round_reduce` for the device form of the exchange: the jobs' partials are written (by the last reduction kernel) into the
+        device tensor `d_out` (jobs x partial_dev_words int64), typically the collective's send buffer."""
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_round_reduce_partial_dev(self.ctx.handle, d_out.data_ptr()), "zk_kzg_round_reduce_partial_dev")
+
+    def round_end_partial_dev(self, d_out, n_jobs: int | None = None):
+        """Close the round leaving every job's partial ON THE DEVICE in `d_out` (no host wait): see the header."""
+        k = self.round_pending() if n_jobs is None else n_jobs
+        if d_out.numel() < k * self.partial_dev_words():
+            raise ValueError("partial buffer too small")
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_round_end_partial_dev(self.ctx.handle, k, d_out.data_ptr()), "zk_kzg_round_end_partial_dev")
+
+    def sum_partials_dev(self, d_all, ranks: int, n_jobs: int) -> list:
+        """All-gathered device partials (ranks x jobs x partial_dev_words, rank-major) -> one G1Affine per job: one kernel, one wait."""
+        L = self.curve.fq_limbs
+        out = np.zeros((max(n_jobs, 1), 2 * L), dtype=np.uint64)
+        inf = np.zeros(max(n_jobs, 1), dtype=np.uint8)
+        self.ctx.use_torch_stream()
+        check(lib().zk_g1_sum_partials_dev(self.ctx.handle, self.curve.curve_id, d_all.data_ptr(), ranks, n_jobs, ptr_of(out), ptr_of(inf)),
+              "zk_g1_sum_partials_dev")
+        return [_point(out[i], inf[i:i + 1], self.curve) for i in range(n_jobs)]
 
     def round_abort(self):
         check(lib().zk_kzg_round_abort(self.ctx.handle), "zk_kzg_round_abort")

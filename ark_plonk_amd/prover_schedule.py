@@ -45,12 +45,35 @@ def all_gather_partials(dist, parts: np.ndarray, world: int, device) -> np.ndarr
     return out.cpu().numpy().view(np.uint64).reshape(world, jobs, l3)
 
 
+def all_gather_partials_dev(dist, mine, world: int):
+    """The same exchange with the partials never leaving the device: `mine` is the int64 device tensor the last
+    reduction kernel of the round wrote (jobs x partial words, zk_kzg_round_end_partial_dev), the result the (world, jobs x words)
+    device tensor zk_g1_sum_partials_dev reads.  RCCL (backend "nccl") gathers device tensors directly: no host copy between the
+    last kernel and the collective.  gloo has no device all_gather: the rehearsal backend stages through the CPU here."""
+    import torch
+    flat = mine.reshape(-1)
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world, flat.numel()), dtype=torch.int64, device=mine.device)
+        if hasattr(dist, "all_gather_into_tensor"):
+            dist.all_gather_into_tensor(out.view(-1), flat)
+        else:
+            dist.all_gather(list(out.unbind(0)), flat)
+        return out
+    host = flat.cpu()
+    out = torch.empty((world, host.numel()), dtype=torch.int64)
+    if hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(out.view(-1), host)
+    else:
+        dist.all_gather(list(out.unbind(0)), host)
+    return out.to(mine.device)
+
+
 class ProofSchedule:
     def __init__(self, log_n: int, ctx, ck: CommitterKey, curve="bls12_381", rank: int = 0, world: int = 1,
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
                  ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
-                 hoist: bool = True):
+                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -171,9 +194,29 @@ class ProofSchedule:
                 self.key_polys[name] = self.sigma[k]
             self.lin_chal = {name: np.array([0x1357 * (k + 1), 0x2468, 0x3579, 0x0123], dtype=np.uint64)
                              for k, name in enumerate(lin_mod.CHALLENGES)}
-        # shard of the SRS this rank owns
-        self.lo = rank * n // world
-        self.hi = (rank + 1) * n // world
+        # shard of the MSMs this rank owns.  "points" (SURVEY.md 8e's preferred axis): SRS[lo, hi) and the same slice of every
+        # polynomial.  "windows" (BASELINE.json north_star's wording): the whole SRS and every whole polynomial, but only the table rows
+        # of the windows rank, rank + world, ... (the key was built with CommitterKey.precompute(rows=(rank, world))): the rank sorts
+        # all n scalars' digits for its windows into its own bucket set.  The partial and the collective are the same either way.
+        if shard_axis not in ("points", "windows"):
+            raise ValueError("shard_axis: 'points' or 'windows'")
+        self.shard_axis = shard_axis
+        if shard_axis == "windows" and world > 1:
+            if ck.table_rows()[:2] != (rank, world):
+                raise ValueError("window sharding needs a key precomputed with rows=(rank, world)")
+            self.lo, self.hi = 0, n
+        else:
+            self.lo = rank * n // world
+            self.hi = (rank + 1) * n // world
+        # the exchange without a host hop: partials written by the last reduction kernel into a device tensor, all-gathered from there,
+        # summed by one kernel (zk_kzg_round_end_partial_dev / zk_g1_sum_partials_dev).  Not for tables with c >= 18 or the commitment cache.
+        self.partials_on_device = bool(partials_on_device and world > 1 and defer_calls and not (self.dedup or self.dedup_abi)
+                                       and 0 < ck.table_window_bits() <= 17)
+        if self.partials_on_device:
+            self._pw = ck.partial_dev_words()
+            self._pbuf = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)       # partials of the library's pending jobs
+            self._pfull = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)      # ... with all-zero rows (infinity) for empty shards
+        self.collectives = 0
         self.points = []
         # evaluation point and opening challenge (transcript outputs in the reference): fixed field elements
         self.z_mont = np.array([0x1234567, 0x89abcdef, 0x13579bdf, 0x0fedcba9], dtype=np.uint64)
@@ -227,7 +270,10 @@ class ProofSchedule:
     def _round_reduce(self):
         """Queue the open round's reductions now; what is launched until `_round_end` runs behind them, under the host's part."""
         if not self._immediate() and any(kind == "q" for kind, _ in self._pending):
-            self.ck.round_reduce()
+            if self.world > 1 and self.partials_on_device:
+                self.ck.round_reduce_partial_dev(self._pbuf)
+            else:
+                self.ck.round_reduce()
 
     def _round_end(self):
         """Close the open round: the points of every call since the last close, in call order."""
@@ -237,6 +283,8 @@ class ProofSchedule:
         if self.world == 1:
             if nq:
                 got = self.ck.round_end(nq)
+        elif any(kind != "r" for kind, _ in pend) and self.partials_on_device:
+            got = self._gather_dev(nq, pend)
         elif any(kind != "r" for kind, _ in pend):
             L3 = 3 * self.cv.fq_limbs
             got = self._gather(self.ck.round_end_partial(nq) if nq else np.zeros((0, L3), dtype=np.uint64), pend)
@@ -264,7 +312,26 @@ class ProofSchedule:
                 q += 1
         return self._all_gather_sum(full)
 
+    def _gather_dev(self, nq, pend):
+        """Sharded round, device form: the library leaves the queued jobs' partials in `_pbuf` (no host wait), ONE all-gather of the
+        device tensor, one summing kernel.  Jobs whose shard is empty ("z") are all-zero rows = the point at infinity."""
+        jobs = [kind for kind, _ in pend if kind != "r"]
+        if nq:
+            self.ck.round_end_partial_dev(self._pbuf, nq)
+        if nq == len(jobs):
+            mine = self._pbuf[:nq]
+        else:
+            self._pfull.zero_()
+            idx = self.torch.tensor([k for k, kind in enumerate(jobs) if kind == "q"], dtype=self.torch.int64, device=self._pbuf.device)
+            if nq:
+                self._pfull.index_copy_(0, idx, self._pbuf[:nq])
+            mine = self._pfull[:len(jobs)]
+        allp = all_gather_partials_dev(self.dist, mine, self.world)
+        self.collectives += 1
+        return self.ck.sum_partials_dev(allp, self.world, len(jobs))
+
     def _all_gather_sum(self, parts):
+        self.collectives += 1
         dev = self.torch.device("cuda", self.ctx.device) if self.dist.get_backend() == "nccl" else self.torch.device("cpu")
         allp = all_gather_partials(self.dist, parts, self.world, dev)
         return sum_partials_batch(allp, self.cv.curve_id)

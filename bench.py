@@ -257,6 +257,13 @@ def parse_args():
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"],
                     help="N > 1: 'replica' (default) = one proof stream per GPU, value = total proofs/s (weak scaling) followed by "
                          "untimed-for-value sharded legs; 'shard' = every MSM point-sharded over the ranks (strong scaling)")
+    ap.add_argument("--shard-axis", default="points", choices=["points", "windows"],
+                    help="sharded MSMs (N > 1): 'points' = rank g owns SRS[g n/G, (g+1) n/G) and that slice of every polynomial (SURVEY.md 8e's "
+                         "preferred axis); 'windows' = rank g holds the whole SRS and the table rows of the windows g, g + G, ... "
+                         "(BASELINE.json north_star's wording; zk_srs_precompute_rows)")
+    ap.add_argument("--host-partials", action="store_true",
+                    help="sharded MSMs: exchange host Jacobian partials (round 3's path: D2H, host combine, H2D, all_gather, D2H) instead of "
+                         "the device form (zk_kzg_round_end_partial_dev -> all_gather_into_tensor -> zk_g1_sum_partials_dev)")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent proof streams per GPU (threads with their own zk_ctx + HIP stream); the K steps are shared out")
     ap.add_argument("--streams-leg", type=int, default=4,
@@ -356,12 +363,15 @@ def main():
         streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
         import threading
         n = 1 << log_n
-        lo, hi = (rank * n // world, (rank + 1) * n // world) if sharded else (0, n)
+        by_windows = sharded and args.shard_axis == "windows" and world > 1
+        lo, hi = (rank * n // world, (rank + 1) * n // world) if (sharded and not by_windows) else (0, n)
         S = 1 if sharded else max(1, min(n_streams, steps))
         srs = build_srs(ctx, cv, n, lo, hi, torch)
         ck0 = zk.CommitterKey(srs, cv, ctx)
         del srs
-        if precompute:
+        if by_windows:
+            ck0.precompute(args.table_window, rows=(rank, world))   # this rank's windows only: about 1/G of the table over the whole SRS
+        elif precompute:
             ck0.precompute(args.table_window)   # window-multiples table resident in HBM (one-time, like PC::trim)
         lanes = []
         for i in range(S):
@@ -372,7 +382,8 @@ def main():
                 kw = dict(dedup=dedup, grand_products=args.grand_products or glue, quotient=args.quotient or glue, linearisation=glue, lookup_round2=glue, fuse_round5=args.fuse_round5,
                           data=data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls, hoist=not args.no_hoist)
                 if sharded:
-                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, **kw)
+                    sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, shard_axis=args.shard_axis,
+                                          partials_on_device=not args.host_partials, **kw)
                 else:
                     sched = ProofSchedule(log_n, cx, ck, cv, **kw)
                 pts = None
@@ -556,7 +567,8 @@ def main():
     if world == 1:
         par = "1 GPU"
     elif main_sharded:
-        par = f"MSM point-sharded over {world} GPUs + RCCL all-gather of partials; NTT replicated"
+        par = (f"MSM sharded by {args.shard_axis} over {world} GPUs + RCCL all-gather of partials "
+               f"({'host Jacobian' if args.host_partials else 'device-resident'} form); NTT replicated")
     else:
         par = f"{world} replicas (one whole proof stream per GPU, no data-path collective)"
     line = {
@@ -835,7 +847,10 @@ def main():
             def run():
                 rs = timed_region(True, log_n=lg)
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
-                     "collective": "RCCL all_gather of 3L-limb Jacobian partials, one per group of PC calls (5 per proof; 11 with --block-every-call)",
+                     "collective": "RCCL all_gather of the jobs' partials, one per group of PC calls (5 per proof; 11 with --block-every-call): "
+                                   + ("3L-limb host Jacobian partials (--host-partials)" if args.host_partials else
+                                      "device-resident XYZZ partials written by the last reduction kernel, summed by zk_g1_sum_partials_dev"),
+                     "shard_axis": args.shard_axis,
                      "points_per_rank": rs["points_per_launch"], "accumulate_ms_per_msm": acc_per_msm(rs),
                      "commitments_sha256": rs["digest"]}
                 if lg == log_n:

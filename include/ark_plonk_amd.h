@@ -168,6 +168,17 @@ int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 int zk_srs_precompute_ex(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits);
 /* window_bits / windows (= rows = mixed additions per scalar) of the SRS's table; both 0 without a table. */
 int zk_srs_table_info(zk_srs* srs, uint32_t* window_bits, uint32_t* windows);
+/* Multi-GPU, sharded by WINDOWS (BASELINE.json north_star: "the MSM shards its windows/buckets across GPUs"; SURVEY.md 8e's
+ * alternative): rank g of G registers the WHOLE SRS and builds only the table rows of the windows first_window, first_window +
+ * window_stride, ... (g, g + G, ...: ceil((W - g) / G) of the W rows), i.e. about 1/G of the table.  Every MSM entry point over such
+ * an SRS then returns the rank's PARTIAL sum_i sum_{w owned} d_{i,w} 2^(c w) P_i -- all N scalars, the owned digits only, the rank's
+ * own bucket set -- and the ranks' partials add up to the MSM (zk_g1_sum_partials*, after the same all-gather as the point-sharded
+ * form: zk_kzg_round_end_partial(_dev)).  A vector too short for the table path is computed whole by the owner of window 0 and is
+ * the point at infinity on the other ranks.  (first_window, window_stride) = (0, 1) is zk_srs_precompute_ex.  The first precompute
+ * of an SRS wins, as above; a later call must name the same rows.  The plain SRS stays resident next to the rows. */
+int zk_srs_precompute_rows(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits, uint32_t first_window, uint32_t window_stride);
+/* first_window / window_stride / rows held (0 / 1 / windows for a whole table; rows = 0 without a table). */
+int zk_srs_table_rows(zk_srs* srs, uint32_t* first_window, uint32_t* window_stride, uint32_t* rows);
 /* One more owner of a live handle (a second zk_ctx / thread that keeps using the SRS on its own): pairs with one more
  * zk_srs_free.  ZK_ERR_BAD_ARG for a handle whose last reference is gone. */
 int zk_srs_retain(zk_srs* srs);
@@ -266,6 +277,25 @@ int zk_kzg_round_end(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xy, uint8_t* ou
 int zk_kzg_round_end_partial(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xyz);
 int zk_kzg_round_pending(zk_ctx* ctx, uint32_t* n_jobs);
 int zk_kzg_round_abort(zk_ctx* ctx);
+/* Since round 4 a begin queues only the digit kernel of its jobs -- the one kernel that reads the caller's vectors, so the inputs are
+ * consumed in stream order at the call, as before -- and zk_kzg_round_reduce / _end queue the rest for ALL jobs of the round as one
+ * launch per kernel: the sort's placement passes, ONE accumulation launch (msm_accumulate_batch), the reductions.
+ *
+ * The multi-GPU exchange without a host hop (the reference is a single process): the round is closed with every job's
+ * partial left ON THE DEVICE -- one point in the library's internal XYZZ limb form, zk_partial_dev_bytes(curve) bytes (256 for
+ * BLS12-381), opaque; every rank runs this library -- at d_out + k * zk_partial_dev_bytes, k = submission order, written by the
+ * last reduction kernel.  d_out is typically the send buffer of the collective (ncclAllGather / torch all_gather_into_tensor on
+ * the same stream).  Neither call waits: d_out, the inputs and the SRS stay valid until the stream has passed this point
+ * (zk_g1_sum_partials_dev waits for it).  zk_kzg_round_reduce_partial_dev is zk_kzg_round_reduce for this form (work queued
+ * after it runs behind the reductions); zk_kzg_round_end_partial_dev closes the round (queues the reductions itself unless reduce
+ * ran; d_out must then be the same buffer).  An all-zero partial is the point at infinity (a rank with an empty shard).
+ * ZK_ERR_UNSUPPORTED (the round stays open, close it with zk_kzg_round_end_partial): tables with window_bits >= 18, the commitment
+ * cache.  zk_g1_sum_partials_dev: ranks x n_jobs partials as the all-gather leaves them (rank-major) -> n_jobs affine sums;
+ * one kernel, one wait, the n_jobs inversions on the host. */
+size_t zk_partial_dev_bytes(int curve_id);
+int zk_kzg_round_reduce_partial_dev(zk_ctx* ctx, void* d_out);
+int zk_kzg_round_end_partial_dev(zk_ctx* ctx, uint32_t n_jobs, void* d_out);
+int zk_g1_sum_partials_dev(zk_ctx* ctx, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
 
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).

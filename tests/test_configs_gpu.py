@@ -50,6 +50,26 @@ def test_config3_msm_2_22_table_plain_and_8_shards(ctx, oracle_cpu):
         cks.close()
     got = zk.sum_partials_batch(np.stack(parts), cid)[0]   # (ranks, jobs = 1, 3L)
     assert got == plain
+    # 8 WINDOW shards (BASELINE.json north_star: "shards its windows/buckets across GPUs"): every rank registers the whole SRS, builds
+    # the table rows of the windows g, g + 8 (2 of the 15 rows; rank 7: one) and sums all n scalars' digits of those windows.  The
+    # partials go through both forms of the exchange: host Jacobian partials, and the device form (the last reduction kernel writes
+    # the partial into the tensor the all-gather would send; zk_g1_sum_partials_dev adds the ranks' partials)
+    parts, dev_parts = [], []
+    pw = None
+    for g in range(G):
+        ckw = zk.CommitterKey(bases, cid, ctx).precompute(rows=(g, G))
+        assert ckw.table_rows() == (g, G, (15 - g + G - 1) // G) and ckw.table_windows() == 15
+        parts.append(ckw.commit_batch_partial([d_s], canonical=[True]))
+        pw = ckw.partial_dev_words()
+        buf = torch.zeros((1, pw), dtype=torch.int64, device="cuda")
+        ckw.commit_begin([d_s], canonical=[True])
+        ckw.round_end_partial_dev(buf, 1)
+        dev_parts.append(buf)
+        if g == G - 1:
+            got_dev = ckw.sum_partials_dev(torch.stack(dev_parts).reshape(G, pw).contiguous(), G, 1)[0]
+        ckw.close()
+    assert zk.sum_partials_batch(np.stack(parts), cid)[0] == plain
+    assert got_dev == plain
 
 
 @pytest.mark.parametrize("log_n", [18, 20])

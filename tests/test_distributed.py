@@ -143,6 +143,12 @@ def test_bench_two_ranks_matches_one_rank():
     d3 = two_ranks(["--mode", "shard"])
     assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"
     assert d1["commitments_sha256"] == d3["commitments_sha256"]
+    # the same sharded by WINDOWS (rank g: the whole SRS, table rows g, g + 2, ...), and with round 3's host-partial exchange
+    d4 = two_ranks(["--mode", "shard", "--shard-axis", "windows"])
+    assert d4["scaling"] == "strong" and "by windows" in d4["config"]["parallelism"]
+    assert d1["commitments_sha256"] == d4["commitments_sha256"]
+    d5 = two_ranks(["--mode", "shard", "--shard-axis", "windows", "--host-partials"])
+    assert d1["commitments_sha256"] == d5["commitments_sha256"]
 
 
 def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
@@ -187,6 +193,7 @@ class _StubDist:
         return self.backend
 
     def _into(self, out, inp):
+        self.ptrs = getattr(self, "ptrs", []) + [inp.data_ptr()]
         self.calls.append(("into", out.device, inp.device, out.dtype, inp.dtype, tuple(out.shape), tuple(inp.shape)))
         out.view(self.world, -1).copy_(inp.unsqueeze(0).expand(self.world, -1))
 
@@ -248,11 +255,51 @@ def test_all_gather_partials_world2_gloo():
         assert np.array_equal(got[0], base + 1000) and np.array_equal(got[1], base + 2000)
 
 
+def _worker_gather_dev(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ark_plonk_amd.prover_schedule import all_gather_partials_dev
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.arange(3 * 32, dtype=torch.int64).reshape(3, 32) + 1000 * (rank + 1)     # 3 jobs x 32 words (a 256-byte partial)
+    got = all_gather_partials_dev(dist, mine, world)
+    q.put((rank, tuple(got.shape), got.tolist()))
+    dist.destroy_process_group()
+
+
+def test_all_gather_partials_dev_world2_gloo():
+    """The device form's exchange step with a real world-2 collective (gloo, CPU tensors standing in for the rank's GPU):
+    rank-major (world, jobs x words), every rank sees both ranks' rows."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gather_dev, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (sh, v) for r, sh, v in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(3 * 32, dtype=np.int64)
+    for rank in (0, 1):
+        sh, v = res[rank]
+        assert sh == (2, 96)
+        assert np.array_equal(np.array(v[0]), base + 1000) and np.array_equal(np.array(v[1]), base + 2000)
+
+
 @pytest.mark.gpu
-def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx):
+@pytest.mark.parametrize("on_device", [True, False])
+def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, on_device, monkeypatch):
     """ProofSchedule with world = 2 and a `dist` that reports backend "nccl": the partials of every group of PC calls must enter
     the collective as int64 tensors on the rank's GPU (RCCL cannot take host tensors), one all_gather per group; with both "ranks"
-    contributing this rank's shard the result is twice the shard's commitment."""
+    contributing this rank's shard the result is twice the shard's commitment.
+    on_device (the default since round 4): NO host copy between the last reduction kernel and the collective -- the tensor the
+    collective sends is the very buffer the library wrote the partials into (zk_kzg_round_end_partial_dev), the host-partial entry
+    point is never called, and the ranks' partials are added on the device (zk_g1_sum_partials_dev)."""
     import torch
     import ark_plonk_amd as zk
     from ark_plonk_amd import _lib
@@ -269,18 +316,64 @@ def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx):
     ck_full = zk.CommitterKey(bases, cv, ctx).precompute()
     ck_shard = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()      # rank 0 of 2 owns SRS[0, n/2)
     d = _StubDist("nccl", 2)
-    sched = ProofSchedule(log_n, ctx, ck_shard, cv, rank=0, world=2, dist=d)
+    sched = ProofSchedule(log_n, ctx, ck_shard, cv, rank=0, world=2, dist=d, partials_on_device=on_device)
+    assert sched.partials_on_device is on_device
+    host_calls = []
+    real_end_partial = ck_shard.round_end_partial
+    monkeypatch.setattr(ck_shard, "round_end_partial", lambda *a, **k: (host_calls.append(1), real_end_partial(*a, **k))[1])
     out = sched.run_once(proof_id=0)
-    assert len(out) == 29 and len(d.calls) == 5              # five groups of PC calls, one collective each
+    assert len(out) == 29 and len(d.calls) == 5 and sched.collectives == 5       # five groups of PC calls, one collective each
+    words = ck_shard.partial_dev_words() if on_device else 3 * cv.fq_limbs
     for kind, odev, idev, odt, idt, oshape, ishape in d.calls:
         assert odev.type == idev.type == "cuda" and odev.index == idev.index == ctx.device and odt == idt == torch.int64
-        assert ishape[0] % (3 * cv.fq_limbs) == 0 and oshape == (2 * ishape[0],)
+        assert ishape[0] % words == 0 and oshape == (2 * ishape[0],)
+    assert [c[6][0] // words for c in d.calls] == [4, 3, 2, 4, 16]                 # jobs per group
+    if on_device:
+        assert not host_calls and all(p == sched._pbuf.data_ptr() for p in d.ptrs)
+    else:
+        assert len(host_calls) == 5
     # rank 0's shard of w_l committed by both stub ranks = 2 * commit(w_l[: n/2]) over SRS[: n/2]
     half = ck_shard.commit(sched.coef[0][: n // 2])
     two = zk.msm.sum_partials(np.stack([ck_shard.commit_batch_partial([sched.coef[0][: n // 2]])[0]] * 2), 0)
     assert out[0] == two and out[0] != half
     ck_full.close()
     ck_shard.close()
+
+
+@pytest.mark.gpu
+def test_device_partials_with_short_and_empty_jobs(ctx):
+    """The device form of a round's partials with every kind of job: table path, a vector too short for it (computed at begin,
+    uploaded converted) and the point at infinity (all-zero scalars); against the host form and the oracle."""
+    import torch
+    import ark_plonk_amd as zk
+    from ark_plonk_amd import _lib
+    cv = zk.get_curve(0)
+    n = 1 << 14
+    rng = np.random.default_rng(77)
+    ks = torch.from_numpy(rng.integers(1, 1 << 62, size=(n, 4), dtype=np.uint64).view(np.int64)).cuda()
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
+    ck = zk.CommitterKey(bases, cv, ctx).precompute()
+    polys = [torch.from_numpy(rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64).view(np.int64)).cuda() for m in (n, 100, n - 1)]
+    polys.append(torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
+    want = ck.commit_batch(polys)
+    pw = ck.partial_dev_words()
+    buf = torch.full((len(polys), pw), -1, dtype=torch.int64, device="cuda")
+    for p in polys:
+        ck.commit_begin([p])
+    ck.round_reduce_partial_dev(buf)
+    with pytest.raises(RuntimeError):
+        ck.round_end(len(polys))                      # reduced towards the device: the host form refuses, the round stays open
+    ck.round_end_partial_dev(buf, len(polys))
+    got = ck.sum_partials_dev(buf.reshape(1, -1), 1, len(polys))
+    assert got == want and got[3].infinity
+    # two "ranks" with the same partials: 2 * commitment, as the host form computes it
+    two = ck.sum_partials_dev(torch.cat([buf.reshape(1, -1)] * 2), 2, len(polys))
+    host2 = zk.sum_partials_batch(np.stack([ck.commit_batch_partial(polys)] * 2), 0)
+    assert two == host2
+    ck.close()
 
 
 @pytest.mark.gpu

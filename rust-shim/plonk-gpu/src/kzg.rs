@@ -33,6 +33,13 @@ pub struct SrsHandle(*mut sys::ZkSrs);
 unsafe impl Send for SrsHandle {}
 unsafe impl Sync for SrsHandle {}
 
+impl SrsHandle {
+    /// The `zk_srs*` of the ABI.
+    pub fn raw(&self) -> *mut sys::ZkSrs {
+        self.0
+    }
+}
+
 impl Drop for SrsHandle {
     fn drop(&mut self) {
         if !self.0.is_null() {
@@ -60,6 +67,31 @@ impl PCCommitterKey for GpuCommitterKey {
 /// Same key / commitment / proof types as `SonicKZG10<Bls12_381, DensePolynomial<Fr>>`; only `trim`, `commit` and `open` differ.
 pub struct GpuKZG10;
 
+/// A device call of `commit` / `open` / `trim` failed and the CPU path is about to answer instead.  The trait methods must not
+/// return a wrong answer, so the fallback stays -- but it must not be silent either: a misconfigured device, ZK_ERR_PENDING, an
+/// out-of-memory or a library bug would otherwise show up only as a slow prover with correct proofs.  Every DISTINCT error code is
+/// reported once on stderr and counted ([`gpu_fallbacks`]); with `ARK_PLONK_AMD_STRICT=1` the failure panics instead (the Python
+/// and C++ front ends of the library have no CPU fallback at all; this makes the Rust one behave the same).
+fn note_fallback(what: &str, e: &GpuError) {
+    use std::sync::atomic::{AtomicU64, Ordering};
+    static SEEN: AtomicU64 = AtomicU64::new(0);
+    FALLBACKS.fetch_add(1, Ordering::Relaxed);
+    if std::env::var("ARK_PLONK_AMD_STRICT").map(|v| v == "1").unwrap_or(false) {
+        panic!("plonk-gpu: {} failed on the device and ARK_PLONK_AMD_STRICT=1 forbids the CPU fallback: {}", what, e);
+    }
+    let bit = 1u64 << ((-e.code).clamp(0, 63) as u32);
+    if SEEN.fetch_or(bit, Ordering::Relaxed) & bit == 0 {
+        eprintln!("plonk-gpu: {} failed on the device ({}); SonicKZG10's CPU path answers instead (reported once per error code)", what, e);
+    }
+}
+
+static FALLBACKS: std::sync::atomic::AtomicU64 = std::sync::atomic::AtomicU64::new(0);
+
+/// How many device calls have been answered by the CPU path since the process started.
+pub fn gpu_fallbacks() -> u64 {
+    FALLBACKS.load(std::sync::atomic::Ordering::Relaxed)
+}
+
 impl GpuKZG10 {
     /// Park `powers_of_g` on the device.  circuit.rs:276 trims on every `gen_proof`: `zk_srs_register` is content-addressed,
     /// so the second call with the same bytes is one keyed digest pass over them (0.7 ms for 2^20 points) and returns the
@@ -72,13 +104,15 @@ impl GpuKZG10 {
         let (xy, inf) = pack_affine(powers);
         let mut srs: *mut sys::ZkSrs = core::ptr::null_mut();
         let rc = unsafe { sys::zk_srs_register(c, CURVE, xy.as_ptr(), inf.as_ptr(), powers.len(), &mut srs) };
-        if check(rc).is_err() {
+        if let Err(e) = check(rc) {
+            note_fallback("zk_srs_register (PC::trim)", &e);
             return None;
         }
         let handle = Arc::new(SrsHandle(srs));
         // the window table (15 rows of 17-bit windows from 2^19 points on: 1.9 GiB per 2^20 points); idempotent: built once per distinct SRS
         let rc = unsafe { sys::zk_srs_precompute(c, srs) };
-        if check(rc).is_err() {
+        if let Err(e) = check(rc) {
+            note_fallback("zk_srs_precompute (PC::trim)", &e);
             return None; // no table: MSMs would still work, but the key then simply takes the CPU path
         }
         Some(handle)
@@ -169,13 +203,16 @@ impl PolynomialCommitment<Fr, Poly> for GpuKZG10 {
         let polys: Vec<&LabeledPolynomial<Fr, Poly>> = polynomials.into_iter().collect();
         if let Some(srs) = ck.srs.as_ref() {
             if Self::plain(ck, &polys) {
-                if let Ok(points) = Self::gpu_commit(srs, &polys) {
-                    let comms = polys
-                        .iter()
-                        .zip(points)
-                        .map(|(p, g)| LabeledCommitment::new(p.label().clone(), kzg10::Commitment(g), None))
-                        .collect();
-                    return Ok((comms, vec![Self::Randomness::empty(); polys.len()]));
+                match Self::gpu_commit(srs, &polys) {
+                    Ok(points) => {
+                        let comms = polys
+                            .iter()
+                            .zip(points)
+                            .map(|(p, g)| LabeledCommitment::new(p.label().clone(), kzg10::Commitment(g), None))
+                            .collect();
+                        return Ok((comms, vec![Self::Randomness::empty(); polys.len()]));
+                    }
+                    Err(e) => note_fallback("zk_kzg_commit_batch (PC::commit)", &e),
                 }
             }
         }
@@ -200,8 +237,9 @@ impl PolynomialCommitment<Fr, Poly> for GpuKZG10 {
         let polys: Vec<&LabeledPolynomial<Fr, Poly>> = labeled_polynomials.into_iter().collect();
         if let Some(srs) = ck.srs.as_ref() {
             if Self::plain(ck, &polys) {
-                if let Ok(w) = Self::gpu_open(srs, &polys, point, &opening_challenge) {
-                    return Ok(kzg10::Proof { w, random_v: None });
+                match Self::gpu_open(srs, &polys, point, &opening_challenge) {
+                    Ok(w) => return Ok(kzg10::Proof { w, random_v: None }),
+                    Err(e) => note_fallback("zk_kzg_open (PC::open)", &e),
                 }
             }
         }
@@ -258,6 +296,17 @@ impl PolynomialCommitment<Fr, Poly> for GpuKZG10 {
 }
 
 impl HomomorphicCommitment<Fr> for GpuKZG10 {
+    /// The hook patches/plonk-core-device-prover.patch adds to the trait: with a device-resident SRS the prover runs its
+    /// device-resident schedule (`Prover::prove_on_device`: vectors uploaded once, commitments from where they lie, eleven PC calls
+    /// closed by five waits).  `ARK_PLONK_AMD_DEVICE_PROVER=0` keeps the host-pointer calls of an unchanged `prove_with_preprocessed`.
+    fn device_backend(ck: &Self::CommitterKey) -> Option<Box<dyn plonk_core::commitment::DeviceBackend<Fr, Self>>> {
+        if std::env::var("ARK_PLONK_AMD_DEVICE_PROVER").map(|v| v == "0").unwrap_or(false) {
+            return None;
+        }
+        ck.srs.as_ref().map(|s| Box::new(crate::device::GpuBackend::new(s.clone())) as Box<dyn plonk_core::commitment::DeviceBackend<Fr, Self>>)
+    }
+
+
     /// commitment.rs:33-48: `into_repr` on the scalars, then one `VariableBaseMSM::multi_scalar_mul` over the commitments'
     /// points.  The verifier's sizes (4 and 19 points, proof.rs:317-325,602) are microseconds on the CPU and stay there; a
     /// caller with thousands of commitments gets `zk_msm_g1`.

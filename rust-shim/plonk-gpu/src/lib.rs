@@ -4,6 +4,9 @@
 //!   commitment and proof types of `SonicKZG10<Bls12_381, DensePolynomial<Fr>>`; `trim` additionally parks the SRS on the GPU,
 //!   `commit` and `open` run there (`zk_kzg_commit_batch`, `zk_kzg_open`), everything else is SonicKZG10's.  It satisfies
 //!   `Prover::<Fr, P, PC>` (proof_system/prover.rs:32-37) and `Circuit::gen_proof::<PC>` (circuit.rs:264-287) unchanged.
+//! * [`device`] -- the device-resident form: [`DevicePoly`], [`GpuDomain`], the deferred rounds of [`GpuKZG10`] and [`GpuBackend`], the
+//!   `plonk_core::commitment::DeviceBackend` that patches/plonk-core-device-prover.patch lets `Prover::prove_with_preprocessed` drive
+//!   (the path bench.py's headline measures; the host-pointer calls above are its `drop_in` leg).
 //! * [`ntt_hook`] / [`msm_hook`] -- what the patched `ark-poly` / `ark-ec` (patches/) call from
 //!   `Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place` and `VariableBaseMSM::multi_scalar_mul`.
 //!
@@ -15,11 +18,13 @@
 //!   little-endian Montgomery residue -- exactly what the ABI calls "Montgomery limbs".
 //! * `GroupAffine<P>` is `{ x, y, infinity: bool, PhantomData }` and NOT `repr(C)`: points are copied field by field.
 
+pub mod device;
 pub mod kzg;
 pub mod msm_hook;
 pub mod ntt_hook;
 
-pub use kzg::{GpuCommitterKey, GpuKZG10};
+pub use device::{DevSlice, DevicePoly, GpuBackend, GpuDomain};
+pub use kzg::{gpu_fallbacks, GpuCommitterKey, GpuKZG10};
 
 use ark_bls12_381::{Fq, Fr, G1Affine};
 use ark_ff::Zero;

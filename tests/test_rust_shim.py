@@ -122,6 +122,101 @@ def test_hand_written_crate_calls_declared_functions_with_the_right_arity():
     # the calls the reference's interface needs: trim -> register + table, commit, open, the verifier-side MSM, the four transforms
     assert {"zk_ctx_create", "zk_srs_register", "zk_srs_precompute", "zk_srs_free", "zk_kzg_commit_batch", "zk_kzg_open", "zk_msm_g1",
             "zk_ntt", "zk_strerror"} <= used
+    # ... and the device-resident form behind the headline (device.rs): vectors, transforms, blocking and deferred PC calls
+    assert {"zk_dev_alloc", "zk_dev_upload", "zk_dev_download", "zk_dev_free", "zk_ntt_dev", "zk_ntt_batch_dev", "zk_kzg_commit_batch_dev",
+            "zk_kzg_open_dev", "zk_kzg_round_begin_dev", "zk_kzg_open_begin_dev", "zk_kzg_round_reduce", "zk_kzg_round_end",
+            "zk_kzg_round_abort"} <= used
+
+
+PATCH = os.path.join(ROOT, "rust-shim", "patches", "plonk-core-device-prover.patch")
+REF = "/root/reference"
+
+
+def _added_lines(path_suffix):
+    """the '+' lines the patch adds to one file"""
+    out, on = [], False
+    for ln in open(PATCH).read().splitlines():
+        if ln.startswith("+++ "):
+            on = ln.split()[1].endswith(path_suffix)
+            continue
+        if ln.startswith("--- ") or ln.startswith("diff "):
+            continue
+        if on and ln.startswith("+"):
+            out.append(ln[1:])
+    return "\n".join(out)
+
+
+def test_the_prover_patch_applies_to_the_reference():
+    """patches/plonk-core-device-prover.patch (commitment.rs: the DeviceBackend hook; error.rs: its error; prover.rs:
+    prove_on_device) applies cleanly to the reference tree this repository was built against."""
+    import shutil
+    import pytest
+    if not os.path.isdir(REF) or shutil.which("patch") is None:
+        pytest.skip("no reference tree / no patch(1) here")
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-d", REF, "-i", PATCH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Hunk" not in r.stdout or "FAILED" not in r.stdout
+
+
+def _transcript_ops(src):
+    """ordered (operation, label) pairs of a prover body: what the transcript hashes, in order"""
+    src = re.sub(r"//[^\n]*", "", src)
+    return [(m.group(1), m.group(2)) for m in re.finditer(r"(append|challenge_scalar)\s*\(\s*b\"([^\"]*)\"", src)]
+
+
+def test_the_patched_prover_hashes_what_the_reference_hashes():
+    """prove_on_device must leave the transcript byte-identical: the same appends and challenge draws, same labels, same order as
+    prove_with_preprocessed (proof_system/prover.rs:163-638).  Parsed from both sources."""
+    import pytest
+    ref_src = os.path.join(REF, "plonk-core", "src", "proof_system", "prover.rs")
+    if not os.path.exists(ref_src):
+        pytest.skip("no reference tree here")
+    text = open(ref_src).read()
+    body = text[text.index("pub fn prove_with_preprocessed"):text.index("/// Proves a circuit is satisfied, then clears the witness variables")]
+    want = _transcript_ops(body)
+    added = _added_lines("proof_system/prover.rs")
+    got = _transcript_ops(added[added.index("fn prove_on_device"):])
+    assert len(want) == 53 and got == want
+    # values too: every appended expression names the same quantity (commitments by their role, evaluations by their field)
+    def appended(src):
+        src = re.sub(r"//[^\n]*", "", src)
+        return [re.sub(r"\s+", "", m.group(1)) for m in re.finditer(r"append\(\s*b\"[^\"]*\",\s*([^;]*?)\)\s*;", src, flags=re.S)]
+    ref_vals, new_vals = appended(body), appended(added[added.index("fn prove_on_device"):])
+    assert len(ref_vals) == len(new_vals)
+    role = {"w_commits[0].commitment()": "&a_comm", "w_commits[1].commitment()": "&b_comm", "w_commits[2].commitment()": "&c_comm",
+            "w_commits[3].commitment()": "&d_comm", "f_poly_commit[0].commitment()": "&f_comm", "h_1_poly_commit[0].commitment()": "&h_1_comm",
+            "h_2_poly_commit[0].commitment()": "&h_2_comm", "z_poly_commit[0].commitment()": "&z_comm_round3",
+            "t_commits[0].commitment()": "&t_1_comm", "t_commits[1].commitment()": "&t_2_comm", "t_commits[2].commitment()": "&t_3_comm",
+            "t_commits[3].commitment()": "&t_4_comm"}
+    for a, b in zip(ref_vals, new_vals):
+        assert role.get(a, a) == b, (a, b)
+
+
+def test_device_backend_trait_and_its_gpu_implementation_agree():
+    """the trait the patch adds to plonk-core/src/commitment.rs and `impl DeviceBackend<Fr, GpuKZG10> for GpuBackend` (device.rs):
+    same methods, same number of parameters; the prover calls nothing else on it."""
+    trait_src = _added_lines("commitment.rs")
+    trait_src = trait_src[trait_src.index("pub trait DeviceBackend"):]
+    impl_src = open(os.path.join(SHIM_SRC, "device.rs")).read()
+    impl_src = impl_src[impl_src.index("impl DeviceBackend<Fr, GpuKZG10> for GpuBackend"):]
+
+    def methods(src):
+        out = {}
+        for m in re.finditer(r"fn (\w+)\s*\(", src):
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            out[m.group(1)] = len(_split_top(src[m.end():i - 1]))
+        return out
+    t, g = methods(trait_src), methods(impl_src)
+    assert set(t) == {"upload", "transform_batch", "commit_begin", "open_begin", "round_reduce", "round_end"}
+    assert {k: g.get(k) for k in t} == t
+    prover = _added_lines("proof_system/prover.rs")
+    assert set(re.findall(r"\bdev\.(\w+)\(", prover)) - {"as_ref"} <= set(t)
+    # the scheme's side of the hook
+    kzg = open(os.path.join(SHIM_SRC, "kzg.rs")).read()
+    assert "fn device_backend(ck: &Self::CommitterKey)" in kzg and "GpuBackend::new" in kzg
 
 
 def test_gpu_kzg10_implements_every_required_method():

@@ -574,7 +574,7 @@ static int msm_partial_locked(zk_ctx* c, zk_srs* s, size_t base_offset, const vo
     const void* d_bases = nullptr;
     int rc = srs_slice(s, base_offset, n, &d_bases);
     if (rc) return rc;
-    if (s->pre_W && n >= ZK_PRE_MIN_N && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
+    if (s->pre_W && n >= ZK_PRE_MIN_N && n <= zk_pre_max_n() && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
     if (s->pre_wstep > 1 && s->pre_w0 != 0) {
         // window-sharded table: what the MSM entry points of this SRS return is the rank's PARTIAL, and the ranks' partials add up, so a
         // vector that does not take the table path is computed (whole, per-window path) by the owner of window 0 only; here: infinity
@@ -679,7 +679,7 @@ static int batch_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const
     bool fused = s->pre_W != 0 && c->msm_window == 0;
     for (uint32_t k = 0; k < n_jobs; ++k) {
         if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
-        if (lens[k] < ZK_PRE_MIN_N) fused = false;
+        if (lens[k] < ZK_PRE_MIN_N || lens[k] > zk_pre_max_n()) fused = false;
     }
     if (fused) {
         uint64_t tmp[16 * 18];
@@ -880,7 +880,7 @@ static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
         zk_ctx::PendingJob& pj = c->pend[slot];
         pj = zk_ctx::PendingJob();
         pj.n = lens[k];
-        if (table && lens[k] >= ZK_PRE_MIN_N) {
+        if (table && lens[k] >= ZK_PRE_MIN_N && lens[k] <= zk_pre_max_n()) {
             const uint8_t kind = kinds ? kinds[k] : 0;
             if ((rc = msm_batch_pre_begin_dev(c, s, slot, 1, d_inputs + k, lens + k, &kind, nullptr))) return rc;
             pj.queued = true;

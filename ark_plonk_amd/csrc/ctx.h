@@ -348,6 +348,17 @@ int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t*
                           uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
+constexpr size_t ZK_PRE_MAX_N = 1u << 26;   // ... and above this: a sorted reference of the table path is sign | 5 bits of window | 26 bits of point index
+// the limit the dispatch uses: ZK_PRE_MAX_N, or 2^ZK_PRE_MAX_LOG_N from the environment when that is smaller (test hook: the
+// fall-back to the per-window path over a table SRS can then be exercised without a 130 GiB table)
+inline size_t zk_pre_max_n() {
+    const char* e = getenv("ZK_PRE_MAX_LOG_N");
+    if (e) {
+        const int v = atoi(e);
+        if (v >= 13 && v < 26) return (size_t)1 << v;
+    }
+    return ZK_PRE_MAX_N;
+}
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points
 int msm_convert_bases_dev(zk_ctx* c, int curve, const void* d_xy_sat, const uint8_t* d_inf, size_t n, void* d_out_internal);
 size_t msm_point_bytes(int curve);

@@ -2093,7 +2093,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     typedef typename Cv::FqU F;
     typedef XYZZ<Fq> PH;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
-    if (n >= (1ull << 26)) return ZK_ERR_UNSUPPORTED;
+    if (n > zk_pre_max_n()) return ZK_ERR_UNSUPPORTED;      // the callers (api.hip) send longer vectors down the per-window path
     pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
     pl.g.w0 = s->pre_w0;                                // a window-sharded table: this rank's rows only (W of the Wt windows)

@@ -4,7 +4,8 @@
 // _in_place as called by the reference at plonk-core/src/proof_system/prover.rs:196-203,240-242,
 // 281-283,302-305, quotient_poly.rs:72-120,175-177,205,294,325, permutation/mod.rs:671-674,751,800.
 //
-// Algorithm (not ark's): a multi-pass Cooley-Tukey decomposition N = 2^s1 * 2^s2 (* 2^s3), s <= 9.
+// Algorithm (not ark's): a multi-pass Cooley-Tukey decomposition N = 2^s1 * 2^s2 (* 2^s3 (* 2^s4)), s <= 9
+// (one pass to 2^9, two to 2^18, three to 2^27, four above).
 // Each pass gives every wavefront a tile of 2^s rows x 2^(9-s) columns = 512 elements, runs the
 // 2^s-point DIT transform in registers (8 elements per lane, three radix-2 stages per window, a
 // wave-private 2 KiB LDS scratch for the lane<->register transposes between windows -- no workgroup
@@ -289,7 +290,6 @@ template <class C>
 int ntt_run(zk_ctx* c, int kind, uint32_t log_n, uint32_t n_polys, const void* const* d_ins, const size_t* in_lens, void* const* d_outs) {
     typedef typename C::Fr Fr;
     if (log_n > (uint32_t)C::FrP::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
-    if (log_n > 27) return ZK_ERR_UNSUPPORTED;
     if (n_polys == 0 || n_polys > 16) return ZK_ERR_BAD_ARG;
     const uint64_t N = 1ull << log_n;
     size_t in_len = 0;               // the longest input of the batch
@@ -330,7 +330,11 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, uint32_t n_polys, const void* c
     NttPlan* pl = nullptr;
     rc = get_plan<C>(c, log_n, inverse, &pl);
     if (rc) return rc;
-    if (pl->n_pass > 3) return ZK_ERR_UNSUPPORTED;
+    // up to four passes of 2^9: log N <= 36 covers every two-adicity the curves have (32 for BLS12-381, 28 for BN254; the reference
+    // admits any domain up to it, prover.rs:169-173, error.rs:14-21).  What bounds the size in practice is memory: the vector, the
+    // work vector and the first pass boundary's table are N x 32 B each (8 GiB at 2^28), so 2^30 in place is 96 GiB of a 288 GB card
+    // and 2^32 does not fit -- that case is ZK_ERR_OOM from the allocations below, not a refusal here.
+    if (pl->n_pass > 4) return ZK_ERR_UNSUPPORTED;
     void* work = nullptr;
     if (pl->n_pass > 1) {
         rc = c->ntt_work.ensure((size_t)n_polys * N * sizeof(Fr));     // one intermediate vector per polynomial of the batch
@@ -378,6 +382,7 @@ int ntt_run(zk_ctx* c, int kind, uint32_t log_n, uint32_t n_polys, const void* c
             uint32_t logc = LC < s1 ? LC : s1;
             a.logc = logc;
             a.s1 = s1;
+            a.s2 = pl->n_pass == 4 ? (uint32_t)pl->s[1] : 0u;
             a.post_mul = post;
             Fr sc = Fr::mul(inverse ? n_inv : Fr::one(), to_rp);   // R'-form of 1/N or 1
             for (int i = 0; i < 8; ++i) a.scale[i] = sc.v[i];
@@ -417,7 +422,7 @@ int ntt_prepare(zk_ctx* c, int curve, uint32_t log_n) {
     for (int inv = 0; inv < 2; ++inv) {
         int rc;
         if (curve == ZK_CURVE_BLS12_381) {
-            if (log_n > 30 || log_n > (uint32_t)FrBls12_381Params::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
+            if (log_n > (uint32_t)FrBls12_381Params::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;
             rc = get_plan<CurveBls>(c, log_n, inv != 0, &pl);
         } else if (curve == ZK_CURVE_BN254) {
             if (log_n > (uint32_t)FrBn254Params::TWO_ADICITY) return ZK_ERR_DOMAIN_TOO_LARGE;

@@ -34,6 +34,7 @@ struct NttPassArgs {
     uint32_t log_m;         // non-final: log2 of the row stride M
     uint32_t log_mprev;     // non-final: log2 of the block this pass transforms (M * L)
     uint32_t s1;            // final: size (bits) of the most significant digit of the block index
+    uint32_t s2;            // final, four passes (log N >= 28): bits of the block index's second digit (0: at most three passes)
     uint32_t n_tiles;
     uint32_t quarter;       // first pass of a multi-pass transform whose input fills at most N/4 (coset_fft of n coefficients on
                             // the 4n domain): only rows < 2^S / 4 are non-zero, so the first two stages are plain copies
@@ -282,7 +283,14 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
     dit_all<F, S, 0>(x, v, c, LC, a.tw_inner, sc);
     if (c >= (1u << a.logc)) return;
     const uint64_t k1o = ((uint64_t)g << a.logc) + c;
-    const uint64_t obase = k1o + (rho << a.s1);              // digit-reversed block index
+    // digit-reversed block index.  Block b = (k1, k2[, k3]) from the most significant digit down; the output index counts k1 as the
+    // LEAST significant digit, then k2, then k3.  With three passes rho = k2 is one digit; with four, rho = (k2, k3) is swapped too.
+    uint64_t rho_rev = rho;
+    if (a.s2) {
+        const uint32_t s3 = log_rest - a.s2;
+        rho_rev = (rho >> s3) | ((rho & ((1ull << s3) - 1ull)) << a.s2);
+    }
+    const uint64_t obase = k1o + (rho_rev << a.s1);
     F sc_mul = F::split_words(a.scale);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -92,6 +92,22 @@ class Proof:
 
 
 def prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcript, coeff_a_mont, coeff_d_mont, lean: bool = False) -> Proof:
+    """`Prover::prove_with_preprocessed` (prover.rs:163-638) on the device: see `_prove`.  A failure between a round's first
+    `commit_begin` and its `round_end` (the "challenges must be different" assertion, an out-of-memory inside a transform) would leave
+    the round open on the ctx -- every later blocking commit / open / MSM would return ZK_ERR_PENDING -- so the round is dropped
+    (`zk_kzg_round_abort`) before the exception travels on."""
+    try:
+        return _prove(pk, ck, wires, public_inputs, preprocessed, coeff_a_mont, coeff_d_mont, lean)
+    except BaseException:
+        try:
+            if ck.round_pending():
+                ck.round_abort()
+        except Exception:
+            pass
+        raise
+
+
+def _prove(pk: ProverKey, ck, wires, public_inputs: dict, preprocessed: Transcript, coeff_a_mont, coeff_d_mont, lean: bool = False) -> Proof:
     """wires: the four wire columns padded to n (prover.rs:188-192), device tensors; public_inputs: position -> 4 Montgomery limbs
     (pi.rs:28-36); preprocessed: the transcript after the verifier key was seeded into it; coeff_a / coeff_d: the embedded
     curve's coefficients (`P::COEFF_A`, `P::COEFF_D`).

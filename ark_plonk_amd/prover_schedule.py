@@ -378,7 +378,21 @@ class ProofSchedule:
 
     def run_once(self, proof_id=None):
         """One proof's hot path.  Returns the 29 commitments/openings (G1Affine) in call order.
-        proof_id: which synthetic witness (None = the next one; pass the same id to reproduce a proof)."""
+        proof_id: which synthetic witness (None = the next one; pass the same id to reproduce a proof).
+        A failure inside an open round drops the round (zk_kzg_round_abort) and the schedule's own count of its jobs, so that the
+        ctx takes blocking calls again and the next proof starts clean."""
+        try:
+            return self._run_once(proof_id)
+        except BaseException:
+            self._pending = []
+            try:
+                if self.ck.round_pending():
+                    self.ck.round_abort()
+            except Exception:
+                pass
+            raise
+
+    def _run_once(self, proof_id=None):
         self._set_proof(proof_id)
         d, d4, n = self.dom_n, self.dom_4n, self.n
         out = []

@@ -110,7 +110,11 @@ int zk_domain_new(int curve_id, uint64_t num_coeffs, zk_domain_info* out);
 /* ---- a2-a5: NTT ------------------------------------------------------------------------------ */
 /* Host-buffer transform.  in: in_len (<= 2^log_n) Montgomery Fr elements, zero-extended;
  * out: 2^log_n elements, natural order.  in == out allowed.
- * Replaces ark_poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place. */
+ * Replaces ark_poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place.
+ * Sizes: every log_n the reference admits (prover.rs:169-173, error.rs:14-21: up to the field's two-adicity, 32 for BLS12-381,
+ * 28 for BN254; beyond it ZK_ERR_DOMAIN_TOO_LARGE, as Error::InvalidEvalDomainSize) -- one pass to 2^9, two to 2^18, three to 2^27,
+ * four above.  What bounds the size in practice is memory: the vector, a work vector and the first pass boundary's twiddle table
+ * are 2^log_n x 32 bytes each (8 GiB at 2^28); a size that does not fit the card returns ZK_ERR_OOM. */
 int zk_ntt(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, const uint64_t* in, size_t in_len, uint64_t* out);
 /* n_polys host-buffer transforms of one kind and size; ins[i] == outs[i] allowed. */
 int zk_ntt_batch(zk_ctx* ctx, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const uint64_t* const* ins,
@@ -188,7 +192,11 @@ size_t zk_srs_len(const zk_srs* srs);
 int zk_srs_cache_config(size_t max_idle_bytes);
 int zk_srs_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* resident_bytes);
 
-/* MSM over srs[base_offset .. base_offset+n) with host / device canonical scalars. */
+/* MSM over srs[base_offset .. base_offset+n) with host / device canonical scalars.
+ * Sizes: the window-table path takes 2^13 <= n <= 2^26 points per MSM (a sorted reference holds 26 bits of point index); shorter and
+ * longer vectors run the per-window path over the same SRS inside the same call (identical result, no table rows read), which
+ * takes n * windows < 2^32 references: about 2^27 points at its 16-bit window.  Beyond that ZK_ERR_UNSUPPORTED (a 2^28-point SRS
+ * is 24 GiB in the ABI form; the reference's largest bench is 2^18, benches/plonk.rs:95-103). */
 int zk_msm_g1_srs(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const uint64_t* scalars, size_t n,
                   uint64_t* out_xy, uint8_t* out_inf);
 int zk_msm_g1_srs_dev(zk_ctx* ctx, zk_srs* srs, size_t base_offset, const void* d_scalars, size_t n,

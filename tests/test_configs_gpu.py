@@ -211,3 +211,88 @@ def test_table_window_20_identity_2_20(ctx, oracle_cpu):
     got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
     ck.close()
     assert_is_scalar_times_g(got, k, cid)
+
+
+# ---- size edges: what a caller gets at the first sizes the round-3 library refused
+def test_ntt_four_passes_2_28(ctx):
+    """log N = 28 needs a fourth pass (three passes end at 2^27).  The reference admits any domain up to the field's two-adicity
+    (prover.rs:169-173, error.rs:14-21).  Checked against the three-pass transform (itself checked against the CPU restatement):
+    the 2^28-point fft of 2^20 coefficients, read at every 256th point, IS their 2^20-point fft -- e[256 k] = sum_j a_j
+    w_{2^28}^(256 k j) = sum_j a_j w_{2^20}^(k j) -- and likewise on the coset; then full-length round trips of all four kinds
+    (8 GiB per vector, in place)."""
+    import torch
+    cid = 0
+    g = torch.Generator(device="cuda").manual_seed(28)
+    a = torch.randint(0, 1 << 62, (1 << 20, 4), dtype=torch.int64, device="cuda", generator=g)
+    d20 = zk.Radix2EvaluationDomain.new(1 << 20, cid, ctx)
+    d28 = zk.Radix2EvaluationDomain.new(1 << 28, cid, ctx)
+    for name in ("fft", "coset_fft"):
+        big = getattr(d28, name)(a)
+        small = getattr(d20, name)(a)
+        assert big.shape[0] == 1 << 28 and torch.equal(big[::256], small), name
+        del big, small
+    x = torch.randint(0, 1 << 62, (1 << 28, 4), dtype=torch.int64, device="cuda", generator=g)
+    y = x.clone()
+    d28.fft_in_place(y)
+    assert not torch.equal(y, x)
+    d28.ifft_in_place(y)
+    assert torch.equal(y, x)
+    d28.coset_fft_in_place(y)
+    d28.coset_ifft_in_place(y)
+    assert torch.equal(y, x)
+    del x, y
+    torch.cuda.empty_cache()
+    # beyond the two-adicity: the reference's Error::InvalidEvalDomainSize
+    assert zk.Radix2EvaluationDomain.new(1 << 33, cid, ctx) is None         # `GeneralEvaluationDomain::new` returns None there too
+
+
+def test_msm_beyond_the_table_path_limit(ctx, oracle_cpu, monkeypatch):
+    """A table-path reference holds 26 bits of point index: MSMs of more than 2^26 points over an SRS WITH a table run the
+    per-window path inside the same call instead of returning ZK_ERR_UNSUPPORTED (round 3).  The dispatch is exercised with the
+    limit lowered through its test hook (a real 2^26-point table is 130 GiB): same commitment on both sides of the limit, single
+    MSMs, blocking batches and deferred rounds."""
+    import torch
+    cid = 0
+    n = (1 << 15) + 2
+    pw_c, pw_m = tau_powers(oracle_cpu, cid, n)
+    bases = srs_from_powers(ctx, cid, pw_c)
+    scal = _rand_scalars(n, 2626)
+    k = sum_scalar_times_powers(oracle_cpu, cid, scal, pw_m)
+    d_s = torch.from_numpy(scal.view(np.int64)).cuda()
+    ck = zk.CommitterKey(bases, cid, ctx).precompute()
+    ctx.profile(1)
+    ctx.profile_reset()
+    want = ck.msm(d_s)                                            # table path
+    assert ctx.profile_get("msm_accumulate_jobs")[1] == 1
+    assert_is_scalar_times_g(want, k, cid)
+    monkeypatch.setenv("ZK_PRE_MAX_LOG_N", "15")                   # n = 2^15 + 2 is now beyond the limit
+    ctx.profile_reset()
+    assert ck.msm(d_s) == want
+    assert ck.commit_batch([d_s, d_s[: 1 << 14]], canonical=[True, True])[0] == want
+    ck.commit_begin([d_s], canonical=[True])
+    ck.commit_begin([d_s[: 1 << 14]], canonical=[True])           # this one still takes the table path
+    got = ck.round_end(2)
+    assert got[0] == want
+    assert ctx.profile_get("msm_accumulate_jobs")[1] == 2          # only the two short jobs went through the merged table launch
+    ctx.profile(0)
+    monkeypatch.delenv("ZK_PRE_MAX_LOG_N")
+    ck.close()
+
+
+def test_msm_2_26_plus_2_points_per_window_path(ctx, oracle_cpu):
+    """The first size past the table path's limit at its real value: 2^26 + 2 points (6.4 GiB of bases) through zk_msm_g1_srs_dev --
+    the per-window path, 16 windows x 67 M references -- against the KZG identity MSM(s, tau^i G) = (sum s_i tau^i) G."""
+    import torch
+    cid = 0
+    n = (1 << 26) + 2
+    pw_c, pw_m = tau_powers(oracle_cpu, cid, n)
+    bases = srs_from_powers(ctx, cid, pw_c)
+    del pw_c
+    scal = _rand_scalars(n, 262626)
+    k = sum_scalar_times_powers(oracle_cpu, cid, scal, pw_m)
+    del pw_m
+    ck = zk.CommitterKey(bases, cid, ctx)
+    del bases
+    got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
+    ck.close()
+    assert_is_scalar_times_g(got, k, cid)

@@ -235,55 +235,125 @@ static inline size_t bitrev(size_t a, int bits) {
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (a & 1); a >>= 1; }
     return r;
 }
+// ark-poly 0.3 `derange`: swap xs[i] <-> xs[bitrev(i)].  Every pair (i, ri) with i < ri is touched by exactly one iteration, so the
+// loop parallelises as it stands (the reference's is serial; same permutation).
 template <class F> static void derange(F* xs, int log_n) {
     size_t n = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static) if (n >= 4096)
     for (size_t i = 1; i < n; ++i) { size_t ri = bitrev(i, log_n); if (i < ri) std::swap(xs[i], xs[ri]); }
 }
+// roots[i] = root^i, i < n/2.  ark 0.3's parallel `roots_of_unity` (compute_powers): each block starts from root^(block start)
+// and runs the recurrence inside the block -- the same field elements as the serial recurrence (a power has one reduced value).
 template <class F> static std::vector<F> roots_of_unity(F root, size_t n) {
     size_t h = n / 2 > 0 ? n / 2 : 1;
     std::vector<F> r(h);
-    F cur = F::one();
-    for (size_t i = 0; i < h; ++i) { r[i] = cur; cur = cur * root; }
+    const size_t B = 4096;
+    size_t nb = (h + B - 1) / B;
+    #pragma omp parallel for schedule(static) if (h >= 4 * B)
+    for (size_t b = 0; b < nb; ++b) {
+        F cur = root.pow_u64((u64)(b * B));
+        size_t e = std::min(h, (b + 1) * B);
+        for (size_t i = b * B; i < e; ++i) { r[i] = cur; cur = cur * root; }
+    }
     return r;
 }
-// in-order -> out-of-order, decimation in frequency (Gentleman-Sande), with root compaction per stage
+// Speed only, semantics untouched: ark-poly 0.3 runs the log2(n) butterfly stages one after the other over the
+// whole vector, parallel inside a stage (`apply_butterfly`), i.e. log2(n) passes over memory -- 22 passes over 128 MiB for a 2^22
+// transform.  The butterflies of a stage with gap g stay inside aligned chunks of 2g elements, and so do all the stages with smaller
+// gaps: once a chunk fits a core's cache (BLOCK elements = 1 MiB) a thread runs ALL the remaining stages of its chunk before it moves
+// on.  Same butterflies, same operands, same results (the order of independent butterflies does not matter), ~log2(n / BLOCK) + 1
+// passes over memory.  The twiddle table is indexed with a stride instead of being compacted between stages (same values).
+static const size_t NTT_BLOCK = (size_t)1 << 15;
+// The twiddles of the stage with gap g are roots[j * (n/2) / g], j < g: read with that stride they are one cache line and -- for the
+// small gaps -- one page each.  ark compacts them per stage for the same reason (`compacted_roots`, MIN_NUM_CHUNKS_FOR_COMPACTION);
+// here: one table for all the in-block stages (the entries of gap g at [g, 2g)), and a per-stage copy for the stages above.
+template <class F> static std::vector<F> block_twiddles(const F* roots, size_t half, size_t max_gap) {
+    std::vector<F> t(2 * max_gap > 2 ? 2 * max_gap : 2);
+    for (size_t g = 1; g <= max_gap; g *= 2) {
+        const size_t stride = half / g;
+        #pragma omp parallel for schedule(static) if (g >= 4096)
+        for (size_t j = 0; j < g; ++j) t[g + j] = roots[j * stride];
+    }
+    return t;
+}
+template <class F> static const F* stage_twiddles(const F* roots, size_t half, size_t gap, std::vector<F>& scratch) {
+    const size_t stride = half / gap;
+    if (stride == 1) return roots;
+    scratch.resize(gap);
+    #pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < gap; ++j) scratch[j] = roots[j * stride];
+    return scratch.data();
+}
+// one DIF stage (gap) on the chunk xs[lo, hi): in-order -> out-of-order butterflies  (a, b) -> (a + b, (a - b) w_j)
+template <class F> static inline void dif_stage(F* xs, size_t lo, size_t hi, size_t gap, const F* tw) {
+    for (size_t c = lo; c < hi; c += 2 * gap)
+        for (size_t j = 0; j < gap; ++j) {
+            F* x = xs + c + j; F* y = x + gap;
+            F neg = *x - *y; *x = *x + *y; *y = neg * tw[j];
+        }
+}
+// one DIT stage (gap) on the chunk xs[lo, hi): out-of-order -> in-order butterflies  (a, b) -> (a + w_j b, a - w_j b)
+template <class F> static inline void dit_stage(F* xs, size_t lo, size_t hi, size_t gap, const F* tw) {
+    for (size_t c = lo; c < hi; c += 2 * gap)
+        for (size_t j = 0; j < gap; ++j) {
+            F* x = xs + c + j; F* y = x + gap;
+            F t = *y * tw[j];
+            F neg = *x - t; *x = *x + t; *y = neg;
+        }
+}
+// in-order -> out-of-order, decimation in frequency (Gentleman-Sande): ark-poly 0.3 io_helper
 template <class F> static void io_helper(F* xs, size_t n, F root) {
     std::vector<F> roots = roots_of_unity(root, n);
-    size_t step = 1;
-    bool first = true;
-    for (size_t gap = n / 2; gap > 0; gap /= 2) {
-        if (!first) {  // compaction: keep every second root
-            size_t m = roots.size() / 2;
-            for (size_t i = 0; i < m; ++i) roots[i] = roots[2 * i];
-            roots.resize(m > 0 ? m : 1);
-        }
-        first = false;
-        size_t chunk = 2 * gap;
-        size_t nchunks = n / chunk;
-        #pragma omp parallel for schedule(static) collapse(2) if (n >= 4096)
-        for (size_t c = 0; c < nchunks; ++c)
-            for (size_t j = 0; j < gap; ++j) {
-                F* lo = xs + c * chunk + j; F* hi = lo + gap;
-                F neg = *lo - *hi; *lo = *lo + *hi; *hi = neg * roots[j];
+    const size_t half = n / 2;
+    if (half == 0) return;
+    std::vector<F> scratch;
+    size_t gap = half;
+    // stages whose chunks are larger than a block: parallel inside the stage (chunk x piece-of-the-half-chunk items)
+    for (; 2 * gap > NTT_BLOCK; gap /= 2) {
+        const F* tw = stage_twiddles(roots.data(), half, gap, scratch);
+        const size_t chunk = 2 * gap, nch = n / chunk, piece = 4096, ppc = gap / piece;     // gap >= NTT_BLOCK / 2 > piece here
+        #pragma omp parallel for schedule(static)
+        for (size_t t = 0; t < nch * ppc; ++t) {
+            const size_t c = (t / ppc) * chunk, j0 = (t % ppc) * piece;
+            for (size_t j = j0; j < j0 + piece; ++j) {
+                F* x = xs + c + j; F* y = x + gap;
+                F neg = *x - *y; *x = *x + *y; *y = neg * tw[j];
             }
-        step *= 2;
+        }
     }
-    (void)step;
+    // all remaining stages, one cache-resident chunk at a time
+    const std::vector<F> small = block_twiddles(roots.data(), half, gap);
+    const size_t chunk = 2 * gap;
+    #pragma omp parallel for schedule(static) if (n >= 4096)
+    for (size_t c = 0; c < n; c += chunk)
+        for (size_t g = gap; g > 0; g /= 2) dif_stage(xs, c, c + chunk, g, small.data() + g);
 }
-// out-of-order -> in-order, decimation in time (Cooley-Tukey)
+// out-of-order -> in-order, decimation in time (Cooley-Tukey): ark-poly 0.3 oi_helper
 template <class F> static void oi_helper(F* xs, size_t n, F root) {
     std::vector<F> roots = roots_of_unity(root, n);
-    for (size_t gap = 1; gap < n; gap *= 2) {
-        size_t chunk = 2 * gap;
-        size_t nchunks = n / chunk;
-        size_t stride = (n / 2) / gap;  // root index step
-        #pragma omp parallel for schedule(static) collapse(2) if (n >= 4096)
-        for (size_t c = 0; c < nchunks; ++c)
-            for (size_t j = 0; j < gap; ++j) {
-                F* lo = xs + c * chunk + j; F* hi = lo + gap;
-                F t = *hi * roots[j * stride];
-                F neg = *lo - t; *lo = *lo + t; *hi = neg;
+    const size_t half = n / 2;
+    if (half == 0) return;
+    const size_t chunk = std::min(n, NTT_BLOCK);
+    {   // the stages with gap < chunk, one cache-resident chunk at a time
+        const std::vector<F> small = block_twiddles(roots.data(), half, chunk / 2);
+        #pragma omp parallel for schedule(static) if (n >= 4096)
+        for (size_t c = 0; c < n; c += chunk)
+            for (size_t g = 1; g < chunk; g *= 2) dit_stage(xs, c, c + chunk, g, small.data() + g);
+    }
+    // the stages whose chunks are larger than a block: parallel inside the stage
+    std::vector<F> scratch;
+    for (size_t gap = chunk; gap < n; gap *= 2) {
+        const F* tw = stage_twiddles(roots.data(), half, gap, scratch);
+        const size_t ch = 2 * gap, nch = n / ch, piece = 4096, ppc = gap / piece;
+        #pragma omp parallel for schedule(static)
+        for (size_t t = 0; t < nch * ppc; ++t) {
+            const size_t c = (t / ppc) * ch, j0 = (t % ppc) * piece;
+            for (size_t j = j0; j < j0 + piece; ++j) {
+                F* x = xs + c + j; F* y = x + gap;
+                F tv = *y * tw[j];
+                F neg = *x - tv; *x = *x + tv; *y = neg;
             }
+        }
     }
 }
 template <class F> static void distribute_powers(F* xs, size_t len, F g) {
@@ -429,6 +499,51 @@ static Jac<Fq> msm_pippenger(const Affine<Fq>* bases, const u64* scalars /* n x 
     return lowest;
 }
 
+// The same sum with the work cut into (window, range of points) tasks so that every core of a large host is busy -- NOT ark's shape
+// (ark 0.3 parallelises over the windows only: at most W = 17 busy threads at 2^20 points), reported by bench.py as `all_cores`.
+// Every task accumulates its range's digits of one window into its own buckets and reduces them with the running sum; the window's
+// sum is the sum of its tasks' results.  `parts` ranges per window.
+template <class Fq, class Fr>
+static Jac<Fq> msm_pippenger_chunked(const Affine<Fq>* bases, const u64* scalars, size_t n, int threads, int parts) {
+    int c = ark_window(n);
+    int num_bits = Fr::P.bits;
+    std::vector<int> starts;
+    for (int w = 0; w < num_bits; w += c) starts.push_back(w);
+    const int W = (int)starts.size();
+    if (parts < 1) parts = 1;
+    std::vector<Jac<Fq>> part_sums((size_t)W * parts);
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int t = 0; t < W * parts; ++t) {
+        const int wi = t / parts, pi = t % parts;
+        const int w_start = starts[wi];
+        const size_t lo = n * (size_t)pi / parts, hi = n * (size_t)(pi + 1) / parts;
+        Jac<Fq> res = Jac<Fq>::zero();
+        std::vector<Jac<Fq>> buckets(((size_t)1 << c) - 1, Jac<Fq>::zero());
+        for (size_t i = lo; i < hi; ++i) {
+            const u64* s = scalars + 4 * i;
+            if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;
+            if (s[0] == 1 && (s[1] | s[2] | s[3]) == 0) {
+                if (w_start == 0) res.add_assign_mixed(bases[i]);
+                continue;
+            }
+            int limb = w_start / 64, off = w_start % 64;
+            u64 v = s[limb] >> off;
+            if (off && limb + 1 < 4) v |= s[limb + 1] << (64 - off);
+            u64 d = v & (((u64)1 << c) - 1);
+            if (d) buckets[d - 1].add_assign_mixed(bases[i]);
+        }
+        Jac<Fq> running = Jac<Fq>::zero();
+        for (size_t b = buckets.size(); b-- > 0;) { running.add_assign(buckets[b]); res.add_assign(running); }
+        part_sums[t] = res;
+    }
+    Jac<Fq> total = Jac<Fq>::zero();
+    for (int wi = W - 1; wi >= 0; --wi) {
+        if (wi != W - 1) for (int k = 0; k < c; ++k) total.double_in_place();
+        for (int pi = 0; pi < parts; ++pi) total.add_assign(part_sums[(size_t)wi * parts + pi]);
+    }
+    return total;
+}
+
 template <class Fq>
 static void load_bases(std::vector<Affine<Fq>>& v, const u64* xy, const uint8_t* inf, size_t n) {
     v.resize(n);
@@ -532,6 +647,27 @@ int ora_ntt(int curve_id, int kind, int log_n, const u64* in, size_t in_len, u64
     ensure_init();
     if (curve_id == 0) return ntt_run<FrBls>(CURVES[0], kind, log_n, in, in_len, out);
     if (curve_id == 1) return ntt_run<FrBn>(CURVES[1], kind, log_n, in, in_len, out);
+    return -1;
+}
+
+// all-cores shape (msm_pippenger_chunked): `parts` point ranges per window
+int ora_msm_g1_chunked(int curve_id, const u64* bases_xy, const uint8_t* inf, const u64* scalars, size_t n,
+                       u64* out_xy, uint8_t* out_inf, int threads, int parts) {
+    ensure_init();
+    if (curve_id == 0) {
+        std::vector<Affine<FqBls>> bases;
+        load_bases<FqBls>(bases, bases_xy, inf, n);
+        Jac<FqBls> r = n ? msm_pippenger_chunked<FqBls, FrBls>(bases.data(), scalars, n, threads, parts) : Jac<FqBls>::zero();
+        store_affine<FqBls>(r.into_affine(), out_xy, out_inf);
+        return 0;
+    }
+    if (curve_id == 1) {
+        std::vector<Affine<FqBn>> bases;
+        load_bases<FqBn>(bases, bases_xy, inf, n);
+        Jac<FqBn> r = n ? msm_pippenger_chunked<FqBn, FrBn>(bases.data(), scalars, n, threads, parts) : Jac<FqBn>::zero();
+        store_affine<FqBn>(r.into_affine(), out_xy, out_inf);
+        return 0;
+    }
     return -1;
 }
 

@@ -32,6 +32,7 @@ def lib():
         L = ctypes.CDLL(_SO)
         L.ora_ntt.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _u64p, ctypes.c_size_t, _u64p]
         L.ora_msm_g1.argtypes = [ctypes.c_int, _u64p, _u8p, _u64p, ctypes.c_size_t, _u64p, _u8p, ctypes.c_int]
+        L.ora_msm_g1_chunked.argtypes = [ctypes.c_int, _u64p, _u8p, _u64p, ctypes.c_size_t, _u64p, _u8p, ctypes.c_int, ctypes.c_int]
         L.ora_srs_powers.argtypes = [ctypes.c_int, _u64p, ctypes.c_size_t, _u64p]
         L.ora_kzg_commit.argtypes = [ctypes.c_int, _u64p, ctypes.c_size_t, _u64p, ctypes.c_size_t, _u64p, _u8p, ctypes.c_int]
         L.ora_kzg_witness.argtypes = [ctypes.c_int, _u64p, ctypes.c_size_t, _u64p, _u64p]
@@ -89,6 +90,27 @@ def msm_g1(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, inf=None, t
                           threads if threads > 0 else num_threads())
     if rc:
         raise ValueError(f"ora_msm_g1 rc={rc}")
+    return out, int(oinf[0])
+
+
+def msm_g1_all_cores(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, inf=None, threads: int = 0, parts: int = 0):
+    """The same MSM cut into (window, point range) tasks so that every core is busy -- not ark's shape (threads over the windows
+    only); `parts` ranges per window (0: threads / windows, at least 1)."""
+    L = FQ_LIMBS[curve_id]
+    b = _c64(bases_xy).reshape(-1, 2 * L)
+    s = _c64(scalars).reshape(-1, 4)
+    n = min(b.shape[0], s.shape[0])
+    inf_a = None if inf is None else np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros(2 * L, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    t = threads if threads > 0 else num_threads()
+    if parts <= 0:
+        c = lib().ora_window_size(n)
+        w = -(-(255 if curve_id == 0 else 254) // c)
+        parts = max(1, -(-t // w))
+    rc = lib().ora_msm_g1_chunked(curve_id, _p64(b), _p8(inf_a), _p64(s), n, _p64(out), _p8(oinf), t, parts)
+    if rc:
+        raise ValueError(f"ora_msm_g1_chunked rc={rc}")
     return out, int(oinf[0])
 
 

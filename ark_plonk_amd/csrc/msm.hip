@@ -4,20 +4,23 @@
 // reference at plonk-core/src/commitment.rs:45,83 and through every `PC::commit` / `PC::open`
 // (proof_system/prover.rs:213,289-291,312-317,361-363,387-389,459-469,579,582-591,606,609-618).
 //
-// Pipeline (all on the ctx stream; no host round trip until the window sums are read back):
-//   1. msm_digits(2)  signed c-bit digits of every scalar (window-major int16; into_repr fused for commits)
+// Pipeline (all on the ctx stream; no host round trip until the window sums are read back).  On the window-table path every step is
+// ONE launch per kernel for all the MSMs of a prover round (job = blockIdx.y, or a block range of the accumulation):
+//   1. digits         signed c-bit digits of every scalar (window-major; into_repr fused for commits) + the slab counts of the sort's
+//                     256 partitions: psort(w)_digits_hist, per job, queued when the job is submitted (the only reader of the input)
 //   2. sort           the (point, sign) references by bucket, no global atomics:
-//                       window-table path: psort_digits_hist / psort_scan / psort_scatter / psort_final -- two-pass
-//                       partition sort over the one shared bucket set;
-//                       per-window path:   msm_hist / msm_scan1/2/3 / msm_scatter -- LDS counting sort
-//   3. msm_accumulate every lane sums a fixed-length chunk of the sorted list with XYZZ mixed
-//                     additions (no inversion); runs that cross a chunk edge are emitted
-//                     as partials (load-balanced regardless of the scalar distribution)
+//                       window-table path: psort_scan / psort(w)_scatter / psort(w)_final -- two-pass partition sort over the one
+//                                          shared bucket set, the jobs of a round batched;
+//                       per-window path:   msm_digits / msm_hist / msm_scan1/2/3 / msm_scatter -- LDS counting sort
+//   3. msm_accumulate(_batch) every lane sums a fixed-length chunk of the sorted list with XYZZ mixed additions (no inversion); runs
+//                     that cross a chunk edge are emitted as partials (load-balanced regardless of the scalar distribution); the
+//                     jobs of a round follow each other inside one launch
 //   4. msm_combine*   joins the chunk-edge partials of each bucket: lane(s) / wavefront (shuffle tree) /
 //                     workgroup per bucket by size class
 //   5. msm_seg_reduce segmented running-sum reduction (sum_j j*B_j), level 1
-//   6. msm_win_finish LDS suffix-scan + tree reduction per (virtual) window -> window sums (arkworks layout)
-//   host: the few window sums are combined (table path: sum of 32 virtual windows; per-window path:
+//   6. msm_win_finish LDS suffix-scan + tree reduction per (virtual) window -> window sums (arkworks layout), or -- the multi-GPU
+//                     exchange -- one more launch that leaves every job's whole sum on the device (zk_kzg_round_end_partial_dev)
+//   host: the few window sums are combined (table path: sum of 64 virtual windows; per-window path:
 //         Horner with W*c doublings) and normalised to affine.
 // Device arithmetic is the signed 30-bit-limb Montgomery field of fields.cuh with the lazy XYZZ
 // group law of ecu.cuh; bases are converted once, at SRS registration, into that form.

@@ -98,7 +98,10 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
     cpu.build()
     cores = cpu.num_threads()
     rng = np.random.default_rng(1)
-    cpu.ntt(cid, 1, 10, rng.integers(0, 1 << 62, size=(1024, 4), dtype=np.uint64))  # warm OpenMP
+    # warm OpenMP: the first PARALLEL region creates the thread team (0.25 s for 128 threads on these hosts -- rounds 1-3 timed it as
+    # part of the 2^20 ifft, whose own loops are parallel only from 2^12 elements on), so the warm-up must be large enough to have one
+    cpu.ntt(cid, 1, 16, rng.integers(0, 1 << 62, size=(1 << 16, 4), dtype=np.uint64))
+    cpu.ntt(cid, 2, 16, rng.integers(0, 1 << 62, size=(1 << 14, 4), dtype=np.uint64))
     # probe at 2^14 to bound the sample
     probe = 14
     srs_s = cpu.srs_powers(cid, 0x7A5C0DE, 1 << 10)
@@ -131,8 +134,8 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
         t_all = time.perf_counter() - t0
         if not (np.array_equal(all_xy, ref_xy) and all_inf == ref_inf):
             t_all = None
-        c_w = cpu.window_size(1 << s_msm) if hasattr(cpu, "window_size") else 0
-        parts = max(1, -(-cores // max(1, -(-bits // c_w)))) if c_w else 0
+        c_w = cpu.window_size(1 << s_msm)
+        parts = max(1, -(-cores // max(1, -(-bits // c_w))))
     except Exception:
         t_all = None
     scale = ark_adds(1 << log_n, bits) / ark_adds(1 << s_msm, bits)

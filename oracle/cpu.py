@@ -93,6 +93,11 @@ def msm_g1(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, inf=None, t
     return out, int(oinf[0])
 
 
+def window_size(n: int) -> int:
+    """ark 0.3's Pippenger window for n points: 3 below 32, else ceil(log2 n) * 69 / 100 + 2."""
+    return int(lib().ora_window_size(n))
+
+
 def msm_g1_all_cores(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, inf=None, threads: int = 0, parts: int = 0):
     """The same MSM cut into (window, point range) tasks so that every core is busy -- not ark's shape (threads over the windows
     only); `parts` ranges per window (0: threads / windows, at least 1)."""

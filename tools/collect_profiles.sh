@@ -9,6 +9,7 @@
 # python3 itself (no env / bash hop: the profiler's library has initialised the GPU by then).
 set -u
 tag=$1
+export ZK_ACC_LAUNCHES_PER_PROOF=${ZK_ACC_LAUNCHES_PER_PROOF:-5}
 out=gpurun_out/prof_$tag
 mkdir -p "$out" profiles
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

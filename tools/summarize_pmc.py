@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -49,7 +50,7 @@ def main():
         if "msm_accumulate" in k:
             # since round 4 one launch (msm_accumulate_batch) sums every MSM of a prover round: 5 launches and 29 MSMs per proof at the headline
             # schedule, so the per-launch average below goes with bench.py's per-launch average of algorithmic bytes (the same launch mix)
-            json.dump({"kernel": k.split("(")[0].replace("void (anonymous namespace)::", "")[:60], "launches": c, "fetch_size_kib_raw": f, "write_size_kib": w,
+            json.dump({"kernel": (re.search(r"msm_accumulate\w*", k) or re.search(r"\w+", k)).group(0), "launches": c, "fetch_size_kib_raw": f, "write_size_kib": w,
                        "hbm_bytes_per_launch": (2 * f + w) * 1024,
                        "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `{cmd}`; per-launch averages; "
                                "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as read.",

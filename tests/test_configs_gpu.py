@@ -296,3 +296,45 @@ def test_msm_2_26_plus_2_points_per_window_path(ctx, oracle_cpu):
     got = ck.msm(torch.from_numpy(scal.view(np.int64)).cuda())
     ck.close()
     assert_is_scalar_times_g(got, k, cid)
+
+
+@pytest.mark.parametrize("cid,log_n,G", [(0, 14, 3), (1, 14, 3), (1, 15, 5), (0, 19, 4)])
+def test_window_shards_small_both_curves(cid, log_n, G, ctx, oracle_cpu):
+    """Window-sharded tables on both curves and both digit paths (c = 16 below 2^19 points: int16 digits, 16 windows; c = 17 at 2^19:
+    folded scalars, 15 windows), with a rank count that does not divide the windows: the G partials -- host form and device form
+    (BN254's partial is 192 bytes) -- add up to the commitment of the whole table and of the CPU restatement; a vector too short for
+    the table path is computed by the owner of window 0 only."""
+    import torch
+    n = 1 << log_n
+    pw_c, pw_m = tau_powers(oracle_cpu, cid, n)
+    bases = srs_from_powers(ctx, cid, pw_c)
+    rng = np.random.default_rng(1000 + 10 * log_n + cid)
+    poly = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    poly[:, 3] >>= 3                                        # Montgomery residues below both moduli
+    short = poly[:100].copy()
+    d_poly = torch.from_numpy(poly.view(np.int64)).cuda()
+    d_short = torch.from_numpy(short.view(np.int64)).cuda()
+    full = zk.CommitterKey(bases, cid, ctx).precompute()
+    want = full.commit_batch([d_poly, d_short])
+    windows = full.table_windows()
+    full.close()
+    if log_n <= 16:
+        exp_xy, exp_inf = oracle_cpu.kzg_commit(cid, bases.cpu().numpy().view(np.uint64), poly)
+        assert not want[0].infinity and np.array_equal(want[0].xy(), exp_xy)
+    parts, dev = [], []
+    for g in range(G):
+        ckw = zk.CommitterKey(bases, cid, ctx).precompute(rows=(g, G))
+        assert ckw.table_rows() == (g, G, (windows - g + G - 1) // G)
+        parts.append(ckw.commit_batch_partial([d_poly, d_short]))
+        pw = ckw.partial_dev_words()
+        assert pw == (32 if cid == 0 else 24)
+        buf = torch.zeros((2, pw), dtype=torch.int64, device="cuda")
+        ckw.commit_begin([d_poly])
+        ckw.commit_begin([d_short])
+        ckw.round_end_partial_dev(buf, 2)
+        dev.append(buf)
+        if g == G - 1:
+            got_dev = ckw.sum_partials_dev(torch.stack(dev).reshape(G, 2 * pw).contiguous(), G, 2)
+        ckw.close()
+    assert zk.sum_partials_batch(np.stack(parts), cid) == want
+    assert got_dev == want

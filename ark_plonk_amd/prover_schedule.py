@@ -104,6 +104,10 @@ class ProofSchedule:
         # (quotient_poly.rs:72-120: wires, z, z_2, f, table, h_1, h_2 are all committed before alpha is drawn) behind round 3.  Same
         # transforms, same sizes, same batches; they run while the host combines the window sums, normalises and hashes.
         self.hoist = hoist
+        # hoist == "stream": the hoisted transforms go to a SECOND HIP stream (a second zk_ctx of the same GPU: a ctx drives one stream),
+        # so that they run WHILE the round's memory-bound sort passes and latency-bound reductions occupy the first one instead of
+        # behind them; joined before their results are used (`_join_side`).  Same transforms, same results.
+        self.side_stream = hoist == "stream" and world == 1
         self._pending = []          # per open call: ("q", n_jobs) queued in the ABI's round | ("r", [points]) already computed
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
@@ -131,6 +135,13 @@ class ProofSchedule:
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
         self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
         dev = torch.device("cuda", ctx.device)
+        self._side_done = []
+        if self.side_stream:
+            from .context import Context
+            self.ctx2 = Context(ctx.device)
+            self.side = torch.cuda.Stream(device=dev)
+            self.dom_n2 = Radix2EvaluationDomain.new(self.n, curve, self.ctx2)
+            self.dom_4n2 = Radix2EvaluationDomain.new(4 * self.n, curve, self.ctx2)
         g = torch.Generator(device=dev).manual_seed(seed)
         n = self.n
 
@@ -266,6 +277,30 @@ class ProofSchedule:
 
     def _hoisting(self):
         return self.hoist and not self._immediate()
+
+    def _side(self, fn):
+        """Run `fn(dom_n, dom_4n)` (transforms) on the side stream, ordered after everything queued on the main stream so far."""
+        if not self.side_stream:
+            return fn(self.dom_n, self.dom_4n)
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            out = fn(self.dom_n2, self.dom_4n2)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._side_done.append(done)
+        return out
+
+    def _join_side(self):
+        """The main stream waits for everything the side stream was given."""
+        if self._side_done:
+            main = self.torch.cuda.current_stream()
+            for ev in self._side_done:
+                main.wait_event(ev)
+            self._side_done = []
 
     def _round_reduce(self):
         """Queue the open round's reductions now; what is launched until `_round_end` runs behind them, under the host's part."""
@@ -411,7 +446,7 @@ class ProofSchedule:
         self._round_begin(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
         if hoist:
             self._round_reduce()
-            sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]     # of round 3
+            sig = self._side(lambda dn, d4n: dn.batch(0, self.sigma) if self.ntt_batch else [dn.fft(self.sigma[i]) for i in range(4)])     # of round 3
         out += self._round_end()
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         t_ev, f_ev, h1_ev, h2_ev = self.aux_evals[0:4]
@@ -433,14 +468,14 @@ class ProofSchedule:
         self._round_begin([c[7]], labels=["h2"])
         if hoist:
             self._round_reduce()
-            c[10] = d.ifft(self.aux_evals[6])     # pi   (of round 3)
-            c[11] = d.ifft(self.aux_evals[7])     # l1   (of round 4)
+            c[10], c[11] = self._side(lambda dn, d4n: (dn.ifft(self.aux_evals[6]), dn.ifft(self.aux_evals[7])))     # pi (of round 3), l1 (of round 4)
         out += self._round_end()                              # f, h_1, h_2 enter the transcript before beta is drawn (prover.rs:320)
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         if sig is None:
             sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
         if self.grand_products:
+            self._join_side()                                 # the sigma evaluations feed the permutation product
             from . import permutation
             z_evals = permutation.permutation_evals(d, self.evals, sig, self.chi_mont, self.z_mont)       # beta, gamma
         c[8] = d.ifft(z_evals)                    # z
@@ -451,23 +486,24 @@ class ProofSchedule:
         self._round_begin([c[9]], labels=["z2"])              # prover.rs:387
         names = ("l1", "z", "w_l", "w_r", "w_o", "w_4", "z2", "f", "table", "h1", "h2", "pi")
 
-        def quotient_coset_ffts():
+        def quotient_coset_ffts(dn, d4n):
             qpolys = (c[11], c[8], c[0], c[1], c[2], c[3], c[9], c[5], c[4], c[6], c[7], c[10])
             if self.ntt_batch:
-                d4.batch(2, qpolys, outs=[self.cos[name] for name in names])          # coset_fft, n coefficients zero-extended to 4n
+                d4n.batch(2, qpolys, outs=[self.cos[name] for name in names])          # coset_fft, n coefficients zero-extended to 4n
             else:
                 for name, poly in zip(names, qpolys):
-                    d4._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)
+                    d4n._run(2, poly, out=self.cos[name] if self.quotient else self.ev4n)
 
         if hoist:
             self._round_reduce()
-            quotient_coset_ffts()                             # of round 4: none of the twelve inputs depends on alpha
+            self._side(quotient_coset_ffts)                   # of round 4: none of the twelve inputs depends on alpha
         out += self._round_end()                              # z, z_2 enter the transcript before alpha is drawn (prover.rs:398)
+        self._join_side()
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         if not hoist:
             c[10] = d.ifft(self.aux_evals[6])         # pi
             c[11] = d.ifft(self.aux_evals[7])         # l1
-            quotient_coset_ffts()
+            quotient_coset_ffts(d, d4)
         c[12] = d.ifft(self.aux_evals[8])         # l1 * alpha^2
         d4._run(2, c[12], out=self.ev4n)
         quot = self.quot

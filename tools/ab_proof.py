@@ -28,7 +28,12 @@ def main():
     from ark_plonk_amd.prover_schedule import ProofSchedule
     from bench import build_srs
 
-    cfgs = [dict(kv.split("=", 1) for kv in c.split()) for c in args.configs]
+    # VAR=VALUE: an environment hook of the library; SCHED.name=value: a keyword of ProofSchedule (one schedule object per distinct set)
+    def conv(v):
+        return {"True": True, "False": False}.get(v, int(v) if v.lstrip("-").isdigit() else v)
+    raw = [dict(kv.split("=", 1) for kv in c.split()) for c in args.configs]
+    cfgs = [{k: v for k, v in c.items() if not k.startswith("SCHED.")} for c in raw]
+    sched_kw = [tuple(sorted((k[6:], conv(v)) for k, v in c.items() if k.startswith("SCHED."))) for c in raw]
     keys = sorted({k for c in cfgs for k in c})
     ctx = zk.Context(0)
     ctx.use_torch_stream()
@@ -38,7 +43,7 @@ def main():
     ck = zk.CommitterKey(srs, cv, ctx)
     del srs
     ck.precompute(0)
-    sched = ProofSchedule(args.log_n, ctx, ck, cv, defer_calls=not args.block_every_call)
+    scheds = {kw: ProofSchedule(args.log_n, ctx, ck, cv, defer_calls=not args.block_every_call, **dict(kw)) for kw in set(sched_kw)}
 
     def use(c):
         for k in keys:
@@ -47,8 +52,9 @@ def main():
 
     import hashlib
     digs = []
-    for c in cfgs:
+    for c, kw in zip(cfgs, sched_kw):
         use(c)
+        sched = scheds[kw]
         pts = sched.run_once(proof_id=0)
         digs.append(hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in pts)).hexdigest()[:12])
         sched.run_once()
@@ -57,6 +63,7 @@ def main():
     for _ in range(args.pairs):
         for i, c in enumerate(cfgs):
             use(c)
+            sched = scheds[sched_kw[i]]
             sched.run_once()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

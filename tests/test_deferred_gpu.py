@@ -223,3 +223,30 @@ def test_schedule_with_hoisted_transforms_gives_the_same_commitments(ctx):
     b = ProofSchedule(log_n, ctx, ck, cv, hoist=False).run_once(0)
     c = ProofSchedule(log_n, ctx, ck, cv, defer_calls=False).run_once(0)
     assert a == b == c and len(a) == 29
+
+
+@pytest.mark.parametrize("merge,long_rounds", [("0", None), ("1", "1"), ("1", "3")])
+def test_round_launch_shapes_give_the_same_points(ctx, monkeypatch, merge, long_rounds):
+    """The tuning hooks the in-process A/B uses (tools/ab_proof.py) select how a round's work is launched: one sort + one accumulation
+    launch per job at submission (ZK_MSM_MERGE=0, the shape before round 4), or one launch per kernel for the whole round with long
+    chunks for all jobs but the last (default) or round 3's chunk length inside the merged launch (ZK_LONG_ROUNDS=3).  Same points
+    from every shape, for jobs of different lengths (2^17 + 2^15 points: several rounds of lanes), through begin / reduce / end."""
+    cv = zk.get_curve(0)
+    n = (1 << 17) + (1 << 15)
+    ck = _ck(ctx, cv, n, seed=77).precompute()
+    polys = _polys(n, 5, 78)
+    polys[1] = polys[1][: n - 1]
+    polys[3] = polys[3][: 1 << 13]
+    monkeypatch.delenv("ZK_MSM_MERGE", raising=False)
+    monkeypatch.delenv("ZK_LONG_ROUNDS", raising=False)
+    want = ck.commit_batch(polys)
+    monkeypatch.setenv("ZK_MSM_MERGE", merge)
+    if long_rounds is not None:
+        monkeypatch.setenv("ZK_LONG_ROUNDS", long_rounds)
+    assert ck.commit_batch(polys) == want
+    ck.commit_begin(polys[:2])
+    ck.commit_begin(polys[2:3])
+    ck.commit_begin(polys[3:])
+    ck.round_reduce()
+    assert ck.round_end(5) == want
+    ck.close()

@@ -2173,8 +2173,12 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
                 const char* le = getenv("ZK_LONG_ROUNDS");
                 const uint32_t long_rounds = le ? (uint32_t)atoi(le) : 1u;
                 const uint32_t lr = long_rounds < 1 ? 1u : long_rounds > rounds ? rounds : long_rounds;
-                pl.n_lanes = lr * ROUND;
-                pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
+                // never more lanes than the plan the buffers were sized for (part_pt holds two partials per lane of max_lanes):
+                // where the whole-round rounding above was refused (chunks below 16), lr rounds of lanes can exceed it
+                if ((uint64_t)lr * ROUND <= max_lanes) {
+                    pl.n_lanes = lr * ROUND;
+                    pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
+                }
             }
         }
     }

@@ -428,3 +428,41 @@ def test_repeated_and_opposite_points_take_the_general_law(cid, table, ctx, orac
     exp_xy, exp_inf = oracle_cpu.msm_g1(cid, bases_h, scal3)
     assert_point(ck.msm(torch.from_numpy(scal3.view(np.int64)).cuda()), exp_xy, exp_inf, cid)
     ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_table_path_irregular_sizes_across_the_lane_rounding_rules(cid, ctx, oracle_cpu):
+    """Lengths that are not powers of two, on both sides of every threshold of the accumulation's lane plan (msm.hip: pre_plan) --
+    one round of resident lanes (131072) exceeded or not, whole-round rounding taken or refused (chunks below 16), two rounds
+    becoming three, the 16-bit -> 17-bit table window at 2^19 points -- as single MSMs and as round batches (in which every job but
+    the last takes the long-chunk plan), odd and even, against the C++ restatement's KZG commitment limb for limb."""
+    import torch
+    cv = bo.CURVES[cid]
+    n_max = 786433
+    g = torch.Generator(device="cuda").manual_seed(4242 + cid)
+    ks = torch.randint(1, 1 << 62, (n_max, 4), dtype=torch.int64, device="cuda", generator=g)
+    ks[:, 1:] = 0
+    bases = torch.empty((n_max, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cid, ks.data_ptr(), n_max, bases.data_ptr()))
+    bases_h = bases.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(99 + cid)
+    for n_srs in (262145, n_max):                          # a 16-bit table (below 2^19 points) and a 17-bit one
+        ck = zk.CommitterKey(bases[:n_srs].contiguous(), cid, ctx).precompute()
+        sizes = [s for s in (131071, 131073, 140001, 163839, 163840, 196609, 262143, 262145, 327681, 524287, 524289, 700001, n_max) if s <= n_srs]
+        polys, want = [], []
+        for n in sizes:
+            p = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+            p[:, 3] >>= 3                                  # Montgomery residues below both moduli
+            polys.append(torch.from_numpy(p.view(np.int64)).cuda())
+            want.append(oracle_cpu.kzg_commit(cid, bases_h[:n_srs], p))
+        for p, (exp_xy, exp_inf) in zip(polys, want):      # single MSMs: the default plan
+            assert_point(ck.commit(p), exp_xy, exp_inf, cid)
+        for lo in range(0, len(polys), 5):                 # round batches: long-chunk plans for all but the last job
+            got = ck.commit_batch(polys[lo:lo + 5])
+            for pt, (exp_xy, exp_inf) in zip(got, want[lo:lo + 5]):
+                assert_point(pt, exp_xy, exp_inf, cid)
+        got = ck.commit_batch(polys[::-1][:6])             # ... and in another order (another job is last)
+        for pt, (exp_xy, exp_inf) in zip(got, want[::-1][:6]):
+            assert_point(pt, exp_xy, exp_inf, cid)
+        ck.close()

@@ -1,6 +1,9 @@
-"""Per-rank compute time of the point-sharded schedule, measured on ONE GPU: runs rank 0 of a world
+"""Per-rank compute time of the sharded schedule, measured on ONE GPU: runs rank 0 of a world
 of W with a stand-in for torch.distributed whose all_gather returns W copies of the local tensor.
-No communication is timed -- this shows where a rank's time goes (NTT replica, MSM shard, reductions).
+No communication is timed -- this shows where a rank's time goes (NTT replica, MSM shard, reductions) for both shard axes
+(points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and both forms of the
+exchange (device-resident partials: zk_kzg_round_end_partial_dev + zk_g1_sum_partials_dev; host Jacobian partials: round 3's).
+AN ESTIMATE, NOT A MEASUREMENT of N GPUs.
 
 usage: python tools/sim_rank.py [W ...]
 """
@@ -29,6 +32,9 @@ class FakeDist:
         for o in outs:
             o.copy_(t)
 
+    def all_gather_into_tensor(self, out, t):
+        out.view(self.world, -1).copy_(t.unsqueeze(0).expand(self.world, -1))
+
 
 def main():
     worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
@@ -39,25 +45,35 @@ def main():
     ctx.use_torch_stream()
     cv = zk.get_curve("bls12_381")
     for w in worlds:
-        srs = build_srs(ctx, cv, n, 0, n // w, torch)
-        ck = zk.CommitterKey(srs, cv, ctx).precompute()
-        del srs
-        sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None)
-        sched.run_once()
-        torch.cuda.synchronize()
-        ctx.profile(True)
-        ctx.profile_reset()
-        steps = 3
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sched.run_once()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps * 1e3
-        ctx.profile(False)
-        parts = {k: ctx.profile_get(k)[0] / steps for k in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt_pass", "fr_convert", "kzg_open_prep")}
-        print(f"world={w}: {dt:.2f} ms/step  " + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
-        ck.close()
-        del sched
+        for axis in ("points", "windows"):
+            if w == 1 and axis == "windows":
+                continue
+            for on_device in ((True,) if w == 1 else (True, False)):
+                if axis == "points":
+                    srs = build_srs(ctx, cv, n, 0, n // w, torch)
+                    ck = zk.CommitterKey(srs, cv, ctx).precompute()
+                else:
+                    srs = build_srs(ctx, cv, n, 0, n, torch)
+                    ck = zk.CommitterKey(srs, cv, ctx).precompute(rows=(0, w))
+                del srs
+                sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None, shard_axis=axis,
+                                      partials_on_device=on_device)
+                sched.run_once()
+                torch.cuda.synchronize()
+                ctx.profile(True)
+                ctx.profile_reset()
+                steps = 3
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    sched.run_once()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps * 1e3
+                ctx.profile(False)
+                parts = {k: ctx.profile_get(k)[0] / steps for k in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt_pass", "kzg_open_prep")}
+                form = "-" if w == 1 else ("device partials" if on_device else "host partials")
+                print(f"world={w} axis={axis:7s} exchange={form:15s}: {dt:6.2f} ms/step  " + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
+                ck.close()
+                del sched
 
 
 if __name__ == "__main__":

@@ -340,6 +340,90 @@ def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, on_device, mo
     ck_shard.close()
 
 
+def _worker_rccl_world1(port, q):
+    """One rank, backend "nccl" (= RCCL on ROCm): the schedule's five exchanges go through a REAL RCCL all_gather of the buffer the
+    library wrote (world 1 is all one card allows: RCCL refuses two ranks on one device).  The schedule is told world = 2; the shim
+    hands RCCL's output to both rows, i.e. a second rank that owns the same shard."""
+    import sys
+    sys.path.insert(0, ROOT)
+    try:
+        import torch
+        import torch.distributed as dist
+        import ark_plonk_amd as zk
+        from ark_plonk_amd import _lib
+        from ark_plonk_amd.prover_schedule import ProofSchedule
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+        class TwoRowsOverRccl:
+            calls = []
+
+            @staticmethod
+            def get_backend():
+                return dist.get_backend()
+
+            @classmethod
+            def all_gather_into_tensor(cls, out, inp):
+                got = torch.empty_like(inp)
+                dist.all_gather_into_tensor(got, inp)             # RCCL, on its own stream, ordered after torch's current stream
+                cls.calls.append((inp.data_ptr(), inp.numel(), str(inp.device)))
+                out.view(2, -1).copy_(got.unsqueeze(0).expand(2, -1))
+
+        cv = zk.get_curve(0)
+        ctx = zk.Context(0)
+        log_n = 13
+        n = 1 << log_n
+        g = torch.Generator(device="cuda").manual_seed(9)
+        ks = torch.randint(1, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        ks[:, 1:] = 0
+        bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+        ctx.use_torch_stream()
+        _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
+        ck = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()
+        res = {}
+        for on_device in (True, False):
+            TwoRowsOverRccl.calls = []
+            sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=2, dist=TwoRowsOverRccl, partials_on_device=on_device)
+            out = sched.run_once(proof_id=0)
+            two = zk.msm.sum_partials(np.stack([ck.commit_batch_partial([sched.coef[0][: n // 2]])[0]] * 2), 0)
+            res[on_device] = dict(n=len(out), collectives=sched.collectives, calls=len(TwoRowsOverRccl.calls),
+                                  devices=sorted({c[2] for c in TwoRowsOverRccl.calls}), first_ok=(out[0] == two),
+                                  from_pbuf=all(c[0] == sched._pbuf.data_ptr() for c in TwoRowsOverRccl.calls) if on_device else None,
+                                  points=[(pt.infinity, [int(v) for v in pt.x], [int(v) for v in pt.y]) for pt in out])
+        ck.close()
+        ctx.close()
+        dist.destroy_process_group()
+        q.put(("ok", res[True], res[False]))
+    except BaseException as e:      # the parent reports it
+        import traceback
+        q.put(("error", repr(e), traceback.format_exc()[-3000:]))
+
+
+@pytest.mark.gpu
+def test_schedule_exchange_over_real_rccl_world1():
+    """The exchange step with RCCL itself in the loop: backend "nccl", one rank on this box's card.  Both forms of the partials (left
+    on the device / read back and re-uploaded) give the same 29 points, five collectives each, every tensor RCCL is handed lives on
+    cuda:0, and in the device form it is the library's own buffer."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_worker_rccl_world1, args=(_free_port(), q))
+    p.start()
+    try:
+        got = q.get(timeout=420)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert got[0] == "ok", got[1:]
+    dev, host = got[1], got[2]
+    for r in (dev, host):
+        assert r["n"] == 29 and r["collectives"] == 5 and r["calls"] == 5 and r["devices"] == ["cuda:0"] and r["first_ok"]
+    assert dev["from_pbuf"] is True
+    assert dev["points"] == host["points"]
+
+
 @pytest.mark.gpu
 def test_device_partials_with_short_and_empty_jobs(ctx):
     """The device form of a round's partials with every kind of job: table path, a vector too short for it (computed at begin,

@@ -39,3 +39,13 @@ def test_msm_kernels_registers_and_spills():
     for name in ("psort_scan", "psortw_scatter", "psortw_final", "psort_scatter", "psort_final"):
         k = find(f"{len(name)}{name}E")                     # Itanium mangling: <length><name>E inside the anonymous namespace
         assert k["VGPRs Spill"] == 0 and k["ScratchSize"] == 0, (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+@pytest.mark.parametrize("tool", ["affine_probe.hip", "energy_probe.hip"])
+def test_measurement_tools_still_build(tool, tmp_path):
+    """The standalone probes behind profiles/r04_notes.md (they include the library's field / group-law headers) compile for gfx950."""
+    out = tmp_path / tool.replace(".hip", "")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "ark_plonk_amd", "csrc"), os.path.join(ROOT, "tools", tool),
+                        "-o", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and out.exists(), r.stderr[-2000:]

@@ -35,3 +35,7 @@ def test_stress_rounds_short(ctx, oracle_cpu):
 
 def test_stress_prover_short(ctx, oracle_cpu):
     assert _load("stress_prover").run(budget=12.0, seed=50, ctx=ctx, max_log_n=9) >= 5
+
+
+def test_stress_shards_short(ctx, oracle_cpu):
+    assert _load("stress_shards").run(budget=20.0, seed=60, ctx=ctx, max_log_n=15) >= 4

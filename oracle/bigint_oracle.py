@@ -35,6 +35,8 @@ What is restated, and the reference call site each function stands behind:
 External anchors used to pin constants (tests/test_oracle.py):
   * TWO_ADIC_ROOT_OF_UNITY of ark-bls12-381 Fr (decimal constant quoted in SURVEY.md 8a).
   * [2]G1 x-coordinate of BLS12-381 (the published compressed encoding a572cbea...f0f4e).
+  * tests/published_points.py: EIP-2537's G1 + G1, EIP-196's [2] / [3] / [9] (1, 2) and "chfast1" scalar multiplication on
+    alt_bn128, c-kzg-4844's SCALE2_ROOT_OF_UNITY[2..4], circom's 2^28-th root of unity of BN254's scalar field.
 """
 from __future__ import annotations
 

@@ -18,6 +18,43 @@ def assert_point(got, exp_xy, exp_inf, cid, tag=""):
     assert np.array_equal(got.x, exp_xy[:L]) and np.array_equal(got.y, exp_xy[L:]), tag
 
 
+@pytest.mark.parametrize("window", [0, 2, 16])
+def test_published_points(window, ctx):
+    """The device against points published elsewhere (not computed by this repository's oracle): EIP-2537's G1 + G1 on BLS12-381,
+    EIP-196's [2](1, 2) and [3](1, 2) on alt_bn128 -- as 1*G + 1*G (the doubling branch), 2*G, and 1*G + 2*G / 3*G."""
+    from published_points import EXT_BLS_2G, EXT_BN254_2G, EXT_BN254_3G, EXT_BN254_9G, EXT_BN254_MUL
+
+    def limbs(cv, pt):
+        R = 1 << (64 * cv.fq_limbs)
+        return np.array(bo.int_to_limbs(bo.to_mont(pt[0], cv.q, R), cv.fq_limbs) + bo.int_to_limbs(bo.to_mont(pt[1], cv.q, R), cv.fq_limbs),
+                        dtype=np.uint64)
+
+    def scal(vals):
+        out = np.zeros((len(vals), 4), dtype=np.uint64)
+        out[:, 0] = vals
+        return out
+
+    ctx.set_msm_window(window)
+    try:
+        for cid, want2, want3 in ((0, EXT_BLS_2G, None), (1, EXT_BN254_2G, EXT_BN254_3G)):
+            cv = bo.CURVES[cid]
+            g = limbs(cv, (cv.gx, cv.gy))
+            for bases, ks, want in ((np.stack([g, g]), [1, 1], want2), (g.reshape(1, -1), [2], want2),
+                                    (np.stack([g, g]), [1, 2], want3), (g.reshape(1, -1), [3], want3)):
+                if want is None:
+                    continue
+                got = zk.VariableBaseMSM.multi_scalar_mul(bases, scal(ks), cid, ctx=ctx)
+                assert_point(got, limbs(cv, want), 0, cid, f"curve {cid} scalars {ks} c={window}")
+        bn = bo.CURVES[1]
+        g = limbs(bn, (bn.gx, bn.gy))
+        assert_point(zk.VariableBaseMSM.multi_scalar_mul(g.reshape(1, -1), scal([9]), 1, ctx=ctx), limbs(bn, EXT_BN254_9G), 0, 1, "9 G")
+        assert_point(zk.VariableBaseMSM.multi_scalar_mul(np.stack([g] * 9), scal([1] * 9), 1, ctx=ctx), limbs(bn, EXT_BN254_9G), 0, 1, "G x 9")
+        pt = limbs(bn, EXT_BN254_MUL["point"]).reshape(1, -1)
+        assert_point(zk.VariableBaseMSM.multi_scalar_mul(pt, scal([EXT_BN254_MUL["scalar"]]), 1, ctx=ctx), limbs(bn, EXT_BN254_MUL["result"]), 0, 1, "chfast1")
+    finally:
+        ctx.set_msm_window(0)
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 @pytest.mark.parametrize("window", [0, 3, 5, 8, 13])
 def test_golden_srs(cid, window, golden, ctx):

@@ -15,6 +15,23 @@ def run_kind(dom, kind, x):
     return getattr(dom, KINDS[kind])(x)
 
 
+def test_published_roots_of_unity(ctx, oracle_cpu):
+    """The device transform (and the C++ restatement) against roots of unity published elsewhere: fft of X over the 2^k-point domain
+    is (1, w, w^2, ...), so output 1 is the domain's generator -- c-kzg-4844's SCALE2_ROOT_OF_UNITY[k] on BLS12-381 (k = 2, 3, 4),
+    circom's 2^28-th root raised to 2^(28-k) on BN254."""
+    from published_points import EXT_BLS_FR_ROOTS, EXT_BN254_FR_ROOT_28
+    for cid in (0, 1):
+        cv = bo.CURVES[cid]
+        for k in (2, 3, 4):
+            w = EXT_BLS_FR_ROOTS[k] if cid == 0 else pow(EXT_BN254_FR_ROOT_28, 1 << (28 - k), cv.r)
+            x = np.zeros((1 << k, 4), dtype=np.uint64)
+            x[1] = bo.int_to_limbs(bo.to_mont(1, cv.r, 1 << 256), 4)
+            want = [bo.int_to_limbs(bo.to_mont(pow(w, i, cv.r), cv.r, 1 << 256), 4) for i in range(1 << k)]
+            got = zk.Radix2EvaluationDomain.new(1 << k, cid, ctx).fft(x)
+            assert np.array_equal(got, np.array(want, dtype=np.uint64)), (cid, k)
+            assert np.array_equal(oracle_cpu.ntt(cid, 0, k, x), np.array(want, dtype=np.uint64)), (cid, k)
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_golden_vectors(cid, golden, ctx):
     g = golden[cid]

@@ -10,6 +10,10 @@ from oracle import bigint_oracle as bo
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+from published_points import (EXT_BLS_2G, EXT_BN254_2G, EXT_BN254_3G, EXT_BN254_9G, EXT_BN254_MUL, EXT_BLS_FR_ROOTS,  # noqa: E402
+                              EXT_BN254_FR_ROOT_28)
+
+
 def test_external_constants():
     cv = bo.BLS12_381
     # ark-bls12-381 0.3 Fr::TWO_ADIC_ROOT_OF_UNITY (decimal)
@@ -17,7 +21,17 @@ def test_external_constants():
     # [2]G1 of BLS12-381: x-coordinate of the published compressed encoding a572cbea...f0f4e
     g2 = bo.ec_add(cv, (cv.gx, cv.gy), (cv.gx, cv.gy))
     assert g2[0] == 0x0572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e
+    assert g2[1] == 0x166a9d8cabc673a322fda673779d8e3822ba3ecb8670e461f73bb9021d5fd76a4c56d9d4cd16bd1bba86881979749d28      # EIP-2537's G1 + G1 vector
     assert bo.on_curve(cv, g2)
+    # alt_bn128 (BN254): the points every EIP-196 ecAdd / ecMul test uses, [2](1, 2) and [3](1, 2); circom's 2^28-th root of unity
+    bn = bo.BN254
+    h2 = bo.ec_add(bn, (bn.gx, bn.gy), (bn.gx, bn.gy))
+    assert h2 == EXT_BN254_2G and bo.ec_add(bn, h2, (bn.gx, bn.gy)) == EXT_BN254_3G
+    assert bn.root_of_unity(28) == EXT_BN254_FR_ROOT_28
+    for k, w in EXT_BLS_FR_ROOTS.items():
+        assert cv.root_of_unity(k) == w
+    assert bo.ec_mul(bn, 9, (bn.gx, bn.gy)) == EXT_BN254_9G
+    assert bo.on_curve(bn, EXT_BN254_MUL["point"]) and bo.ec_mul(bn, EXT_BN254_MUL["scalar"], EXT_BN254_MUL["point"]) == EXT_BN254_MUL["result"]
     # Montgomery R of Fr
     assert (1 << 256) % cv.r == 0x1824b159acc5056f998c4fefecbc4ff55884b7fa0003480200000001fffffffe
     for c in (bo.BLS12_381, bo.BN254):
@@ -259,3 +273,27 @@ def test_oracle_prover_and_oracle_verifier_agree(cid):
             for k in ("a_comm", "z_2_comm", "t_4_comm"):
                 assert pr["commitments"][k] == bo.ec_mul(cv, dlog[k], (cv.gx, cv.gy))
             assert pr["aw_opening"] == bo.ec_mul(cv, dlog["aw_opening"], (cv.gx, cv.gy))
+
+
+def test_cpu_restatement_against_published_points(oracle_cpu):
+    """The C++ restatement (the checker of every -m gpu test) against points this repository did not compute: EIP-2537's G1 + G1,
+    EIP-196's [2], [3], [9] (1, 2) and its "chfast1" scalar multiplication."""
+    def limbs(cv, pt):
+        R = 1 << (64 * cv.fq_limbs)
+        return np.array(bo.int_to_limbs(bo.to_mont(pt[0], cv.q, R), cv.fq_limbs) + bo.int_to_limbs(bo.to_mont(pt[1], cv.q, R), cv.fq_limbs),
+                        dtype=np.uint64)
+
+    def msm(cid, pts, ks):
+        cv = bo.CURVES[cid]
+        sc = np.zeros((len(ks), 4), dtype=np.uint64)
+        sc[:, 0] = ks
+        out, inf = oracle_cpu.msm_g1(cid, np.stack([limbs(cv, p) for p in pts]), sc)
+        assert not inf
+        return out
+
+    bls, bn = bo.BLS12_381, bo.BN254
+    g, h = (bls.gx, bls.gy), (bn.gx, bn.gy)
+    assert np.array_equal(msm(0, [g, g], [1, 1]), limbs(bls, EXT_BLS_2G)) and np.array_equal(msm(0, [g], [2]), limbs(bls, EXT_BLS_2G))
+    assert np.array_equal(msm(1, [h, h], [1, 1]), limbs(bn, EXT_BN254_2G)) and np.array_equal(msm(1, [h, h], [1, 2]), limbs(bn, EXT_BN254_3G))
+    assert np.array_equal(msm(1, [h], [9]), limbs(bn, EXT_BN254_9G))
+    assert np.array_equal(msm(1, [EXT_BN254_MUL["point"]], [EXT_BN254_MUL["scalar"]]), limbs(bn, EXT_BN254_MUL["result"]))

@@ -114,17 +114,23 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
         s_msm -= 1
     s_ntt = log_n
     x = rng.integers(0, 1 << 62, size=(1 << s_ntt, 4), dtype=np.uint64)
-    t0 = time.perf_counter()
-    cpu.ntt(cid, 1, s_ntt, x)
-    t_ntt_n = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    cpu.ntt(cid, 2, s_ntt + 2, x)
-    t_ntt_4n = time.perf_counter() - t0
+
+    def best_of(reps, fn):
+        """the CPU side gets its best run: the box's host cores are shared with other jobs of the pool (0.09 - 0.27 s for the same 2^20
+        ifft from session to session), and a first run also pays the page faults of its output vector"""
+        best, res = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, res
+
+    t_ntt_n, _ = best_of(3, lambda: cpu.ntt(cid, 1, s_ntt, x))
+    t_ntt_4n, _ = best_of(3, lambda: cpu.ntt(cid, 2, s_ntt + 2, x))
     bases = np.tile(srs_s, ((1 << s_msm) >> 10, 1))
     sc = rng.integers(0, 1 << 62, size=(1 << s_msm, 4), dtype=np.uint64)
-    t0 = time.perf_counter()
-    ref_xy, ref_inf = cpu.msm_g1(cid, bases, sc, threads=cores)
-    t_msm = time.perf_counter() - t0
+    t_msm, (ref_xy, ref_inf) = best_of(2, lambda: cpu.msm_g1(cid, bases, sc, threads=cores))
     # all-cores shape: (window, point range) tasks, each with its own buckets, so that every core of the host is busy -- not what
     # ark 0.3 does (threads over the windows only), reported next to it
     t_all, parts = None, 0
@@ -144,7 +150,7 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
         "value": 1.0 / t_proof, "unit": "proofs/s", "cores": cores, "kind": "port",
         "sample": f"oracle/ark_cpu.cpp (OpenMP, {cores} threads) at the benchmark sizes: ifft 2^{s_ntt} {t_ntt_n:.3f}s, coset_fft 2^{s_ntt + 2} "
                   f"{t_ntt_4n:.3f}s, MSM 2^{s_msm} {t_msm:.3f}s (threads over windows as ark/rayon"
-                  + ("" if s_msm == log_n else f"; scaled x{scale:.2f} to 2^{log_n} by G1-add count") + "); x 17 / 14 / 29 per proof",
+                  + ("" if s_msm == log_n else f"; scaled x{scale:.2f} to 2^{log_n} by G1-add count") + "); best of 3 / 3 / 2 runs; x 17 / 14 / 29 per proof",
         "note": "a restatement of the ark 0.3 algorithms in portable C++ (4 / 6 x 64-bit CIOS Montgomery with unsigned __int128, no assembly): "
                 "the transforms run the reference's butterflies cache-blocked (the same values, ~3 instead of log2 n passes over memory); "
                 "the MSM keeps ark's own parallel shape (threads over the windows only -- at most 17 busy at 2^20 points), which is what "

@@ -142,3 +142,21 @@ def test_cpp_host_header_compiles():
     src = '#include "host/ark_plonk_amd.hpp"\nint main() { return sizeof(zk::G1Affine) > 0 ? 0 : 1; }\n'
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++", "-"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_null_handles_are_refused_by_every_entry_point():
+    """Never `abort` / fault across the boundary (SURVEY.md 8b "Errors"): each of the ABI's functions that takes a ctx, an SRS or a
+    transcript handle first returns a negative code when that handle is NULL and every other argument is zero -- in a child process,
+    so a fault would fail this test with the function's name instead of ending the run."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_null_probe.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"crashed in {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else '?'} (exit {r.returncode})"
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res) >= 70
+    empty_is_ok = {"zk_g1_sum_partials_dev"}              # n_jobs = 0: nothing to do, documented as ZK_OK
+    for name, rc in res.items():
+        assert rc < 0 or name in empty_is_ok, (name, rc)
+        if name not in empty_is_ok:
+            assert rc == _lib.ZK_ERR_BAD_ARG, (name, rc)

@@ -73,7 +73,7 @@ class ProofSchedule:
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
                  ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
-                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True):
+                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True, split_rounds: int = 0):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -108,6 +108,12 @@ class ProofSchedule:
         # so that they run WHILE the round's memory-bound sort passes and latency-bound reductions occupy the first one instead of
         # behind them; joined before their results are used (`_join_side`).  Same transforms, same results.
         self.side_stream = hoist == "stream" and world == 1
+        # split_rounds = m > 1 (an experiment, off by default; profiles/r04_notes.md): every m-th job of a round (jobs 0, m, 2m, ...) is
+        # queued on this ctx, the others on a second ctx of the same GPU driving a second stream, so that the short group's
+        # accumulation runs while the long group is still being sorted and its reductions while the long group accumulates.  Same
+        # calls, same SRS handle (CommitterKey.with_ctx), same points.
+        self.split_rounds = int(split_rounds) if (int(split_rounds) > 1 and world == 1 and defer_calls and not (self.dedup or self.dedup_abi)) else 0
+        self._order = []            # split_rounds: "a" | "b" per queued job of the open round, in call order
         self._pending = []          # per open call: ("q", n_jobs) queued in the ABI's round | ("r", [points]) already computed
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
@@ -136,10 +142,13 @@ class ProofSchedule:
         self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
         dev = torch.device("cuda", ctx.device)
         self._side_done = []
-        if self.side_stream:
+        if self.side_stream or self.split_rounds:
             from .context import Context
             self.ctx2 = Context(ctx.device)
             self.side = torch.cuda.Stream(device=dev)
+        if self.split_rounds:
+            self.ck2 = ck.with_ctx(self.ctx2)
+        if self.side_stream:
             self.dom_n2 = Radix2EvaluationDomain.new(self.n, curve, self.ctx2)
             self.dom_4n2 = Radix2EvaluationDomain.new(4 * self.n, curve, self.ctx2)
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -250,6 +259,11 @@ class ProofSchedule:
             self._pending.append(("r", self._commit_now(polys, canonical, labels)))
             return
         self.msms_run += len(polys)
+        if self.split_rounds:
+            for p, kd in zip(polys, canonical or [False] * len(polys)):
+                self._on_group(lambda k, p=p, kd=kd: k.commit_begin([p], canonical=[kd]))
+                self._pending.append(("q", 1))
+            return
         if self.world == 1:
             self.ck.commit_begin(polys, canonical=canonical)
         else:
@@ -272,8 +286,26 @@ class ProofSchedule:
             self._round_begin([w], canonical=[True], labels=[label])
             return
         self.msms_run += 1
-        self.ck.open_begin(polys, self.z_mont, self.chi_mont)
+        if self.split_rounds:
+            self._on_group(lambda k: k.open_begin(polys, self.z_mont, self.chi_mont))
+        else:
+            self.ck.open_begin(polys, self.z_mont, self.chi_mont)
         self._pending.append(("q", 1))
+
+    def _on_group(self, fn):
+        """split_rounds: queue one job of the open round on this ctx (every m-th job) or on the second ctx / stream (the others; the
+        second stream first waits for what the main stream has queued so far -- the job's input)."""
+        which = "a" if len(self._order) % self.split_rounds == 0 else "b"
+        self._order.append(which)
+        if which == "a":
+            fn(self.ck)
+            return
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            fn(self.ck2)
 
     def _hoisting(self):
         return self.hoist and not self._immediate()
@@ -304,6 +336,13 @@ class ProofSchedule:
 
     def _round_reduce(self):
         """Queue the open round's reductions now; what is launched until `_round_end` runs behind them, under the host's part."""
+        if self.split_rounds and self._order:
+            if "a" in self._order:
+                self.ck.round_reduce()
+            if "b" in self._order:
+                with self.torch.cuda.stream(self.side):
+                    self.ck2.round_reduce()
+            return
         if not self._immediate() and any(kind == "q" for kind, _ in self._pending):
             if self.world > 1 and self.partials_on_device:
                 self.ck.round_reduce_partial_dev(self._pbuf)
@@ -315,7 +354,16 @@ class ProofSchedule:
         pend, self._pending = self._pending, []
         nq = sum(n for kind, n in pend if kind == "q")
         got = []
-        if self.world == 1:
+        if self.split_rounds and self._order:
+            order, self._order = self._order, []
+            ga = self.ck.round_end(order.count("a")) if "a" in order else []
+            gb = []
+            if "b" in order:
+                with self.torch.cuda.stream(self.side):
+                    gb = self.ck2.round_end(order.count("b"))
+            ia, ib = iter(ga), iter(gb)
+            got = [next(ia) if w == "a" else next(ib) for w in order]
+        elif self.world == 1:
             if nq:
                 got = self.ck.round_end(nq)
         elif any(kind != "r" for kind, _ in pend) and self.partials_on_device:
@@ -420,11 +468,13 @@ class ProofSchedule:
             return self._run_once(proof_id)
         except BaseException:
             self._pending = []
-            try:
-                if self.ck.round_pending():
-                    self.ck.round_abort()
-            except Exception:
-                pass
+            self._order = []
+            for k in [self.ck] + ([self.ck2] if self.split_rounds else []):
+                try:
+                    if k.round_pending():
+                        k.round_abort()
+                except Exception:
+                    pass
             raise
 
     def _run_once(self, proof_id=None):

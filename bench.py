@@ -632,19 +632,21 @@ def main():
     # the second kernel family north_star names: the NTT passes, against the same HBM roofline (2 * 32 * N bytes per transform)
     if ntt_ms:
         ntt_ach = (r["ntt_bytes"] * kb) / (ntt_ms * 1e-3) / 1e9
-        ntt_traffic, ntt_src = None, None
+        ntt_traffic, ntt_src, ntt_issue = None, None, None
         ntt_pmc = os.path.join(ROOT, "profiles", "pmc_ntt.json")
         if os.path.exists(ntt_pmc) and not main_sharded and log_n == 20 and cv.curve_id == 0:
             try:
                 pm = json.load(open(ntt_pmc))
                 ntt_traffic = pm.get("hbm_bytes_per_proof")
                 ntt_src = {"file": "profiles/pmc_ntt.json", "collected": pm.get("collected"), "commit": pm.get("commit")}
+                ntt_issue = pm.get("issue")      # SQ counters of the same session: what really bounds the passes (vector issue)
             except Exception:
                 ntt_traffic = None
         line["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_mid<S> / ntt_pass_final<S>: every pass of the 31 transforms of a proof (17 of 2^%d, 14 of 2^%d)" % (log_n, log_n + 2),
                                 "achieved": ntt_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_ach / HBM_PEAK_GBS,
                                 "alg_bytes_per_proof": r["ntt_bytes"], "ms_per_proof": ntt_ms / kb, "calls_timed": int(ntt_n),
                                 "traffic": ntt_traffic, "traffic_unit": "HBM bytes per proof (all NTT passes)", "traffic_source": ntt_src,
+                                "issue": ntt_issue,
                                 "timing": f"HIP events around every zk_ntt(_batch)_dev call of {kb} proofs run right after the timed region (the scopes "
                                           "of the timed region itself carry msm_accumulate only)",
                                 "note": "three passes per transform: the vector crosses HBM three times and every mid pass also reads a pass-boundary "

@@ -160,3 +160,17 @@ def test_null_handles_are_refused_by_every_entry_point():
         assert rc < 0 or name in empty_is_ok, (name, rc)
         if name not in empty_is_ok:
             assert rc == _lib.ZK_ERR_BAD_ARG, (name, rc)
+
+
+def test_committed_counter_files_name_the_current_kernel_build():
+    """bench.py quotes profiles/pmc_*.json (`roofline.traffic`, `roofline_ntt.traffic` / `.issue`): both must carry the commit of the
+    kernel sources they were collected from, and -- in a git checkout -- that commit is the last one that touched csrc/."""
+    import json
+    import subprocess
+    a = json.load(open(os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")))
+    n = json.load(open(os.path.join(ROOT, "profiles", "pmc_ntt.json")))
+    assert a["commit"] == n["commit"] and a["hbm_bytes_per_launch"] > 0 and n["hbm_bytes_per_proof"] > n["alg_bytes_per_proof_n20"]
+    assert 0.5 < n["issue"]["valu_busy_per_simd_weighted"] < 1.2 and len(n["issue"]["kernels"]) >= 3
+    r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "ark_plonk_amd/csrc"], capture_output=True, text=True)
+    if r.returncode == 0 and r.stdout.strip():
+        assert r.stdout.strip().startswith(a["commit"]) or a["commit"].startswith(r.stdout.strip()), (a["commit"], r.stdout.strip())

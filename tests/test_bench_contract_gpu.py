@@ -47,7 +47,7 @@ def test_bench_json_contract():
     # the NTT passes against the same roofline (north_star names both kernels), the BenchCircuit-shaped data on this binary, the power leg
     rn = d["roofline_ntt"]
     assert rn["bound"] == "hbm" and rn["peak"] == 8000.0 and rn["achieved"] > 0 and abs(rn["frac"] - rn["achieved"] / rn["peak"]) < 1e-12
-    assert rn["alg_bytes_per_proof"] == 17 * 64 * (1 << 13) + 14 * 64 * (1 << 15) and "traffic" in rn
+    assert rn["alg_bytes_per_proof"] == 17 * 64 * (1 << 13) + 14 * 64 * (1 << 15) and "traffic" in rn and "issue" in rn
     bc = d["data_benchcircuit"]
     assert bc["proofs_per_s"] > 0 and len(bc["commitments_sha256"]) == 64 and bc["commitments_sha256"] != d["commitments_sha256"]
     assert "power" in d and ("socket_power_w" in d["power"] or "error" in d["power"])

@@ -28,7 +28,7 @@ done
 python3 tools/summarize_pmc.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "profiles/${tag}_pmc_hbm" "python3 $PMCB" > "$out/pmc_summary.txt"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
   --output-format csv -d "$out/pmc_sq" -o p -- python3 $PMCB > "$out/pmc_sq.log" 2>&1 || exit 1
-python3 tools/summarize_sq.py "$out/pmc_sq" "profiles/${tag}_pmc_sq.md" "python3 $PMCB" > "$out/sq_summary.txt"
+python3 tools/summarize_sq.py "$out/pmc_sq" "profiles/${tag}_pmc_sq.md" "python3 $PMCB" profiles/pmc_ntt.json "$out/trace" > "$out/sq_summary.txt"
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_clk" -o p -- python3 $PMCB > "$out/pmc_clk.log" 2>&1
 python3 tools/summarize_clock.py "$out/pmc_clk" "profiles/${tag}_pmc_clock.md" > "$out/clk_summary.txt" 2>&1
 tail -n 30 "$out/trace_summary.txt"; cat "$out/pmc_summary.txt" | head -12; head -8 "$out/sq_summary.txt"; cat "$out/clk_summary.txt" | head -12

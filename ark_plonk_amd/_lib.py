@@ -66,6 +66,8 @@ SYMBOLS = {
     "zk_ctx_use_own_stream": (c_int, [c_void_p]),
     "zk_ctx_sync": (c_int, [c_void_p]),
     "zk_ctx_set_msm_window": (c_int, [c_void_p, c_int]),
+    "zk_ctx_set_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "zk_ctx_get_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "zk_profile_enable": (c_int, [c_void_p, c_int]),
     "zk_profile_reset": (c_int, [c_void_p]),
     "zk_profile_get": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),
@@ -123,6 +125,11 @@ SYMBOLS = {
     "zk_kzg_round_reduce_partial_dev": (c_int, [c_void_p, c_void_p]),
     "zk_kzg_round_end_partial_dev": (c_int, [c_void_p, c_u32, c_void_p]),
     "zk_g1_sum_partials_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
+    "zk_winsums_dev_bytes": (c_size_t, [c_void_p, c_void_p]),
+    "zk_winsums_geometry": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
+    "zk_kzg_round_reduce_winsums_dev": (c_int, [c_void_p, c_void_p]),
+    "zk_kzg_round_end_winsums_dev": (c_int, [c_void_p, c_u32, c_void_p]),
+    "zk_g1_sum_winsums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_abort": (c_int, [c_void_p]),
     "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),

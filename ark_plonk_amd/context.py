@@ -79,6 +79,17 @@ class Context:
     def set_msm_window(self, c: int):
         check(lib().zk_ctx_set_msm_window(self.handle, int(c)), "zk_ctx_set_msm_window")
 
+    # -- tuning options of the MSM planner (zk_ctx_set_option; the ZK_* environment hooks of rounds 2-4 are gone)
+    OPTIONS = ("msm_merge", "pre_vw", "pre_logg", "chunk_l", "long_rounds", "combine_sg", "pre_max_log_n")
+
+    def set_option(self, key: str, value: int):
+        check(lib().zk_ctx_set_option(self.handle, key.encode(), int(value)), f"zk_ctx_set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = ctypes.c_int64()
+        check(lib().zk_ctx_get_option(self.handle, key.encode(), ctypes.byref(v)), f"zk_ctx_get_option({key})")
+        return v.value
+
     # -- N3: content-addressed commitment cache (prover.rs:569-607 re-commits 12 polynomials)
     def set_commit_cache(self, on: bool = True, capacity: int = 0):
         check(lib().zk_ctx_set_commit_cache(self.handle, 1 if on else 0, int(capacity)), "zk_ctx_set_commit_cache")

@@ -131,6 +131,13 @@ int ensure_pinned_small(zk_ctx* c) {
     return ZK_OK;
 }
 
+constexpr size_t PINNED_JOB_SLOT = 512;
+int ensure_pinned_jobs(zk_ctx* c) {
+    if (c->pinned_jobs) return ZK_OK;
+    if (hipHostMalloc(&c->pinned_jobs, 16 * PINNED_JOB_SLOT, hipHostMallocDefault) != hipSuccess) return ZK_ERR_OOM;
+    return ZK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -200,6 +207,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         if (c->round_ev) (void)hipEventDestroy(c->round_ev);
         if (c->pinned) (void)hipHostFree(c->pinned);
         if (c->pinned_small) (void)hipHostFree(c->pinned_small);
+        if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
         zk_io_release(c);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
@@ -234,6 +242,54 @@ int zk_ctx_set_msm_window(zk_ctx* c, int w) {
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
     c->msm_window = w;
+    return ZK_OK;
+}
+
+// Tuning options (ZkTune, ctx.h).  Refused while a round is open: a job's plan must not change between its accumulation and its reduction.
+static int* tune_field(zk_ctx* c, const char* key, int64_t* lo, int64_t* hi) {
+    struct Row {
+        const char* key;
+        int ZkTune::*field;
+        int64_t lo, hi;
+    };
+    static const Row rows[] = {
+        {"msm_merge", &ZkTune::msm_merge, 0, 1},         {"pre_vw", &ZkTune::pre_vw, 0, 512},
+        {"pre_logg", &ZkTune::pre_logg, -1, 5},          {"chunk_l", &ZkTune::chunk_l, 0, 1024},
+        {"long_rounds", &ZkTune::long_rounds, 1, 16},    {"combine_sg", &ZkTune::combine_sg, 0, 4},
+        {"pre_max_log_n", &ZkTune::pre_max_log_n, 0, 25},
+    };
+    for (const Row& r : rows)
+        if (strcmp(key, r.key) == 0) {
+            *lo = r.lo;
+            *hi = r.hi;
+            return &(c->tune.*(r.field));
+        }
+    return nullptr;
+}
+
+int zk_ctx_set_option(zk_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
+    int64_t lo = 0, hi = 0;
+    int* f = tune_field(c, key, &lo, &hi);
+    if (!f) return ZK_ERR_UNSUPPORTED;
+    if (value < lo || value > hi) return ZK_ERR_BAD_ARG;
+    if (f == &c->tune.pre_vw && value && (value < 8 || (value & (value - 1)))) return ZK_ERR_BAD_ARG;
+    if (f == &c->tune.chunk_l && value && value < 8) return ZK_ERR_BAD_ARG;
+    if (f == &c->tune.combine_sg && value == 3) return ZK_ERR_BAD_ARG;
+    if (f == &c->tune.pre_max_log_n && value && value < 13) return ZK_ERR_BAD_ARG;
+    *f = (int)value;
+    return ZK_OK;
+}
+
+int zk_ctx_get_option(zk_ctx* c, const char* key, int64_t* value) {
+    if (!c || !key || !value) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    int64_t lo = 0, hi = 0;
+    int* f = tune_field(c, key, &lo, &hi);
+    if (!f) return ZK_ERR_UNSUPPORTED;
+    *value = *f;
     return ZK_OK;
 }
 
@@ -574,7 +630,7 @@ static int msm_partial_locked(zk_ctx* c, zk_srs* s, size_t base_offset, const vo
     const void* d_bases = nullptr;
     int rc = srs_slice(s, base_offset, n, &d_bases);
     if (rc) return rc;
-    if (s->pre_W && n >= ZK_PRE_MIN_N && n <= zk_pre_max_n() && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
+    if (s->pre_W && n >= ZK_PRE_MIN_N && n <= zk_pre_max_n(c) && c->msm_window == 0) return msm_run_pre_dev(c, s, base_offset, d_scalars, n, out_xyz);
     if (s->pre_wstep > 1 && s->pre_w0 != 0) {
         // window-sharded table: what the MSM entry points of this SRS return is the rank's PARTIAL, and the ranks' partials add up, so a
         // vector that does not take the table path is computed (whole, per-window path) by the owner of window 0 only; here: infinity
@@ -679,7 +735,7 @@ static int batch_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const
     bool fused = s->pre_W != 0 && c->msm_window == 0;
     for (uint32_t k = 0; k < n_jobs; ++k) {
         if (lens[k] > s->n || (lens[k] && !d_inputs[k])) return ZK_ERR_BAD_ARG;
-        if (lens[k] < ZK_PRE_MIN_N || lens[k] > zk_pre_max_n()) fused = false;
+        if (lens[k] < ZK_PRE_MIN_N || lens[k] > zk_pre_max_n(c)) fused = false;
     }
     if (fused) {
         uint64_t tmp[16 * 18];
@@ -845,6 +901,7 @@ static void round_clear(zk_ctx* c) {
     c->pend_srs = nullptr;
     c->pend_reduced = false;
     c->pend_partials = nullptr;
+    c->pend_partial_kind = 0;
     c->round_reduced = 0;
 }
 
@@ -880,7 +937,7 @@ static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
         zk_ctx::PendingJob& pj = c->pend[slot];
         pj = zk_ctx::PendingJob();
         pj.n = lens[k];
-        if (table && lens[k] >= ZK_PRE_MIN_N && lens[k] <= zk_pre_max_n()) {
+        if (table && lens[k] >= ZK_PRE_MIN_N && lens[k] <= zk_pre_max_n(c)) {
             const uint8_t kind = kinds ? kinds[k] : 0;
             if ((rc = msm_batch_pre_begin_dev(c, s, slot, 1, d_inputs + k, lens + k, &kind, nullptr))) return rc;
             pj.queued = true;
@@ -997,67 +1054,111 @@ int zk_kzg_round_reduce(zk_ctx* c) {
 }
 
 // ---- the same round closed with its partials left ON THE DEVICE (multi-GPU exchange without a host hop)
+// Two forms.  kind 1: ONE point per job (zk_partial_dev_bytes) -- a further dependent quad launch forms sum_v S_v + B_v sum_v v T_v.
+// kind 2: the job's 2 VW virtual-window sums S_v | T_v as the last reduction kernel writes them (zk_winsums_dev_bytes: 32 KiB per job
+// at the default geometry) -- that combination is linear in them, so the ranks add them element-wise after the all-gather
+// (zk_g1_sum_winsums_dev: one throughput-shaped kernel) and the one combine per job stays on the host pool, as on a single GPU.
 size_t zk_partial_dev_bytes(int curve_id) { return msm_partial_dev_bytes(curve_id); }
 
-// ctx lock held: queues everything up to every job's partial at d_out + k * zk_partial_dev_bytes (k = submission order)
-static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out) {
-    zk_srs* s = c->pend_srs;
-    const size_t pb = msm_partial_dev_bytes(s->curve);
-    uint32_t slots[16], nq = 0;
-    size_t qlens[16];
-    void* outs[16];
-    for (uint32_t k = 0; k < c->pend_n; ++k) {
-        const zk_ctx::PendingJob& pj = c->pend[k];
-        if (pj.queued) {
-            slots[nq] = k;
-            qlens[nq] = pj.n;
-            outs[nq] = (char*)d_out + (size_t)k * pb;
-            ++nq;
-        } else if (!pj.have_xyz) {
-            return ZK_ERR_UNSUPPORTED;         // the commitment cache holds affine points only
-        }
-    }
-    if (nq) {
-        SrsRead rl(s->mu);
-        int rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens, outs);
-        if (rc) return rc;
-    }
-    // jobs computed at submission (vectors too short for the table path): their host Jacobian, converted, goes up in one small copy each
-    for (uint32_t k = 0; k < c->pend_n; ++k) {
-        const zk_ctx::PendingJob& pj = c->pend[k];
-        if (pj.queued) continue;
-        unsigned char tmp[512];
-        if (pb > sizeof tmp) return ZK_ERR_UNSUPPORTED;
-        int rc = g1_jacobian_to_partial_host(s->curve, pj.xyz, tmp);
-        if (rc) return rc;
-        ZK_HIP_TRY(hipMemcpyAsync((char*)d_out + (size_t)k * pb, tmp, pb, hipMemcpyHostToDevice, c->stream));   // pageable source: staged before the call returns
-    }
-    c->pend_reduced = true;
-    c->pend_partials = d_out;
+size_t zk_winsums_dev_bytes(zk_ctx* c, zk_srs* s) {
+    if (!c || !s) return 0;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    uint32_t vw = 0, vb = 0;
+    if (!msm_partial_dev_supported(c, s, &vw, &vb)) return 0;
+    return (size_t)2 * vw * msm_partial_dev_bytes(s->curve);
+}
+
+int zk_winsums_geometry(zk_ctx* c, zk_srs* s, uint32_t out[4]) {
+    if (!c || !s || !out) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    SrsRead rl(s->mu);
+    uint32_t vw = 0, vb = 0;
+    if (!msm_partial_dev_supported(c, s, &vw, &vb)) return ZK_ERR_UNSUPPORTED;
+    out[0] = s->pre_c;
+    out[1] = s->pre_W;
+    out[2] = vw;
+    out[3] = vb;
     return ZK_OK;
 }
 
-int zk_kzg_round_reduce_partial_dev(zk_ctx* c, void* d_out) {
+// ctx lock held: queues everything up to every job's partial at d_out + k * (bytes of the form), k = submission order.
+// Whatever makes the device forms impossible is found BEFORE anything is queued, so that ZK_ERR_UNSUPPORTED really leaves the
+// round as it was (the accumulation used to have run, with the long-chunk plan, when a c >= 18 table was refused).
+static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out, int kind) {
+    zk_srs* s = c->pend_srs;
+    const size_t pb = msm_partial_dev_bytes(s->curve);
+    if (pb > PINNED_JOB_SLOT) return ZK_ERR_UNSUPPORTED;
+    uint32_t slots[16], nq = 0;
+    size_t qlens[16];
+    void* outs[16];
+    uint32_t n_host = 0;
+    for (uint32_t k = 0; k < c->pend_n; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (!pj.queued && !pj.have_xyz) return ZK_ERR_UNSUPPORTED;         // the commitment cache holds affine points only
+        if (!pj.queued) ++n_host;
+    }
+    SrsRead rl(s->mu);
+    uint32_t vw = 0, vb = 0;
+    const bool geom = msm_partial_dev_supported(c, s, &vw, &vb);
+    const size_t jb = kind == 2 ? (size_t)2 * vw * pb : pb;                 // bytes per job in d_out
+    if (kind == 2 && !geom) return ZK_ERR_UNSUPPORTED;                      // without a table there are no virtual windows to speak of
+    for (uint32_t k = 0; k < c->pend_n; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (!pj.queued) continue;
+        if (!geom) return ZK_ERR_UNSUPPORTED;                               // tables with window_bits >= 18 finish on the host
+        slots[nq] = k;
+        qlens[nq] = pj.n;
+        outs[nq] = (char*)d_out + (size_t)k * jb;
+        ++nq;
+    }
+    int rc;
+    if (n_host && (rc = ensure_pinned_jobs(c))) return rc;
+    if (nq && (rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens, outs, kind))) return rc;
+    // jobs computed at submission (vectors too short for the table path): their host Jacobian, converted, goes up in one small copy
+    // each from a pinned slot of its own (truly asynchronous; the slot is reused by the next round of this ctx only, which begins
+    // after this one was waited for).  As window sums such a job is S_0 = the point, every other sum the point at infinity.
+    for (uint32_t k = 0; k < c->pend_n; ++k) {
+        const zk_ctx::PendingJob& pj = c->pend[k];
+        if (pj.queued) continue;
+        unsigned char* slot = (unsigned char*)c->pinned_jobs + (size_t)k * PINNED_JOB_SLOT;
+        if ((rc = g1_jacobian_to_partial_host(s->curve, pj.xyz, slot))) return rc;
+        char* dst = (char*)d_out + (size_t)k * jb;
+        if (kind == 2) ZK_HIP_TRY(hipMemsetAsync(dst, 0, jb, c->stream));
+        ZK_HIP_TRY(hipMemcpyAsync(dst, slot, pb, hipMemcpyHostToDevice, c->stream));
+    }
+    c->pend_reduced = true;
+    c->pend_partials = d_out;
+    c->pend_partial_kind = kind;
+    return ZK_OK;
+}
+
+static int round_reduce_dev_form(zk_ctx* c, void* d_out, int kind) {
     if (!c || !d_out) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (c->pend_n == 0) return ZK_OK;
-    if (c->pend_reduced) return c->pend_partials == d_out ? ZK_OK : ZK_ERR_PENDING;
-    return round_reduce_partial_dev_locked(c, d_out);
+    if (c->pend_reduced) return (c->pend_partials == d_out && c->pend_partial_kind == kind) ? ZK_OK : ZK_ERR_PENDING;
+    return round_reduce_partial_dev_locked(c, d_out, kind);
 }
 
-int zk_kzg_round_end_partial_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) {
+static int round_end_dev_form(zk_ctx* c, uint32_t n_jobs, void* d_out, int kind) {
     if (!c || (n_jobs && !d_out)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (c->pend_n != n_jobs) return ZK_ERR_BAD_ARG;           // the round stays open
     if (n_jobs == 0) return ZK_OK;
     int rc = ZK_OK;
-    if (!c->pend_reduced) rc = round_reduce_partial_dev_locked(c, d_out);
-    else if (c->pend_partials != d_out) rc = ZK_ERR_PENDING;    // reduced towards the host (zk_kzg_round_reduce) or towards another buffer
+    if (!c->pend_reduced) rc = round_reduce_partial_dev_locked(c, d_out, kind);
+    else if (c->pend_partials != d_out || c->pend_partial_kind != kind) rc = ZK_ERR_PENDING;    // reduced towards the host or another buffer / form
     if (rc == ZK_ERR_PENDING || rc == ZK_ERR_UNSUPPORTED) return rc;   // nothing was queued by this call: the round stays open for the host form
     if (rc) (void)hipStreamSynchronize(c->stream);          // as round_end_locked: kernels of the round may still read the inputs
     round_clear(c);
     return rc;
 }
+
+int zk_kzg_round_reduce_partial_dev(zk_ctx* c, void* d_out) { return round_reduce_dev_form(c, d_out, 1); }
+int zk_kzg_round_end_partial_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) { return round_end_dev_form(c, n_jobs, d_out, 1); }
+int zk_kzg_round_reduce_winsums_dev(zk_ctx* c, void* d_out) { return round_reduce_dev_form(c, d_out, 2); }
+int zk_kzg_round_end_winsums_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) { return round_end_dev_form(c, n_jobs, d_out, 2); }
 
 int zk_g1_sum_partials_dev(zk_ctx* c, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
     if (n_jobs == 0) return ZK_OK;
@@ -1066,6 +1167,16 @@ int zk_g1_sum_partials_dev(zk_ctx* c, int curve_id, const void* d_partials, size
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;               // the pinned buffer belongs to the open round
     return g1_sum_partials_dev(c, curve_id, d_partials, ranks, n_jobs, out_xy, out_inf);
+}
+
+int zk_g1_sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    if (n_jobs == 0) return ZK_OK;
+    if (!c || !s || s->device != c->device || !d_all || !out_xy || ranks == 0) return ZK_ERR_BAD_ARG;
+    if (n_jobs > 16) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
+    SrsRead rl(s->mu);
+    return g1_sum_winsums_dev(c, s, d_all, ranks, n_jobs, out_xy, out_inf);
 }
 
 int zk_kzg_round_end(zk_ctx* c, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {

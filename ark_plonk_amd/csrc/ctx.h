@@ -166,6 +166,10 @@ struct MsmBufs {
     DevBuf counts, offsets, entries, buckets, part_pt, part_key, seg, seg2, seg3, win, tmp, scalars, stage, upload;
     int stage_of_job = 0;   // table-path job living in this set: 0 none, 1 digits queued (placement + accumulation wait for the round's
                             // merged launches), 2 accumulated (reductions pending) -- msm_batch_pre_begin / _reduce
+    // the chunk plan the job's accumulation launch was sized with (pre_queue_accumulate): the reductions read the chunk-edge partials
+    // through exactly these two numbers, whatever a later pre_plan of the same job would derive (a round whose reduction
+    // was refused after the accumulation had run was re-planned with the other chunk length)
+    uint32_t acc_chunk_l = 0, acc_n_lanes = 0;
     void release() {
         DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg2, &seg3, &win, &tmp, &scalars, &stage, &upload};
         for (DevBuf* b : all) b->release();
@@ -193,8 +197,22 @@ struct NttPlan {
     }
 };
 
+// Tuning options of a ctx (zk_ctx_set_option): plain integers read by the MSM planner.  They replace the ZK_* environment hooks of
+// rounds 2-4 (getenv in a library racing a caller's setenv is undefined behaviour, and a number must not depend on ambient variables).
+// Every default is "the library decides".  A/B tools set them per ctx; results are identical for every value.
+struct ZkTune {
+    int msm_merge = 1;       // 1: one sort / accumulation launch per round for all deferred jobs; 0: per job at submission (round 3's shape)
+    int pre_vw = 0;          // virtual windows of the shared-bucket reduction (0 = default 64; a power of two 8 .. 512)
+    int pre_logg = -1;       // log2 buckets per reduction segment (-1 = default)
+    int chunk_l = 0;         // sorted references per accumulation lane (0 = planned)
+    int long_rounds = 1;     // rounds of resident lanes for a non-final job of a merged accumulation launch
+    int combine_sg = 0;      // lanes per small bucket in msm_combine when a launch has > 2 jobs (0 = default 1; 2; 4)
+    int pre_max_log_n = 0;   // vectors longer than 2^this leave the window-table path (0 = the built-in 2^26); test hook, 13 .. 25
+};
+
 struct zk_ctx {
     int device = 0;
+    ZkTune tune;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::recursive_mutex mu;
@@ -268,6 +286,8 @@ struct zk_ctx {
     uint32_t pend_n = 0;
     bool pend_reduced = false;      // zk_kzg_round_reduce ran: the round takes no further jobs, zk_kzg_round_end only waits
     void* pend_partials = nullptr;  // ... as zk_kzg_round_reduce_partial_dev: the jobs' partials are (being) written there, on the device
+    int pend_partial_kind = 0;      // 1: one point per job (zk_partial_dev_bytes); 2: the job's virtual-window sums (zk_winsums_dev_bytes)
+    void* pinned_jobs = nullptr;    // 16 x 512 B pinned: partials of jobs computed at submission, on their way to the device (async copies)
     hipEvent_t round_ev = nullptr;  // recorded behind the reduction kernels of a round (msm_batch_pre_reduce)
     uint32_t round_reduced = 0;     // jobs whose reductions are queued behind round_ev (0: none)
     zk_srs* pend_srs = nullptr;
@@ -339,24 +359,29 @@ int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const*
 // jobs in slots[0 .. n_jobs) with one launch per reduction kernel, wait once, combine on the host
 int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                             const uint8_t* kinds = nullptr, const std::function<int(uint32_t)>* before_job = nullptr);
-int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr);
+// d_partials + partial_kind 1: every job's sum as ONE point at d_partials[k]; 2: the job's 2 VW virtual-window sums there (msm_winsums_dev_bytes)
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr,
+                             int partial_kind = 1);
+// whether (and in which geometry) the device-resident forms of the exchange exist for this SRS's table: vw = virtual windows, vb = buckets
+// of each; false for tables the reduction finishes on the host side only (window_bits >= 18) or without a table
+bool msm_partial_dev_supported(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb);
 // multi-GPU exchange on the device: a partial = one point in the internal XYZZ form
 size_t msm_partial_dev_bytes(int curve);
 int g1_sum_partials_dev(zk_ctx* c, int curve, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
+// ... or the 2 VW virtual-window sums of a job (S_v | T_v), added element-wise over the ranks, combined on the host pool as the
+// single-GPU path combines them
+int g1_sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
 int g1_jacobian_to_partial_host(int curve, const uint64_t* xyz, void* out);
 int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,
                           uint64_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 int fr_convert_stream(zk_ctx* c, int curve, const void* d_in, size_t n, void* d_out, hipStream_t st);
 constexpr size_t ZK_PRE_MIN_N = 1u << 13;   // below this the per-window path is used
 constexpr size_t ZK_PRE_MAX_N = 1u << 26;   // ... and above this: a sorted reference of the table path is sign | 5 bits of window | 26 bits of point index
-// the limit the dispatch uses: ZK_PRE_MAX_N, or 2^ZK_PRE_MAX_LOG_N from the environment when that is smaller (test hook: the
-// fall-back to the per-window path over a table SRS can then be exercised without a 130 GiB table)
-inline size_t zk_pre_max_n() {
-    const char* e = getenv("ZK_PRE_MAX_LOG_N");
-    if (e) {
-        const int v = atoi(e);
-        if (v >= 13 && v < 26) return (size_t)1 << v;
-    }
+// the limit the dispatch uses: ZK_PRE_MAX_N, or 2^pre_max_log_n of the ctx's options when that is set (test hook: the fall-back to
+// the per-window path over a table SRS can then be exercised without a 130 GiB table).  Ranks of a window-sharded MSM must agree on it.
+inline size_t zk_pre_max_n(const zk_ctx* c) {
+    const int v = c->tune.pre_max_log_n;
+    if (v >= 13 && v < 26) return (size_t)1 << v;
     return ZK_PRE_MAX_N;
 }
 // arkworks-layout affine bases (x||y, Montgomery R = 2^(64L)) -> device-internal points

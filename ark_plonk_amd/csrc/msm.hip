@@ -1625,9 +1625,8 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
             hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
         }
     } else {
-        // lanes per small bucket when the launch has many jobs.  ZK_COMBINE_SG: tuning hook (profiles/r03_notes.md)
-        static const int sg_env = getenv("ZK_COMBINE_SG") ? atoi(getenv("ZK_COMBINE_SG")) : 0;
-        const int sg = sg_env ? sg_env : 1;
+        // lanes per small bucket when the launch has many jobs.  Option "combine_sg": tuning hook (profiles/r03_notes.md)
+        const int sg = c->tune.combine_sg ? c->tune.combine_sg : 1;
         if (sg == 4) {
             unsigned blocks = (unsigned)(((uint64_t)nb * 4 + T - 1) / T);
             hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
@@ -2088,6 +2087,34 @@ struct PrePlan {
                         // c = 16 table serves, with virtual windows of 1024 buckets)
 };
 
+// the reduction's view of the shared bucket set: a function of the table's window (pl.g.B buckets) and the ctx's options only
+inline void pre_reduce_geom(const zk_ctx* c, PrePlan& pl) {
+    pl.wide_red = pl.g.B > (1u << 16);
+    pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows (wide: windows of 512 buckets)
+    pl.gv.W = pl.wide_red ? pl.g.B / WIDE_VB : PRE_VW;
+    pl.gv.B = pl.g.B / pl.gv.W;
+    pl.gv.nb = pl.g.B;
+    // 64 chains (one wavefront per SIMD) per virtual window: segments of 8 buckets for windows of 512 (c = 16; measured against 4 / 16),
+    // of 16 for windows of 1024 (c = 17; 64 x 16 measured against 128 x 8, and against 128 and 32 virtual windows)
+    pl.gv.logG = pl.wide_red ? 2 : pl.gv.B >= 1024 ? 4 : 3;
+    if (!pl.wide_red) {                                   // tuning options "pre_vw" / "pre_logg" (profiles/r02_notes.md)
+        if (c->tune.pre_vw) {
+            const uint32_t v = (uint32_t)c->tune.pre_vw;
+            if (v >= 8 && v <= 512 && (v & (v - 1)) == 0 && pl.g.B % v == 0) {
+                pl.gv.W = v;
+                pl.gv.B = pl.g.B / v;
+            }
+        }
+        if (c->tune.pre_logg >= 0) {
+            const uint32_t v = (uint32_t)c->tune.pre_logg;
+            if (v <= 5 && (pl.gv.B >> v) >= 1) pl.gv.logG = v;
+        }
+    }
+    pl.gv.ns = pl.gv.B >> pl.gv.logG;
+    pl.gv.logq = 0;
+    while ((256u << pl.gv.logq) < pl.gv.ns) ++pl.gv.logq;
+}
+
 // long_chunks: the job is followed by another one inside a merged accumulation launch (msm_accumulate_batch): one round of
 // resident lanes with one long chunk each instead of several rounds of short ones.  The buffers are sized for the larger plan.
 template <class Cv>
@@ -2096,7 +2123,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     typedef typename Cv::FqU F;
     typedef XYZZ<Fq> PH;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
-    if (n > zk_pre_max_n()) return ZK_ERR_UNSUPPORTED;      // the callers (api.hip) send longer vectors down the per-window path
+    if (n > zk_pre_max_n(c)) return ZK_ERR_UNSUPPORTED;      // the callers (api.hip) send longer vectors down the per-window path
     pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
     pl.g.w0 = s->pre_w0;                                // a window-sharded table: this rank's rows only (W of the Wt windows)
@@ -2104,35 +2131,12 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     pl.g.W = s->pre_rows;
     pl.g.nb = pl.g.W * pl.g.B;
     pl.wide = pl.g.c > 16;
-    pl.wide_red = pl.g.B > (1u << 16);
     pl.nf = (uint64_t)n * pl.g.W;                       // flattened (window, scalar) digits
     if (pl.nf >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
     pl.g1 = pl.g;                                       // the sort sees ONE window of nf digits
     pl.g1.W = 1;
     pl.g1.nb = pl.g.B;
-    pl.gv = pl.g;                                       // the reduction sees PRE_VW virtual windows (wide: windows of 512 buckets)
-    pl.gv.W = pl.wide_red ? pl.g.B / WIDE_VB : PRE_VW;
-    pl.gv.B = pl.g.B / pl.gv.W;
-    pl.gv.nb = pl.g.B;
-    // 64 chains (one wavefront per SIMD) per virtual window: segments of 8 buckets for windows of 512 (c = 16; measured against 4 / 16),
-    // of 16 for windows of 1024 (c = 17; 64 x 16 measured against 128 x 8, and against 128 and 32 virtual windows)
-    pl.gv.logG = pl.wide_red ? 2 : pl.gv.B >= 1024 ? 4 : 3;
-    if (!pl.wide_red) {                                   // tuning hooks (profiles/r02_notes.md)
-        if (const char* e = getenv("ZK_PRE_VW")) {
-            const uint32_t v = (uint32_t)atoi(e);
-            if (v >= 8 && v <= 512 && (v & (v - 1)) == 0 && pl.g.B % v == 0) {
-                pl.gv.W = v;
-                pl.gv.B = pl.g.B / v;
-            }
-        }
-        if (const char* e = getenv("ZK_PRE_LOGG")) {
-            const uint32_t v = (uint32_t)atoi(e);
-            if (v <= 5 && (pl.gv.B >> v) >= 1) pl.gv.logG = v;
-        }
-    }
-    pl.gv.ns = pl.gv.B >> pl.gv.logG;
-    pl.gv.logq = 0;
-    while ((256u << pl.gv.logq) < pl.gv.ns) ++pl.gv.logq;
+    pre_reduce_geom(c, pl);
     // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 rounds of
     // resident lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131072 at the kernel's VGPR count), so that
     // lanes finishing early are replaced instead of idling through the tail (measured at 2^20:
@@ -2140,12 +2144,9 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     pl.chunk_l = PRE_CHUNK_L;
     while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 196608) pl.chunk_l >>= 1;
     bool tuned = false;
-    if (const char* e = getenv("ZK_CHUNK_L")) {          // tuning hook (profiles/r02_notes.md)
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 8 && v <= 1024) {
-            pl.chunk_l = v;
-            tuned = true;
-        }
+    if (c->tune.chunk_l >= 8 && c->tune.chunk_l <= 1024) {          // tuning option "chunk_l" (profiles/r02_notes.md)
+        pl.chunk_l = (uint32_t)c->tune.chunk_l;
+        tuned = true;
     }
     pl.n_lanes = (uint32_t)((pl.nf + pl.chunk_l - 1) / pl.chunk_l);
     // whole rounds of resident lanes: every lane does the same work, so 1.9 rounds take as long as 2 (15 windows of 2^20 digits
@@ -2154,7 +2155,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     // wavefronts, shortens with the chunk (2^20, c = 17: 60 -> 40 per lane, msm_accumulate -2.5 % per launch, msm_combine* +7
     // partials per bucket instead of 5, net +0.5 .. 0.8 % proofs/s; 30 and 24 per lane give the accumulation another 1 % and
     // the combine more than that back: profiles/r03_notes.md).  A job that is not the last one of a merged launch has no end of
-    // its own: one round (ZK_LONG_ROUNDS: tuning hook), a third of the partials.
+    // its own: one round (option "long_rounds": tuning hook), a third of the partials.
     uint32_t max_lanes = pl.n_lanes;
     {
         constexpr uint32_t ROUND = 131072;
@@ -2170,8 +2171,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
             }
             max_lanes = pl.n_lanes;
             if (long_chunks) {
-                const char* le = getenv("ZK_LONG_ROUNDS");
-                const uint32_t long_rounds = le ? (uint32_t)atoi(le) : 1u;
+                const uint32_t long_rounds = (uint32_t)c->tune.long_rounds;
                 const uint32_t lr = long_rounds < 1 ? 1u : long_rounds > rounds ? rounds : long_rounds;
                 // never more lanes than the plan the buffers were sized for (part_pt holds two partials per lane of max_lanes):
                 // where the whole-round rounding above was refused (chunks below 16), lr rounds of lanes can exceed it
@@ -2338,6 +2338,8 @@ int pre_queue_accumulate(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, con
         J.tab_off = tab_offs ? tab_offs[k] : 0;
         J.L0 = pls[k].chunk_l;
         J.n_lanes = pls[k].n_lanes;
+        mb.acc_chunk_l = pls[k].chunk_l;        // the reductions find the chunk-edge partials through these two
+        mb.acc_n_lanes = pls[k].n_lanes;
         J.blk0 = (uint32_t)blocks;
         blocks += (pls[k].n_lanes + T - 1) / T;
         points += lens[k];
@@ -2357,14 +2359,20 @@ int pre_queue_accumulate(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, con
 // d_partials (optional, n_jobs pointers): instead of the virtual-window sums going to the host, every job's whole sum
 //   sum_v S_v + B_v sum_v v T_v  is formed on the device (one more msm_win_finish_q launch over the VW pairs of each job) and left
 // at d_partials[k] as ONE point in the internal XYZZ form (zk_partial_dev_bytes): the multi-GPU exchange reads it from there.
+// the device forms of a round's result need the quad-cooperative reduction of at most 128 power-of-two virtual windows
+inline bool pre_partial_dev_ok(const PrePlan& p) {
+    return !p.wide_red && p.gv.logq == 0 && p.gv.ns <= 256 && p.gv.W <= 128 && (p.gv.W & (p.gv.W - 1)) == 0;
+}
+
 template <class Cv>
-int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_t n_jobs, void* h_win, hipStream_t st, void* const* d_partials = nullptr) {
+int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_t n_jobs, void* h_win, hipStream_t st, void* const* d_partials = nullptr,
+                     int partial_kind = 1) {
     typedef typename Cv::FqU F;
     constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     RJobs jobs;
     memset(&jobs, 0, sizeof jobs);
     const PrePlan& p0 = pls[0];
-    if (d_partials && p0.wide_red) return ZK_ERR_UNSUPPORTED;     // tables with c >= 18 finish on the host (queue_reduce_wide)
+    if (d_partials && !pre_partial_dev_ok(p0)) return ZK_ERR_UNSUPPORTED;     // checked by the callers before anything is queued
     for (uint32_t k = 0; k < n_jobs; ++k) {
         MsmBufs& mb = *mbs[k];
         jobs.part_pt[k] = mb.part_pt.p;
@@ -2375,15 +2383,18 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
         jobs.seg_acc[k] = (char*)mb.seg.p + (p0.wide_red ? (size_t)(p0.g.B >> WIDE_LOGG1) : (size_t)p0.gv.W * p0.gv.ns) * PT;
         // the window sums (a few KiB per job) are written by the last kernel straight into the pinned host
         // buffer (hipHostMalloc memory is device-visible): no copy launches at the tail of the call
-        if (d_partials) {
+        if (d_partials && partial_kind == 2) {
+            jobs.win_s[k] = (uint32_t*)d_partials[k];                                       // S_v | T_v, internal form, straight into the
+            jobs.win_t[k] = (uint32_t*)((char*)d_partials[k] + (size_t)p0.gv.W * PT);       // caller's buffer (the collective's send buffer)
+        } else if (d_partials) {
             jobs.win_s[k] = (uint32_t*)mb.win.p;                                            // S_v | T_v, internal form, on the device
             jobs.win_t[k] = (uint32_t*)((char*)mb.win.p + (size_t)p0.gv.W * PT);
         } else {
             jobs.win_s[k] = (uint32_t*)((char*)h_win + (size_t)k * p0.win_bytes);
             jobs.win_t[k] = jobs.win_s[k] + (size_t)p0.gv.W * 4 * F::SAT;
         }
-        jobs.L[k] = pls[k].chunk_l;
-        jobs.lanes[k] = pls[k].n_lanes;
+        jobs.L[k] = mb.acc_chunk_l;            // the plan the accumulation really ran with (pre_queue_accumulate), not a re-derived one
+        jobs.lanes[k] = mb.acc_n_lanes;
         jobs.nbk[k] = p0.g1.nb;
     }
     // the queue counters were cleared by the job's sort (psort_hist / the memset of the fallback sort)
@@ -2401,10 +2412,9 @@ int pre_queue_reduce(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, uint32_
     if (!d_partials) return queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true);
     int rc = queue_reduce<F>(c, jobs, n_jobs, p0.g1.nb, p0.gv, st, true, 1u);
     if (rc) return rc;
+    if (partial_kind == 2) return ZK_OK;      // the window sums ARE the result: zk_g1_sum_winsums_dev adds the ranks' and the host combines
     // the VW pairs of a job as one "window" of VW chains: R_u = T_u, Y_u = S_u, Z = sum_u S_u + B_v * sum_u u T_u
-    uint32_t chains = 1;
-    while (chains < p0.gv.W) chains <<= 1;
-    if (chains != p0.gv.W || chains > 128) return ZK_ERR_UNSUPPORTED;
+    const uint32_t chains = p0.gv.W;
     MsmGeom gf;
     memset(&gf, 0, sizeof gf);
     gf.W = 1;
@@ -2475,6 +2485,42 @@ int sum_partials_dev(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jo
         }
     }
     return ZK_OK;
+}
+
+// element-wise sum over the ranks of every job's 2 VW virtual-window sums (ranks x n_jobs x 2 VW points as the all-gather leaves
+// them) -> n_jobs x 2 VW points in the arkworks layout in pinned host memory, where the single-GPU path's last reduction kernel
+// puts them: one quad per (job, sum), ranks - 1 dependent additions each, 2 VW n_jobs quads side by side -- throughput-shaped
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) g1_sum_winsums_q(const void* all, uint32_t ranks, uint32_t n_pts /* n_jobs * 2 VW */,
+                                                                                                     uint32_t* out_sat) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = tid >> 2, role = tid & 3;
+    const bool live = k < n_pts;                   // no early exit: wave shuffles inside qadd
+    F acc = F::zero();
+#pragma unroll 1
+    for (uint32_t r = 0; r < ranks; ++r) acc = qadd<F>(acc, live ? ld_coord<F>(all, (uint64_t)r * n_pts + k, role) : F::zero(), role);
+    const bool inf = quad_is_inf(acc, role);
+    if (live) {
+        uint32_t* o = out_sat + (size_t)k * 4 * F::SAT + role * F::SAT;
+        if (inf) {
+            for (int i = 0; i < F::SAT; ++i) o[i] = 0;
+        } else {
+            acc.to_sat(o);
+        }
+    }
+}
+
+template <class Cv>
+bool partial_dev_supported(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb) {
+    if (!s->pre_W || s->pre_rows == 0) return false;
+    // the reduction geometry is a function of the table's window and the ctx's options only (pre_reduce_geom), not of a job's length
+    PrePlan pl;
+    pl.g = make_geom<typename Cv::FrP>(ZK_PRE_MIN_N, (int)s->pre_c, PRE_C_MAX);
+    pre_reduce_geom(c, pl);
+    if (!pre_partial_dev_ok(pl)) return false;
+    if (vw) *vw = pl.gv.W;
+    if (vb) *vb = pl.gv.B;
+    return true;
 }
 
 // a host Jacobian point (X, Y, Z: what the blocking entry points return) in the device partial form, for jobs of a round that
@@ -2626,11 +2672,8 @@ int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 //           accumulation of job k) the job's whole sort and its own accumulation launch follow at once (stage 2).
 //   reduce  the placement passes and ONE accumulation launch for every stage-1 job, then the reductions of all jobs, an event.
 //   end     waits for that event and finishes on the host.
-// ZK_MSM_MERGE=0 (A/B hook): every job is sorted and accumulated by its own launches at begin, as before round 4.
-static bool msm_merge_enabled() {      // read at every call: tools/ab_proof.py alternates it inside one process
-    const char* e = getenv("ZK_MSM_MERGE");
-    return !(e && atoi(e) == 0);
-}
+// Option "msm_merge" = 0 (A/B hook): every job is sorted and accumulated by its own launches at begin, as before round 4.
+static bool msm_merge_enabled(const zk_ctx* c) { return c->tune.msm_merge != 0; }
 
 template <class Cv>
 int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
@@ -2640,7 +2683,7 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
     if (slot0 + n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
     hipStream_t st = c->stream;
-    const bool defer = msm_merge_enabled() && !before_job;
+    const bool defer = msm_merge_enabled(c) && !before_job;
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[slot0 + k];
         PrePlan pl;
@@ -2664,7 +2707,8 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
 // results) BEHIND the reductions before it waits: `reduce` queues everything up to the reduction kernels and an event, `end` waits
 // for that event only -- the work queued in between runs while the host combines the window sums and normalises.
 template <class Cv>
-int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr) {
+int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr,
+                         int partial_kind = 1) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
@@ -2685,6 +2729,9 @@ int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* 
         const bool deferred = mbs[k]->stage_of_job == 1;
         if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k], deferred && k != last_deferred))) return rc;    // buffers already large enough: no allocation
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
+        // a device form the reduction cannot deliver is refused HERE, before the sort and the accumulation of the deferred jobs
+        // are queued: the round is then exactly as it was and the host form may still close it
+        if (d_partials && !pre_partial_dev_ok(pl[k])) return ZK_ERR_UNSUPPORTED;
         if (deferred) {
             dpl[nd] = pl[k];
             dmb[nd] = mbs[k];
@@ -2699,12 +2746,64 @@ int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* 
         if ((rc = pre_queue_accumulate<Cv>(c, dpl, dmb, dlen, nullptr, nd, s, st))) return rc;
         for (uint32_t k = 0; k < nd; ++k) dmb[k]->stage_of_job = 2;
     }
-    if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st, d_partials))) return rc;
+    if ((rc = pre_queue_reduce<Cv>(c, pl, mbs, n_jobs, c->pinned, st, d_partials, partial_kind))) return rc;
     for (uint32_t k = 0; k < n_jobs; ++k) mbs[k]->stage_of_job = 0;
     if (!c->round_ev) ZK_HIP_TRY(hipEventCreateWithFlags(&c->round_ev, hipEventDisableTiming));
     ZK_HIP_TRY(hipEventRecord(c->round_ev, st));
     c->round_reduced = n_jobs;
     return ZK_OK;
+}
+
+// the host tail of a round on the shared-bucket path: n_jobs x (VW pairs S_v | T_v in pinned memory, arkworks layout) -> Jacobian (and affine)
+template <class Cv>
+int pre_host_finish_jobs(zk_ctx* c, const char* h_win, size_t wb, uint32_t n_jobs, uint32_t VW, uint32_t VB, uint64_t* out_xyz /* n_jobs x 3L */,
+                         uint64_t* out_xy /* optional */, uint8_t* out_inf /* optional */) {
+    typedef typename Cv::Fq Fq;
+    constexpr int L64 = Fq::N / 2;
+    int rcs[MAX_JOBS] = {0};
+    // ~200 point additions + one field inversion per job (measured: 200 us on one host thread, the GPU idle meanwhile): every
+    // job's virtual windows are cut into HOST_CHUNKS ranges that go to the pool as separate items, and whichever thread
+    // finishes a job's last range also does that job's final sum and affine normalisation -- one wake-up of the pool per round
+    HostPartial<Fq> part[MAX_JOBS * HOST_CHUNKS];
+    std::atomic<uint32_t> left[MAX_JOBS];
+    for (uint32_t k = 0; k < n_jobs; ++k) left[k].store(HOST_CHUNKS);
+    c->pool->run(n_jobs * HOST_CHUNKS, [&](uint32_t i) {
+        const uint32_t k = i / HOST_CHUNKS, ch = i % HOST_CHUNKS;
+        pre_host_partial<Cv>(h_win + (size_t)k * wb, VW, ch * (VW / HOST_CHUNKS), (ch + 1) * (VW / HOST_CHUNKS), part[i]);
+        if (left[k].fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
+        pre_host_final<Cv>(part + k * HOST_CHUNKS, VW, VB, xyz);
+        if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
+    });
+    for (uint32_t k = 0; k < n_jobs; ++k)
+        if (rcs[k]) return rcs[k];
+    return ZK_OK;
+}
+
+// the ranks' virtual-window sums (zk_kzg_round_end_winsums_dev on every rank, all-gathered rank-major) -> n_jobs affine commitments:
+// one kernel adds them element-wise into the pinned buffer, one wait, then the single-GPU path's own host tail
+template <class Cv>
+int sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    typedef typename Cv::Fq Fq;
+    typedef typename Cv::FqU F;
+    typedef XYZZ<Fq> PH;
+    constexpr int L64 = Fq::N / 2;
+    if (n_jobs == 0) return ZK_OK;
+    if (ranks == 0 || ranks > 4096 || n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_BAD_ARG;
+    uint32_t VW = 0, VB = 0;
+    if (!partial_dev_supported<Cv>(c, s, &VW, &VB)) return ZK_ERR_UNSUPPORTED;
+    const size_t wb = (size_t)2 * VW * sizeof(PH);
+    int rc = ensure_pinned(c, wb * MAX_JOBS);
+    if (rc) return rc;
+    const uint32_t n_pts = n_jobs * 2 * VW;
+    {
+        ProfScope ps(c, "msm_sum_winsums", c->stream);
+        hipLaunchKernelGGL(g1_sum_winsums_q<F>, dim3((n_pts * 4 + 255) / 256), dim3(256), 0, c->stream, d_all, (uint32_t)ranks, n_pts, (uint32_t*)c->pinned);
+        ZK_HIP_TRY(hipGetLastError());
+    }
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t xyz[MAX_JOBS * 3 * L64];
+    return pre_host_finish_jobs<Cv>(c, (const char*)c->pinned, wb, n_jobs, VW, VB, xyz, out_xy, out_inf);
 }
 
 template <class Cv>
@@ -2737,32 +2836,18 @@ int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slo
         }
     } tail_timer{host_timing, n_jobs, t0, t1};
     const char* h_win = (const char*)c->pinned;
-    int rcs[MAX_JOBS] = {0};
     if (pl[0].wide_red) {
+        int rcs[MAX_JOBS] = {0};
         c->pool->run(n_jobs, [&](uint32_t k) {
             uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
             pre_host_wide<Cv>(h_win + (size_t)k * wb, ilog2_floor(pl[k].gv.B), xyz);
             if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
         });
-    } else {
-        // ~200 point additions + one field inversion per job (measured: 200 us on one host thread, the GPU idle meanwhile): every
-        // job's virtual windows are cut into HOST_CHUNKS ranges that go to the pool as separate items, and whichever thread
-        // finishes a job's last range also does that job's final sum and affine normalisation -- one wake-up of the pool per round
-        HostPartial<Fq> part[MAX_JOBS * HOST_CHUNKS];
-        std::atomic<uint32_t> left[MAX_JOBS];
-        for (uint32_t k = 0; k < n_jobs; ++k) left[k].store(HOST_CHUNKS);
-        c->pool->run(n_jobs * HOST_CHUNKS, [&](uint32_t i) {
-            const uint32_t k = i / HOST_CHUNKS, ch = i % HOST_CHUNKS, VW = pl[k].gv.W;
-            pre_host_partial<Cv>(h_win + (size_t)k * wb, VW, ch * (VW / HOST_CHUNKS), (ch + 1) * (VW / HOST_CHUNKS), part[i]);
-            if (left[k].fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-            uint64_t* xyz = out_xyz + (size_t)k * 3 * L64;
-            pre_host_final<Cv>(part + k * HOST_CHUNKS, VW, pl[k].gv.B, xyz);
-            if (out_xy) rcs[k] = jac_to_affine<Fq>(xyz, out_xy + (size_t)k * 2 * L64, out_inf ? out_inf + k : nullptr);
-        });
+        for (uint32_t k = 0; k < n_jobs; ++k)
+            if (rcs[k]) return rcs[k];
+        return ZK_OK;
     }
-    for (uint32_t k = 0; k < n_jobs; ++k)
-        if (rcs[k]) return rcs[k];
-    return ZK_OK;
+    return pre_host_finish_jobs<Cv>(c, h_win, wb, n_jobs, pl[0].gv.W, pl[0].gv.B, out_xyz, out_xy, out_inf);
 }
 
 template <class Cv>
@@ -2887,8 +2972,13 @@ int ZK_SYM(msm_batch_pre_begin_dev)(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32
                                     const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
     return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
 }
-int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials) {
-    return msm_batch_pre_reduce<CurveSel>(c, s, n_jobs, slots, lens, d_partials);
+int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials,
+                                     int partial_kind) {
+    return msm_batch_pre_reduce<CurveSel>(c, s, n_jobs, slots, lens, d_partials, partial_kind);
+}
+bool ZK_SYM(msm_partial_dev_supported)(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb) { return partial_dev_supported<CurveSel>(c, s, vw, vb); }
+int ZK_SYM(g1_sum_winsums_dev)(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
+    return sum_winsums_dev<CurveSel>(c, s, d_all, ranks, n_jobs, out_xy, out_inf);
 }
 size_t ZK_SYM(msm_partial_dev_bytes)() { return (size_t)4 * Store<CurveSel::FqU>::WORDS * 4; }
 int ZK_SYM(g1_sum_partials_dev)(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {

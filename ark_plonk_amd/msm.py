@@ -14,7 +14,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import ZK_ERR_UNSUPPORTED, check, lib
 from .context import Context, _is_torch, as_host_u64, check_dev_tensor, default_context, ptr_of
 from .curves import get_curve
 
@@ -319,6 +319,44 @@ class CommitterKey:
         self.ctx.use_torch_stream()
         check(lib().zk_g1_sum_partials_dev(self.ctx.handle, self.curve.curve_id, d_all.data_ptr(), ranks, n_jobs, ptr_of(out), ptr_of(inf)),
               "zk_g1_sum_partials_dev")
+        return [_point(out[i], inf[i:i + 1], self.curve) for i in range(n_jobs)]
+
+    # -- the exchange one step earlier: a job's 2 VW virtual-window sums instead of their combination (see the header)
+    def winsums_dev_words(self) -> int:
+        """int64 words of one job's window sums (zk_winsums_dev_bytes / 8); 0 where the form does not exist (no table, c >= 18)."""
+        return lib().zk_winsums_dev_bytes(self.ctx.handle, self._h) // 8
+
+    def winsums_geometry(self):
+        """(window_bits, windows of a full-width scalar, virtual windows, buckets per virtual window), or None: what every rank of a
+        sharded MSM must agree on for its window sums to be addable element-wise."""
+        g = (ctypes.c_uint32 * 4)()
+        rc = lib().zk_winsums_geometry(self.ctx.handle, self._h, g)
+        if rc == ZK_ERR_UNSUPPORTED:
+            return None
+        check(rc, "zk_winsums_geometry")
+        return tuple(g)
+
+    def round_reduce_winsums_dev(self, d_out):
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_round_reduce_winsums_dev(self.ctx.handle, d_out.data_ptr()), "zk_kzg_round_reduce_winsums_dev")
+
+    def round_end_winsums_dev(self, d_out, n_jobs: int | None = None):
+        """Close the round leaving every job's window sums ON THE DEVICE in `d_out` (jobs x winsums_dev_words int64, no host wait)."""
+        k = self.round_pending() if n_jobs is None else n_jobs
+        if d_out.numel() < k * self.winsums_dev_words():
+            raise ValueError("window-sum buffer too small")
+        self.ctx.use_torch_stream()
+        check(lib().zk_kzg_round_end_winsums_dev(self.ctx.handle, k, d_out.data_ptr()), "zk_kzg_round_end_winsums_dev")
+
+    def sum_winsums_dev(self, d_all, ranks: int, n_jobs: int) -> list:
+        """All-gathered window sums (ranks x jobs x winsums_dev_words, rank-major) -> one G1Affine per job: one element-wise kernel,
+        one wait, the combine + inversion per job on the host pool (as zk_kzg_round_end)."""
+        L = self.curve.fq_limbs
+        out = np.zeros((max(n_jobs, 1), 2 * L), dtype=np.uint64)
+        inf = np.zeros(max(n_jobs, 1), dtype=np.uint8)
+        self.ctx.use_torch_stream()
+        check(lib().zk_g1_sum_winsums_dev(self.ctx.handle, self._h, d_all.data_ptr(), ranks, n_jobs, ptr_of(out), ptr_of(inf)),
+              "zk_g1_sum_winsums_dev")
         return [_point(out[i], inf[i:i + 1], self.curve) for i in range(n_jobs)]
 
     def round_abort(self):

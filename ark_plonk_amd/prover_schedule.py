@@ -73,7 +73,8 @@ class ProofSchedule:
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
                  ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
-                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True, split_rounds: int = 0):
+                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True, split_rounds: int = 0,
+                 exchange: str | None = None):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -228,12 +229,31 @@ class ProofSchedule:
         else:
             self.lo = rank * n // world
             self.hi = (rank + 1) * n // world
-        # the exchange without a host hop: partials written by the last reduction kernel into a device tensor, all-gathered from there,
-        # summed by one kernel (zk_kzg_round_end_partial_dev / zk_g1_sum_partials_dev).  Not for tables with c >= 18 or the commitment cache.
-        self.partials_on_device = bool(partials_on_device and world > 1 and defer_calls and not (self.dedup or self.dedup_abi)
-                                       and 0 < ck.table_window_bits() <= 17)
+        # The exchange of a sharded round (world > 1), three forms, same points:
+        #   "winsums" (default)  every job's 2 VW virtual-window sums, written by the reduction kernel the single-GPU path ends with, straight
+        #                        into the collective's send buffer; all-gathered (32 KiB per job); added element-wise by one kernel; ONE
+        #                        host wait, the combine per job on the host pool (zk_kzg_round_end_winsums_dev / zk_g1_sum_winsums_dev)
+        #   "point"              round 4's device form: one more dependent quad launch forms every job's sum, 256 B per job gathered
+        #                        (zk_kzg_round_end_partial_dev / zk_g1_sum_partials_dev)
+        #   "host"               round 3's: window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
+        # The device forms need the deferred rounds, a table with c <= 17 and no commitment cache; otherwise "host" is used.
+        if exchange is None:
+            exchange = "winsums" if partials_on_device else "host"
+        if exchange not in ("winsums", "point", "host"):
+            raise ValueError("exchange: 'winsums', 'point' or 'host'")
+        geom = ck.winsums_geometry() if world > 1 else None
+        if not (world > 1 and defer_calls and not (self.dedup or self.dedup_abi) and geom is not None):
+            exchange = "host"
+        self.exchange = exchange
+        self.partials_on_device = exchange != "host"
+        if world > 1 and dist is not None and geom is not None and hasattr(dist, "all_gather_object"):
+            # once per schedule: element-wise sums of window sums mean something only if every rank reduces in the same geometry
+            seen = [None] * world
+            dist.all_gather_object(seen, (exchange,) + tuple(geom))
+            if len(set(seen)) != 1:
+                raise RuntimeError(f"ranks disagree on the exchange form / table geometry (window bits, windows, virtual windows, buckets): {seen}")
         if self.partials_on_device:
-            self._pw = ck.partial_dev_words()
+            self._pw = ck.winsums_dev_words() if exchange == "winsums" else ck.partial_dev_words()
             self._pbuf = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)       # partials of the library's pending jobs
             self._pfull = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)      # ... with all-zero rows (infinity) for empty shards
         self.collectives = 0
@@ -344,7 +364,9 @@ class ProofSchedule:
                     self.ck2.round_reduce()
             return
         if not self._immediate() and any(kind == "q" for kind, _ in self._pending):
-            if self.world > 1 and self.partials_on_device:
+            if self.world > 1 and self.exchange == "winsums":
+                self.ck.round_reduce_winsums_dev(self._pbuf)
+            elif self.world > 1 and self.exchange == "point":
                 self.ck.round_reduce_partial_dev(self._pbuf)
             else:
                 self.ck.round_reduce()
@@ -396,11 +418,13 @@ class ProofSchedule:
         return self._all_gather_sum(full)
 
     def _gather_dev(self, nq, pend):
-        """Sharded round, device form: the library leaves the queued jobs' partials in `_pbuf` (no host wait), ONE all-gather of the
-        device tensor, one summing kernel.  Jobs whose shard is empty ("z") are all-zero rows = the point at infinity."""
+        """Sharded round, device forms: the library leaves the queued jobs' partials (one point, or the 2 VW window sums) in `_pbuf`
+        (no host wait), ONE all-gather of the device tensor, one summing kernel.  Jobs whose shard is empty ("z") are all-zero rows
+        = the point at infinity (every window sum infinite)."""
         jobs = [kind for kind, _ in pend if kind != "r"]
+        ws = self.exchange == "winsums"
         if nq:
-            self.ck.round_end_partial_dev(self._pbuf, nq)
+            (self.ck.round_end_winsums_dev if ws else self.ck.round_end_partial_dev)(self._pbuf, nq)
         if nq == len(jobs):
             mine = self._pbuf[:nq]
         else:
@@ -411,7 +435,7 @@ class ProofSchedule:
             mine = self._pfull[:len(jobs)]
         allp = all_gather_partials_dev(self.dist, mine, self.world)
         self.collectives += 1
-        return self.ck.sum_partials_dev(allp, self.world, len(jobs))
+        return (self.ck.sum_winsums_dev if ws else self.ck.sum_partials_dev)(allp, self.world, len(jobs))
 
     def _all_gather_sum(self, parts):
         self.collectives += 1

@@ -12,8 +12,11 @@ line; under an external torchrun it is a rank.  `value` for N > 1 is the through
 proofs are independent, so every rank runs the schedule K times with no data-path collective (SURVEY.md 8e
 "whole proofs: replicas only", scaling "weak").  The same run then times extra legs, never part of `value`:
 `msm_sharded` (this size) and `msm_sharded_n22` (BASELINE config 3, n = 2^22): one proof stream with every MSM
-sharded by points over the ranks and combined by an RCCL all-gather of Jacobian partials per prover round
-(NTTs replicated).  `--mode shard` makes the sharded form the headline instead (scaling "strong").
+sharded by points over the ranks and combined by ONE RCCL all-gather per group of PC calls (`--exchange`: the jobs' virtual-window
+sums, 32 KiB each, straight out of the last reduction kernel -- the default -- or one point per job, or host Jacobians; NTTs
+replicated).  `--mode shard` makes the sharded form the headline instead (scaling "strong").  Every N > 1 line carries `ranks`: the
+world, the backend, the (host, PCI address) of the card each rank drove, how many of those are distinct and an all-reduced sum of
+ones; with backend nccl the run refuses to start when ranks share a card.  `--rehearse` walks the N > 1 control flow without a GPU.
 
 N = 1 adds, also never part of `value`:
   concurrent_streams  the same GPU with 4 proofs in flight (one thread + zk_ctx + HIP stream each, ONE shared SRS);
@@ -256,6 +259,129 @@ def self_launch(n_ranks: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+# ---- N > 1: what the collective library really saw ------------------------------------------------------------------------------
+def device_identity(torch, dev_index: int) -> str:
+    """PCI address (+ UUID where torch exposes it) of the HIP device this rank drives: two ranks on one card have equal strings."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+    except Exception as e:       # a rehearsal on a host without a GPU
+        return f"none:{e.__class__.__name__}"
+    pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    uuid = getattr(pr, "uuid", None)
+    return f"{pci}/{uuid}" if uuid is not None else pci
+
+
+def ranks_handshake(dist, torch, backend: str, world: int, rank: int, local_rank: int, dev_index, tensor_device=None):
+    """Run once after init_process_group: every rank's (host, device identity, local rank, pid) all-gathered, and an all_reduce(SUM) of
+    a 1 per rank through the data path's own backend (on the rank's GPU for RCCL).  The `ranks` object of the line: evidence that N
+    processes drove N different cards, or the reason the run refused to start (backend nccl and fewer distinct devices than ranks)."""
+    ident = "cpu" if dev_index is None else device_identity(torch, dev_index)
+    me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "device": ident, "pid": os.getpid()}
+    seen = [None] * world
+    dist.all_gather_object(seen, me)
+    if tensor_device is None:
+        tensor_device = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.int64, device=tensor_device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    seen.sort(key=lambda d: d["rank"])
+    distinct = len({(d["host"], d["device"]) for d in seen})
+    return {"world": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "distinct_devices": distinct,
+            "shared_card": distinct < world, "sum_check": int(one.item()), "hosts": len({d["host"] for d in seen}),
+            "devices": [f"{d['rank']}:{d['host']}:{d['device']}:local{d['local_rank']}" for d in seen]}
+
+
+# rank 0 of an N > 1 run: the line as far as it is known.  `value` exists as soon as the headline region has been timed; should the job be
+# torn down during one of the EXTRA legs (a rank lost inside a collective: torchrun SIGTERMs the others), a thread that owns SIGTERM prints
+# the line with what it has -- the main thread may be stuck inside a collective and never run a Python-level handler.
+_LINE = {"line": None, "printed": False, "leg": None}
+
+
+def install_sigterm_line_printer():
+    import signal
+    import threading
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})          # inherited by every thread created from here on
+
+    def waiter():
+        signal.sigwait({signal.SIGTERM})
+        if _LINE["line"] is not None and not _LINE["printed"]:
+            line = dict(_LINE["line"])
+            line["aborted_in_leg"] = _LINE["leg"]
+            _LINE["printed"] = True
+            print(json.dumps(line), flush=True)
+        os._exit(143)
+
+    threading.Thread(target=waiter, daemon=True).start()
+
+
+REHEARSAL_GROUPS = (4, 3, 2, 4, 16)        # jobs per group of PC calls of one proof (prover.rs:213 | 289-317 | 361-389 | 459-469 | 579-618)
+REHEARSAL_WORDS = 2 * 64 * 32              # int64 words of one job's window sums at the default geometry (BLS12-381: 128 points x 256 B)
+
+
+def rehearse(args, world: int, rank: int, local_rank: int) -> int:
+    """bench.py's N > 1 control flow with no GPU and no compute (see --rehearse)."""
+    import torch
+    import torch.distributed as dist
+    from datetime import timedelta
+    if args.backend == "nccl":
+        print("bench.py --rehearse is a CPU rehearsal: use --backend gloo", file=sys.stderr)
+        return 2
+    if world > 1:
+        if rank == 0:
+            install_sigterm_line_printer()        # before the backend starts its threads: they must inherit the blocked mask
+        dist.init_process_group(args.backend, timeout=timedelta(seconds=args.dist_timeout))
+        info = ranks_handshake(dist, torch, args.backend, world, rank, local_rank, None)
+    else:
+        info = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def one_proof(step: int):
+        for gi, jobs in enumerate(REHEARSAL_GROUPS):
+            if rank == args.fault_rank and gi == 2 and step == (1 if args.fault_at == "step" else 3):
+                os._exit(41)                                   # a rank lost between two collectives of a proof
+            mine = torch.full((jobs * REHEARSAL_WORDS,), (rank + 1) * 1000 + gi, dtype=torch.int64)
+            out = torch.empty((world, jobs * REHEARSAL_WORDS), dtype=torch.int64)
+            if world > 1:
+                dist.all_gather_into_tensor(out.view(-1), mine)
+            else:
+                out[0] = mine
+            for r in range(world):                             # rank-major, as zk_g1_sum_winsums_dev reads it
+                if not bool((out[r] == (r + 1) * 1000 + gi).all()):
+                    raise RuntimeError(f"rank {rank}: row {r} of group {gi} is not rank {r}'s tensor")
+
+    for _ in range(args.warmup):
+        one_proof(0)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_proof(1 if k == 0 else 2)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        line = {"metric": "REHEARSAL of the N > 1 control flow: no GPU, no compute, not a measurement", "rehearsal": True, "value": None,
+                "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 tensors of the exchange's shapes", "data": "synthetic",
+                "config": {"workload": "five all_gather_into_tensor per step of 4|3|2|4|16 x 32 KiB, contents checked on every rank"},
+                "collectives_per_step": len(REHEARSAL_GROUPS), "bytes_per_rank_per_step": sum(REHEARSAL_GROUPS) * REHEARSAL_WORDS * 8, "ranks": info}
+        _LINE["line"], _LINE["leg"] = line, "rehearsal_leg"
+    # an "extra leg" after the timed region, as the real run has them: a job torn down in here still gets its headline line out
+    one_proof(3)
+    barrier()
+    if rank == 0:
+        _LINE["leg"] = None
+        _LINE["printed"] = True
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,9 +403,31 @@ def parse_args():
                     help="sharded MSMs (N > 1): 'points' = rank g owns SRS[g n/G, (g+1) n/G) and that slice of every polynomial (SURVEY.md 8e's "
                          "preferred axis); 'windows' = rank g holds the whole SRS and the table rows of the windows g, g + G, ... "
                          "(BASELINE.json north_star's wording; zk_srs_precompute_rows)")
-    ap.add_argument("--host-partials", action="store_true",
-                    help="sharded MSMs: exchange host Jacobian partials (round 3's path: D2H, host combine, H2D, all_gather, D2H) instead of "
-                         "the device form (zk_kzg_round_end_partial_dev -> all_gather_into_tensor -> zk_g1_sum_partials_dev)")
+    ap.add_argument("--exchange", default="winsums", choices=["winsums", "point", "host"],
+                    help="sharded MSMs, what the ranks all-gather per group of PC calls: 'winsums' (default) = every job's 2 VW virtual-window sums as "
+                         "the last reduction kernel of the single-GPU path leaves them on the device (32 KiB per job), added element-wise by one "
+                         "kernel, one host combine per job (zk_kzg_round_end_winsums_dev -> all_gather_into_tensor -> zk_g1_sum_winsums_dev); "
+                         "'point' = round 4's device form, one more dependent launch per group forms each job's sum (256 B per job; "
+                         "zk_kzg_round_end_partial_dev -> zk_g1_sum_partials_dev); 'host' = round 3's host Jacobian partials (D2H, host "
+                         "combine, H2D, all_gather, D2H)")
+    ap.add_argument("--host-partials", action="store_true", help="= --exchange host")
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="N > 1: timeout (s) of the process group: a rank lost inside a collective takes the job down after this long instead of "
+                         "hanging it (every collective of this program completes in milliseconds)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 control flow WITHOUT the GPU and without any compute: rendezvous, the `ranks` handshake, barriers, the max-over-ranks "
+                         "timing and the five all-gathers of a sharded proof with tensors of the real shapes (4|3|2|4|16 jobs x 32 KiB) whose "
+                         "contents every rank checks.  Prints a line with \"rehearsal\": true and value null -- never a measurement.  Runs on "
+                         "CPU-only hosts (tests/test_distributed.py: 8 gloo ranks, and one of them killed)")
+    ap.add_argument("--fault-rank", type=int, default=-1,
+                    help="test hook: this rank dies (os._exit(41), no clean-up) in the middle of the run -- --rehearse: inside the first timed step, "
+                         "between two collectives (--fault-at step) or inside the extra leg that follows the timed region (--fault-at leg); "
+                         "otherwise inside the msm_sharded leg.  The job must end non-zero within --dist-timeout, not hang; killed inside a leg, "
+                         "rank 0 still prints the headline line it already has, with `aborted_in_leg`")
+    ap.add_argument("--fault-at", default="step", choices=["step", "leg"], help="see --fault-rank")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="a tuning option of the library (zk_ctx_set_option: msm_merge, pre_vw, pre_logg, chunk_l, long_rounds, combine_sg, pre_max_log_n), "
+                         "set on every zk_ctx of the run and recorded in config.options; the library reads no environment variable")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent proof streams per GPU (threads with their own zk_ctx + HIP stream); the K steps are shared out")
     ap.add_argument("--streams-leg", type=int, default=4,
@@ -326,13 +474,38 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.host_partials:
+        args.exchange = "host"
+    if args.rehearse:
+        sys.exit(rehearse(args, world, rank, local_rank))
     n_dev = torch.cuda.device_count()
+    ranks_info = None
     if world > 1:
-        torch.cuda.set_device(local_rank % n_dev)
+        # One process per GPU.  With RCCL a rank without a card of its own is an error on EVERY rank before the rendezvous (all of
+        # them see the same LOCAL_WORLD_SIZE and device count, so nobody is left waiting); folding ranks onto one card
+        # (local_rank % n_dev) is for the gloo rehearsals on a one-card box only and is reported in the line (`ranks.shared_card`).
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if args.backend == "nccl" and local_world > n_dev:
+            print(f"bench.py: {local_world} ranks on this host but {n_dev} GPU(s) visible: backend nccl needs one GPU per rank "
+                  f"(rank {rank}); use --backend gloo for a one-card rehearsal", file=sys.stderr)
+            sys.exit(2)
+        if rank == 0:
+            install_sigterm_line_printer()        # before HIP / the backend start their threads: they must inherit the blocked mask
+        dev_index = local_rank % max(n_dev, 1)
+        torch.cuda.set_device(dev_index)
+        from datetime import timedelta
+        tmo = timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % n_dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
+        ranks_info = ranks_handshake(dist, torch, args.backend, world, rank, local_rank, dev_index)
+        if args.backend == "nccl" and (ranks_info["distinct_devices"] < world or ranks_info["sum_check"] != world):
+            if rank == 0:
+                print(f"bench.py: RCCL saw {ranks_info['distinct_devices']} distinct device(s) for {world} ranks (sum check "
+                      f"{ranks_info['sum_check']}): {ranks_info['devices']}", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -341,8 +514,16 @@ def main():
     import ark_plonk_amd as zk
     from ark_plonk_amd.prover_schedule import DropInSchedule, ProofSchedule
 
+    options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
+
+    def new_ctx(d):
+        c = zk.Context(d)
+        for k, v in options.items():
+            c.set_option(k, v)
+        return c
+
     dev = torch.cuda.current_device()
-    ctx = zk.Context(dev)
+    ctx = new_ctx(dev)
     ctx.use_torch_stream()
     cv = zk.get_curve(args.curve)
     sbits = cv.r.bit_length()
@@ -391,7 +572,7 @@ def main():
             ck0.precompute(args.table_window)   # window-multiples table resident in HBM (one-time, like PC::trim)
         lanes = []
         for i in range(S):
-            cx = ctx if i == 0 else zk.Context(dev)
+            cx = ctx if i == 0 else new_ctx(dev)
             st = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
             ck = ck0 if i == 0 else ck0.with_ctx(cx)     # the SRS and its table belong to the device, not to a ctx
             with torch.cuda.stream(st):
@@ -399,7 +580,7 @@ def main():
                           data=data, ntt_batch=not args.no_ntt_batch, defer_calls=defer_calls, hoist=not args.no_hoist)
                 if sharded:
                     sched = ProofSchedule(log_n, cx, ck, cv, rank=rank, world=world, dist=dist, shard_axis=args.shard_axis,
-                                          partials_on_device=not args.host_partials, **kw)
+                                          exchange=args.exchange, **kw)
                 else:
                     sched = ProofSchedule(log_n, cx, ck, cv, **kw)
                 pts = None
@@ -474,6 +655,7 @@ def main():
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
+               "exchange": getattr(lanes[0]["sched"], "exchange", None) if sharded else None, "collectives": lanes[0]["sched"].collectives,
                "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": msms_run, "kb": kb,
                "windows": ck0.table_windows()}
         if dedup == "abi":
@@ -583,8 +765,8 @@ def main():
     if world == 1:
         par = "1 GPU"
     elif main_sharded:
-        par = (f"MSM sharded by {args.shard_axis} over {world} GPUs + RCCL all-gather of partials "
-               f"({'host Jacobian' if args.host_partials else 'device-resident'} form); NTT replicated")
+        par = (f"MSM sharded by {args.shard_axis} over {world} GPUs + one all-gather per group of PC calls "
+               f"(exchange form '{r['exchange']}'); NTT replicated")
     else:
         par = f"{world} replicas (one whole proof stream per GPU, no data-path collective)"
     line = {
@@ -596,7 +778,7 @@ def main():
         "config": {"workload": f"per-proof hot path of Prover::prove at n=2^{log_n}: 13 ifft(n)+4 fft(n)+13 coset_fft(4n)+"
                                f"1 coset_ifft(4n)+29 KZG commits (MSM ~n), {cv.name}, SRS+inputs HBM-resident"
                                + (", wire columns as BenchCircuit builds them (periodic {6,7,-20,1} rows + 3 blinding rows)" if args.data != "uniform" else ""),
-                   "log_n": log_n, "curve": cv.name, "parallelism": par, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows",
+                   "log_n": log_n, "curve": cv.name, "parallelism": par, "options": options or None, "msm_path": "per-window" if args.no_precompute else f"window table, {W} shared-bucket windows",
                    "pc_calls": ("the reference's eleven PC::commit / PC::open calls (4|1|1|1|1|1|4|7|1|7|1 polynomials), every call blocking"
                                 if args.block_every_call or args.dedup else
                                 "the reference's eleven PC::commit / PC::open calls (4|1|1|1|1|1|4|7|1|7|1 polynomials, 29 MSMs); calls whose inputs do not depend on each "
@@ -666,6 +848,10 @@ def main():
         line["config"]["parallelism"] += f", {S} concurrent proof streams per GPU (kernel times below overlap other streams' work)"
     if args.check:
         line["commitments_sha256"] = r["digest"]
+    if ranks_info is not None:
+        # what the collective library saw: N processes, the card each one drove, and a SUM of ones through the data path's backend
+        line["ranks"] = ranks_info
+    _LINE["line"] = line          # N > 1: from here on a torn-down job still prints its headline (install_sigterm_line_printer)
 
     def acc_per_msm(rr):
         a_ms, a_n = rr["prof"]["msm_accumulate"]
@@ -673,6 +859,7 @@ def main():
 
     def leg(name, fn):
         """an extra leg never takes the headline down; every rank agrees on its outcome first"""
+        _LINE["leg"] = name
         try:
             res = fn()
             ok = True
@@ -806,7 +993,7 @@ def main():
             S3 = 3
             lanes3 = []
             for i in range(S3):
-                cx = ctx if i == 0 else zk.Context(dev)
+                cx = ctx if i == 0 else new_ctx(dev)
                 st3 = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
                 lanes3.append((cx, st3, (pk if i == 0 else pk.with_ctx(cx), ckp if i == 0 else ckp.with_ctx(cx)) + a[2:]))
             for cx, st3, a3 in lanes3[1:]:
@@ -863,11 +1050,16 @@ def main():
         # prover round) -- single-proof latency
         def shard_leg(lg):
             def run():
+                if rank == args.fault_rank:
+                    os._exit(41)              # test hook: a rank lost inside an extra leg (tests/test_distributed.py)
                 rs = timed_region(True, log_n=lg)
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
-                     "collective": "RCCL all_gather of the jobs' partials, one per group of PC calls (5 per proof; 11 with --block-every-call): "
-                                   + ("3L-limb host Jacobian partials (--host-partials)" if args.host_partials else
-                                      "device-resident XYZZ partials written by the last reduction kernel, summed by zk_g1_sum_partials_dev"),
+                     "collective": "all_gather of the jobs' partials, one per group of PC calls (5 per proof; 11 with --block-every-call): "
+                                   + {"host": "3L-limb host Jacobian partials (--exchange host)",
+                                      "point": "one device-resident XYZZ point per job formed by a further reduction launch, summed by zk_g1_sum_partials_dev",
+                                      "winsums": "the 2 VW virtual-window sums of every job (32 KiB) as the single-GPU path's last reduction kernel writes "
+                                                 "them, added element-wise by zk_g1_sum_winsums_dev, combined per job on the host pool"}[rs["exchange"]],
+                     "exchange": rs["exchange"], "collectives_per_proof": rs["collectives"] // max(steps + args.warmup + (1 if args.check else 0) + rs["kb"], 1),
                      "shard_axis": args.shard_axis,
                      "points_per_rank": rs["points_per_launch"], "accumulate_ms_per_msm": acc_per_msm(rs),
                      "commitments_sha256": rs["digest"]}
@@ -885,13 +1077,16 @@ def main():
         n22 = args.sharded_n22_leg == "on" or (args.sharded_n22_leg == "auto" and log_n == 20 and cv.curve_id == 0)
         if n22 and log_n != 22:
             leg("msm_sharded_n22", shard_leg(22))
+    _LINE["leg"] = None
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(log_n, cv.curve_id, sbits)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        if not _LINE["printed"]:
+            _LINE["printed"] = True
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

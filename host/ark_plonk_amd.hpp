@@ -40,6 +40,14 @@ class Context {
     Context& operator=(const Context&) = delete;
     zk_ctx* handle() const { return h_; }
     void sync() { check(zk_ctx_sync(h_), "zk_ctx_sync"); }
+    // tuning options of the MSM planner (see the header: "msm_merge", "pre_vw", "pre_logg", "chunk_l", "long_rounds", "combine_sg",
+    // "pre_max_log_n"); results never depend on them
+    void set_option(const char* key, int64_t value) { check(zk_ctx_set_option(h_, key, value), "zk_ctx_set_option"); }
+    int64_t get_option(const char* key) const {
+        int64_t v = 0;
+        check(zk_ctx_get_option(h_, key, &v), "zk_ctx_get_option");
+        return v;
+    }
 
   private:
     zk_ctx* h_ = nullptr;
@@ -239,6 +247,26 @@ class CommitterKey {
         uint32_t k = 0;
         check(zk_kzg_round_pending(ctx_->handle(), &k), "zk_kzg_round_pending");
         check(zk_kzg_round_end_partial_dev(ctx_->handle(), k, d_out), "zk_kzg_round_end_partial_dev");
+    }
+    // the same exchange one step earlier (the default of the sharded schedule): every job's 2 VW virtual-window sums, winsums_bytes()
+    // per job, left where the single-GPU path's last reduction kernel writes them; all-gathered; added element-wise
+    size_t winsums_bytes() const { return zk_winsums_dev_bytes(ctx_->handle(), h_); }
+    void round_end_winsums_dev(void* d_out) const {
+        uint32_t k = 0;
+        check(zk_kzg_round_pending(ctx_->handle(), &k), "zk_kzg_round_pending");
+        check(zk_kzg_round_end_winsums_dev(ctx_->handle(), k, d_out), "zk_kzg_round_end_winsums_dev");
+    }
+    std::vector<G1Affine> sum_winsums_dev(const void* d_all, size_t ranks, uint32_t jobs) const {
+        const int L = fq_limbs(curve_);
+        std::vector<uint64_t> xy((size_t)(jobs ? jobs : 1) * 2 * L);
+        std::vector<uint8_t> inf(jobs ? jobs : 1);
+        check(zk_g1_sum_winsums_dev(ctx_->handle(), h_, d_all, ranks, jobs, xy.data(), inf.data()), "zk_g1_sum_winsums_dev");
+        std::vector<G1Affine> out(jobs);
+        for (uint32_t i = 0; i < jobs; ++i) {
+            out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
+            out[i].infinity = inf[i] != 0;
+        }
+        return out;
     }
     // ranks x jobs partials as the all-gather leaves them -> one affine point per job
     std::vector<G1Affine> sum_partials_dev(const void* d_all, size_t ranks, uint32_t jobs) const {

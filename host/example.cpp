@@ -72,6 +72,21 @@ int main(int argc, char** argv) {
             zk::check(zk_dev_free(ctx.handle(), d_parts), "zk_dev_free");
             std::printf("device_partials %s\n", (summed.size() == 2 && summed[0].xy == single.xy && summed[1].xy == single.xy) ? "ok" : "MISMATCH");
         }
+        // ... and its default form: the jobs' virtual-window sums (2 VW points each) stay on the device, one kernel adds the ranks' element-wise,
+        // the host pool combines -- here with a planner option flipped in between (options never change a result)
+        {
+            void* d_ws = nullptr;
+            zk::check(zk_dev_alloc(ctx.handle(), 2 * ck.winsums_bytes(), &d_ws), "zk_dev_alloc");
+            ctx.set_option("msm_merge", 0);
+            ck.commit_begin({&d_coeffs});
+            ck.commit_begin({&d_again});
+            ck.round_end_winsums_dev(d_ws);
+            ctx.set_option("msm_merge", 1);
+            auto summed = ck.sum_winsums_dev(d_ws, 1, 2);
+            zk::check(zk_dev_free(ctx.handle(), d_ws), "zk_dev_free");
+            std::printf("device_winsums %s\n", (ctx.get_option("msm_merge") == 1 && summed.size() == 2 && summed[0].xy == single.xy &&
+                                                summed[1].xy == single.xy) ? "ok" : "MISMATCH");
+        }
         // the unchanged caller's PC::commit(ck, polys): host vectors, one call for the whole slice (prover.rs:213)
         auto host_round = ck.commit({&coeffs, &ev, &coeffs});
         zk::CommitterKey again(ctx, srs);                 // PC::trim on the next gen_proof: the same bytes -> the resident SRS and table

@@ -83,6 +83,22 @@ int zk_io_stats(zk_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset
  * 56 GB/s as pinned memory; 1: through the ctx's pinned staging ring (49 GB/s there; for hosts whose runtime stages pageable
  * copies slowly).  Tuning hook, see tools/pcie_probe.py. */
 int zk_ctx_set_staging(zk_ctx* ctx, int mode);
+/* Tuning options of the MSM planner, per ctx, integers by name (SURVEY.md 5 "runtime ctx options"; until round 4 these were ZK_*
+ * environment variables read inside the hot path).  Results are identical for every value; only launch shapes change.  Keys:
+ *   "msm_merge"      1 (default): one sort / accumulation launch per round for all its deferred jobs; 0: per job at submission
+ *   "pre_vw"         virtual windows of the shared-bucket reduction: 0 = default (64), else a power of two 8 .. 512
+ *   "pre_logg"       log2 buckets per reduction segment: -1 = default, else 0 .. 5
+ *   "chunk_l"        sorted references per accumulation lane: 0 = planned, else 8 .. 1024
+ *   "long_rounds"    rounds of resident lanes given to a non-final job of a merged accumulation launch: 1 (default) .. 16
+ *   "combine_sg"     lanes per small bucket in the combine kernel when a launch has more than two jobs: 0 = default (1), 2, 4
+ *   "pre_max_log_n"  vectors longer than 2^value take the per-window path even over a table: 0 = built-in limit (2^26), 13 .. 25
+ *                    (test hook; the ranks of a window-sharded MSM must agree on it, as on "pre_vw" / "pre_logg" for the
+ *                    window-sum exchange below)
+ * ZK_ERR_UNSUPPORTED: unknown key; ZK_ERR_BAD_ARG: value out of range; ZK_ERR_PENDING: a deferred round is open (a job's plan must
+ * not change between its accumulation and its reduction).  The library reads NO environment variable on a compute path
+ * (ZK_VERBOSE and ZK_HOST_TIMING switch diagnostics on stderr only). */
+int zk_ctx_set_option(zk_ctx* ctx, const char* key, int64_t value);
+int zk_ctx_get_option(zk_ctx* ctx, const char* key, int64_t* value);
 
 /* Per-kernel HIP-event timing (bench.py roofline leg). on = 1: every launch of the hot kernels is bracketed by
  * hipEventRecord on the ctx stream (≈ 200 scopes, ≈ 2 ms per 2^20 proof); on = 2: only the dominant kernel, msm_accumulate
@@ -297,13 +313,30 @@ int zk_kzg_round_abort(zk_ctx* ctx);
  * (zk_g1_sum_partials_dev waits for it).  zk_kzg_round_reduce_partial_dev is zk_kzg_round_reduce for this form (work queued
  * after it runs behind the reductions); zk_kzg_round_end_partial_dev closes the round (queues the reductions itself unless reduce
  * ran; d_out must then be the same buffer).  An all-zero partial is the point at infinity (a rank with an empty shard).
- * ZK_ERR_UNSUPPORTED (the round stays open, close it with zk_kzg_round_end_partial): tables with window_bits >= 18, the commitment
- * cache.  zk_g1_sum_partials_dev: ranks x n_jobs partials as the all-gather leaves them (rank-major) -> n_jobs affine sums;
+ * ZK_ERR_UNSUPPORTED (returned before anything is queued: the round stays open, close it with zk_kzg_round_end_partial): tables with
+ * window_bits >= 18, the commitment cache.  zk_g1_sum_partials_dev: ranks x n_jobs partials as the all-gather leaves them (rank-major) -> n_jobs affine sums;
  * one kernel, one wait, the n_jobs inversions on the host. */
 size_t zk_partial_dev_bytes(int curve_id);
 int zk_kzg_round_reduce_partial_dev(zk_ctx* ctx, void* d_out);
 int zk_kzg_round_end_partial_dev(zk_ctx* ctx, uint32_t n_jobs, void* d_out);
 int zk_g1_sum_partials_dev(zk_ctx* ctx, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
+/* The same exchange one step earlier (round 5; the default of the sharded schedule): a job's result is
+ *   sum_v S_v + B_v * sum_v v * T_v
+ * over the 2 VW virtual-window sums S_v | T_v its last reduction kernel writes (VW = 64 by default: 128 points, 32 KiB for BLS12-381),
+ * and that expression is LINEAR in them.  zk_kzg_round_reduce_winsums_dev / zk_kzg_round_end_winsums_dev close the round with those
+ * sums -- not their combination -- left on the device at d_out + k * zk_winsums_dev_bytes(ctx, srs), written by the reduction kernel
+ * the single-GPU path ends with: no further dependent launch.  The ranks all-gather them and zk_g1_sum_winsums_dev adds the ranks'
+ * sums element-wise (one kernel of n_jobs * 2 VW independent quads, ranks - 1 additions each), waits once, and leaves the one
+ * combine + inversion per job to the ctx's host pool exactly as zk_kzg_round_end does.  Same results, same rules as the form above
+ * (ZK_ERR_UNSUPPORTED before anything is queued: no table, window_bits >= 18, the commitment cache; the round then stays open).  Every
+ * rank must run the same table window and the same "pre_vw" / "pre_logg" options: zk_winsums_geometry returns {window_bits, windows of
+ * a full-width scalar, VW, buckets per virtual window} for the caller to compare across ranks once (the Python schedule all-gathers it
+ * at construction and refuses a mismatch); zk_winsums_dev_bytes is 0 where the form does not exist. */
+size_t zk_winsums_dev_bytes(zk_ctx* ctx, zk_srs* srs);
+int zk_winsums_geometry(zk_ctx* ctx, zk_srs* srs, uint32_t out[4]);
+int zk_kzg_round_reduce_winsums_dev(zk_ctx* ctx, void* d_out);
+int zk_kzg_round_end_winsums_dev(zk_ctx* ctx, uint32_t n_jobs, void* d_out);
+int zk_g1_sum_winsums_dev(zk_ctx* ctx, zk_srs* srs, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
 
 /* ---- a7: KZG10 open (PC::open, prover.rs:582-591,609-618) ------------------------------------- */
 /* p = sum_k challenge^k * polys[k]; witness = (p - p(z)) / (X - z); returns commit(witness).

@@ -14,7 +14,7 @@ res = {}
 for name, (rt, args) in sorted(_lib.SYMBOLS.items()):
     if rt is not ctypes.c_int or not args or args[0] is not ctypes.c_void_p or name == "zk_ctx_create":
         continue
-    vals = [0 if a in (ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_uint8) else None for a in args]
+    vals = [0 if a in (ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint8) else None for a in args]
     print(name, file=sys.stderr, flush=True)            # the last name on stderr is the one that crashed
     res[name] = getattr(L, name)(*vals)
 print(json.dumps(res))

@@ -199,6 +199,39 @@ int main() {
                     TCHECK(zk_kzg_round_end_partial_dev(c, 4, parts) == ZK_OK);
                     TCHECK(zk_g1_sum_partials_dev(c, CURVE, parts, 1, 4, xy, inf) == ZK_OK && inf[0] && inf[3]);
                     TCHECK(zk_dev_free(c, parts) == ZK_OK);
+                    // ... and the window-sum form (round 5): 2 VW sums per job on the device, summed over the ranks, combined by the host pool
+                    {
+                        const size_t wb = zk_winsums_dev_bytes(c, srs);
+                        uint32_t geom[4] = {0, 0, 0, 0};
+                        TCHECK(wb == 2 * 64 * pb && zk_winsums_geometry(c, srs, geom) == ZK_OK && geom[0] == 16 && geom[2] == 64);
+                        void* ws = nullptr;
+                        TCHECK(zk_dev_alloc(c, 2 * 4 * wb, &ws) == ZK_OK);
+                        TCHECK(zk_kzg_round_begin_dev(c, srs, 4, in, lens, nullptr) == ZK_OK);
+                        TCHECK(zk_kzg_round_reduce_winsums_dev(c, ws) == ZK_OK);
+                        TCHECK(zk_kzg_round_end_partial_dev(c, 4, ws) == ZK_ERR_PENDING);          // reduced towards the other form
+                        TCHECK(zk_kzg_round_end_winsums_dev(c, 4, ws) == ZK_OK);
+                        TCHECK(zk_g1_sum_winsums_dev(c, srs, ws, 2, 4, xy, inf) == ZK_OK && inf[0] && inf[3]);
+                        TCHECK(zk_dev_free(c, ws) == ZK_OK);
+                    }
+                    // tuning options: per ctx, refused while a round is open, toggled here between rounds while a second thread of the
+                    // SAME ctx reads them (the ctx lock orders the two; getenv / setenv would have raced)
+                    {
+                        std::thread reader([&] {
+                            for (int r = 0; r < 50; ++r) {
+                                int64_t v = -7;
+                                TCHECK(zk_ctx_get_option(c, "msm_merge", &v) == ZK_OK && (v == 0 || v == 1));
+                                TCHECK(zk_ctx_get_option(c, "pre_vw", &v) == ZK_OK && (v == 0 || v == 32));
+                            }
+                        });
+                        TCHECK(zk_ctx_set_option(c, "msm_merge", it & 1) == ZK_OK);
+                        TCHECK(zk_ctx_set_option(c, "pre_vw", (it & 2) ? 32 : 0) == ZK_OK);
+                        TCHECK(zk_ctx_set_option(c, "no_such_key", 1) == ZK_ERR_UNSUPPORTED && zk_ctx_set_option(c, "pre_vw", 48) == ZK_ERR_BAD_ARG);
+                        TCHECK(zk_kzg_round_begin_dev(c, srs, 2, in, lens, nullptr) == ZK_OK);
+                        TCHECK(zk_ctx_set_option(c, "chunk_l", 64) == ZK_ERR_PENDING);
+                        TCHECK(zk_kzg_round_end(c, 2, xy, inf) == ZK_OK);
+                        reader.join();
+                        TCHECK(zk_ctx_set_option(c, "msm_merge", 1) == ZK_OK && zk_ctx_set_option(c, "pre_vw", 0) == ZK_OK);
+                    }
                     // the commitment cache: second batch is all hits
                     TCHECK(zk_ctx_set_commit_cache(c, 1, 8) == ZK_OK);
                     TCHECK(zk_kzg_commit_batch_dev(c, srs, 4, in, lens, xy, inf) == ZK_OK);

@@ -246,7 +246,7 @@ def test_ntt_four_passes_2_28(ctx):
     assert zk.Radix2EvaluationDomain.new(1 << 33, cid, ctx) is None         # `GeneralEvaluationDomain::new` returns None there too
 
 
-def test_msm_beyond_the_table_path_limit(ctx, oracle_cpu, monkeypatch):
+def test_msm_beyond_the_table_path_limit(ctx, oracle_cpu):
     """A table-path reference holds 26 bits of point index: MSMs of more than 2^26 points over an SRS WITH a table run the
     per-window path inside the same call instead of returning ZK_ERR_UNSUPPORTED (round 3).  The dispatch is exercised with the
     limit lowered through its test hook (a real 2^26-point table is 130 GiB): same commitment on both sides of the limit, single
@@ -265,17 +265,20 @@ def test_msm_beyond_the_table_path_limit(ctx, oracle_cpu, monkeypatch):
     want = ck.msm(d_s)                                            # table path
     assert ctx.profile_get("msm_accumulate_jobs")[1] == 1
     assert_is_scalar_times_g(want, k, cid)
-    monkeypatch.setenv("ZK_PRE_MAX_LOG_N", "15")                   # n = 2^15 + 2 is now beyond the limit
-    ctx.profile_reset()
-    assert ck.msm(d_s) == want
-    assert ck.commit_batch([d_s, d_s[: 1 << 14]], canonical=[True, True])[0] == want
-    ck.commit_begin([d_s], canonical=[True])
-    ck.commit_begin([d_s[: 1 << 14]], canonical=[True])           # this one still takes the table path
-    got = ck.round_end(2)
-    assert got[0] == want
-    assert ctx.profile_get("msm_accumulate_jobs")[1] == 2          # only the two short jobs went through the merged table launch
-    ctx.profile(0)
-    monkeypatch.delenv("ZK_PRE_MAX_LOG_N")
+    try:
+        ctx.set_option("pre_max_log_n", 15)                            # n = 2^15 + 2 is now beyond the limit
+        ctx.profile_reset()
+        assert ck.msm(d_s) == want
+        assert ck.commit_batch([d_s, d_s[: 1 << 14]], canonical=[True, True])[0] == want
+        ck.commit_begin([d_s], canonical=[True])
+        ck.commit_begin([d_s[: 1 << 14]], canonical=[True])           # this one still takes the table path
+        got = ck.round_end(2)
+        assert got[0] == want
+        assert ctx.profile_get("msm_accumulate_jobs")[1] == 2          # only the two short jobs went through the merged table launch
+        ctx.profile(0)
+    finally:
+        ctx.set_option("pre_max_log_n", 0)
+        ctx.profile(0)
     ck.close()
 
 

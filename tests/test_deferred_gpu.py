@@ -231,11 +231,11 @@ def test_schedule_with_hoisted_transforms_gives_the_same_commitments(ctx):
     assert a == d == e == f
 
 
-@pytest.mark.parametrize("merge,long_rounds", [("0", None), ("1", "1"), ("1", "3")])
-def test_round_launch_shapes_give_the_same_points(ctx, monkeypatch, merge, long_rounds):
-    """The tuning hooks the in-process A/B uses (tools/ab_proof.py) select how a round's work is launched: one sort + one accumulation
-    launch per job at submission (ZK_MSM_MERGE=0, the shape before round 4), or one launch per kernel for the whole round with long
-    chunks for all jobs but the last (default) or round 3's chunk length inside the merged launch (ZK_LONG_ROUNDS=3).  Same points
+@pytest.mark.parametrize("merge,long_rounds", [(0, None), (1, 1), (1, 3)])
+def test_round_launch_shapes_give_the_same_points(ctx, merge, long_rounds):
+    """The tuning options the in-process A/B uses (tools/ab_proof.py, zk_ctx_set_option) select how a round's work is launched: one sort +
+    one accumulation launch per job at submission (msm_merge = 0, the shape before round 4), or one launch per kernel for the whole round
+    with long chunks for all jobs but the last (default) or round 3's chunk length inside the merged launch (long_rounds = 3).  Same points
     from every shape, for jobs of different lengths (2^17 + 2^15 points: several rounds of lanes), through begin / reduce / end."""
     cv = zk.get_curve(0)
     n = (1 << 17) + (1 << 15)
@@ -243,16 +243,57 @@ def test_round_launch_shapes_give_the_same_points(ctx, monkeypatch, merge, long_
     polys = _polys(n, 5, 78)
     polys[1] = polys[1][: n - 1]
     polys[3] = polys[3][: 1 << 13]
-    monkeypatch.delenv("ZK_MSM_MERGE", raising=False)
-    monkeypatch.delenv("ZK_LONG_ROUNDS", raising=False)
+    assert ctx.get_option("msm_merge") == 1 and ctx.get_option("long_rounds") == 1          # the defaults
     want = ck.commit_batch(polys)
-    monkeypatch.setenv("ZK_MSM_MERGE", merge)
-    if long_rounds is not None:
-        monkeypatch.setenv("ZK_LONG_ROUNDS", long_rounds)
-    assert ck.commit_batch(polys) == want
-    ck.commit_begin(polys[:2])
-    ck.commit_begin(polys[2:3])
-    ck.commit_begin(polys[3:])
-    ck.round_reduce()
-    assert ck.round_end(5) == want
+    try:
+        ctx.set_option("msm_merge", merge)
+        if long_rounds is not None:
+            ctx.set_option("long_rounds", long_rounds)
+        assert ck.commit_batch(polys) == want
+        ck.commit_begin(polys[:2])
+        ck.commit_begin(polys[2:3])
+        with pytest.raises(RuntimeError):
+            ctx.set_option("msm_merge", 1 - merge)        # a round is open: the plan of its jobs must not change (ZK_ERR_PENDING)
+        ck.commit_begin(polys[3:])
+        ck.round_reduce()
+        assert ck.round_end(5) == want
+    finally:
+        ctx.set_option("msm_merge", 1)
+        ctx.set_option("long_rounds", 1)
+    ck.close()
+
+
+def test_ctx_options_api(ctx):
+    """zk_ctx_set_option / zk_ctx_get_option: every key of the header round-trips, unknown keys and out-of-range values are refused,
+    and the reduction-geometry options change launch shapes only (same points)."""
+    from ark_plonk_amd import _lib
+    L = _lib.lib()
+    import ctypes
+    for key in ctx.OPTIONS:
+        old = ctx.get_option(key)
+        assert old == {"msm_merge": 1, "pre_logg": -1, "long_rounds": 1}.get(key, 0)
+    assert L.zk_ctx_set_option(ctx.handle, b"no_such_key", 1) == _lib.ZK_ERR_UNSUPPORTED
+    v = ctypes.c_int64()
+    assert L.zk_ctx_get_option(ctx.handle, b"no_such_key", ctypes.byref(v)) == _lib.ZK_ERR_UNSUPPORTED
+    for key, bad in (("pre_vw", 48), ("pre_vw", 4), ("chunk_l", 4), ("combine_sg", 3), ("pre_max_log_n", 12), ("pre_max_log_n", 26), ("long_rounds", 0),
+                     ("msm_merge", 2), ("pre_logg", 6)):
+        assert L.zk_ctx_set_option(ctx.handle, key.encode(), bad) == _lib.ZK_ERR_BAD_ARG, (key, bad)
+    assert L.zk_ctx_set_option(None, b"pre_vw", 64) == _lib.ZK_ERR_BAD_ARG and L.zk_ctx_set_option(ctx.handle, None, 64) == _lib.ZK_ERR_BAD_ARG
+    cv = zk.get_curve(0)
+    n = 1 << 15
+    ck = _ck(ctx, cv, n, seed=91).precompute()
+    polys = _polys(n, 3, 92)
+    want = ck.commit_batch(polys)
+    try:
+        for opts in ({"pre_vw": 32, "pre_logg": 3}, {"pre_vw": 128, "pre_logg": 2}, {"chunk_l": 48}, {"combine_sg": 4}, {"combine_sg": 2}):
+            for k, val in opts.items():
+                ctx.set_option(k, val)
+                assert ctx.get_option(k) == val
+            assert ck.commit_batch(polys) == want, opts
+            for k in opts:
+                ctx.set_option(k, -1 if k == "pre_logg" else 0)
+    finally:
+        for k in ("pre_vw", "chunk_l", "combine_sg"):
+            ctx.set_option(k, 0)
+        ctx.set_option("pre_logg", -1)
     ck.close()

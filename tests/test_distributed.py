@@ -149,6 +149,15 @@ def test_bench_two_ranks_matches_one_rank():
     assert d1["commitments_sha256"] == d4["commitments_sha256"]
     d5 = two_ranks(["--mode", "shard", "--shard-axis", "windows", "--host-partials"])
     assert d1["commitments_sha256"] == d5["commitments_sha256"]
+    # the three forms of the exchange: window sums (default), one point per job (round 4), host Jacobians (round 3)
+    assert "'winsums'" in d3["config"]["parallelism"] and "'winsums'" in d4["config"]["parallelism"] and "'host'" in d5["config"]["parallelism"]
+    d6 = two_ranks(["--mode", "shard", "--exchange", "point"])
+    assert "'point'" in d6["config"]["parallelism"] and d1["commitments_sha256"] == d6["commitments_sha256"]
+    # every N > 1 line says what the backend saw: two processes, ONE card here (a gloo rehearsal), the all-reduced sum of ones
+    for d in (d2, d3, d4, d5, d6):
+        rk = d["ranks"]
+        assert rk["world"] == 2 and rk["sum_check"] == 2 and rk["distinct_devices"] == 1 and rk["shared_card"] is True and len(rk["devices"]) == 2
+    assert "ranks" not in d1
 
 
 def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
@@ -292,8 +301,8 @@ def test_all_gather_partials_dev_world2_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("on_device", [True, False])
-def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, on_device, monkeypatch):
+@pytest.mark.parametrize("exchange", ["winsums", "point", "host"])
+def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, exchange, monkeypatch):
     """ProofSchedule with world = 2 and a `dist` that reports backend "nccl": the partials of every group of PC calls must enter
     the collective as int64 tensors on the rank's GPU (RCCL cannot take host tensors), one all_gather per group; with both "ranks"
     contributing this rank's shard the result is twice the shard's commitment.
@@ -316,14 +325,16 @@ def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, on_device, mo
     ck_full = zk.CommitterKey(bases, cv, ctx).precompute()
     ck_shard = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()      # rank 0 of 2 owns SRS[0, n/2)
     d = _StubDist("nccl", 2)
-    sched = ProofSchedule(log_n, ctx, ck_shard, cv, rank=0, world=2, dist=d, partials_on_device=on_device)
-    assert sched.partials_on_device is on_device
+    on_device = exchange != "host"
+    sched = ProofSchedule(log_n, ctx, ck_shard, cv, rank=0, world=2, dist=d, exchange=exchange)
+    assert sched.partials_on_device is on_device and sched.exchange == exchange
     host_calls = []
     real_end_partial = ck_shard.round_end_partial
     monkeypatch.setattr(ck_shard, "round_end_partial", lambda *a, **k: (host_calls.append(1), real_end_partial(*a, **k))[1])
     out = sched.run_once(proof_id=0)
     assert len(out) == 29 and len(d.calls) == 5 and sched.collectives == 5       # five groups of PC calls, one collective each
-    words = ck_shard.partial_dev_words() if on_device else 3 * cv.fq_limbs
+    words = {"winsums": ck_shard.winsums_dev_words(), "point": ck_shard.partial_dev_words(), "host": 3 * cv.fq_limbs}[exchange]
+    assert ck_shard.winsums_dev_words() == 2 * ck_shard.winsums_geometry()[2] * ck_shard.partial_dev_words() == 4096      # 128 points x 256 B
     for kind, odev, idev, odt, idt, oshape, ishape in d.calls:
         assert odev.type == idev.type == "cuda" and odev.index == idev.index == ctx.device and odt == idt == torch.int64
         assert ishape[0] % words == 0 and oshape == (2 * ishape[0],)
@@ -390,19 +401,20 @@ def _worker_rccl_world1(port, q):
         _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
         ck = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()
         res = {}
-        for on_device in (True, False):
+        for exchange in ("winsums", "point", "host"):
+            on_device = exchange != "host"
             TwoRowsOverRccl.calls = []
-            sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=2, dist=TwoRowsOverRccl, partials_on_device=on_device)
+            sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=2, dist=TwoRowsOverRccl, exchange=exchange)
             out = sched.run_once(proof_id=0)
             two = zk.msm.sum_partials(np.stack([ck.commit_batch_partial([sched.coef[0][: n // 2]])[0]] * 2), 0)
-            res[on_device] = dict(n=len(out), collectives=sched.collectives, calls=len(TwoRowsOverRccl.calls),
+            res[exchange] = dict(n=len(out), collectives=sched.collectives, calls=len(TwoRowsOverRccl.calls),
                                   devices=sorted({c[2] for c in TwoRowsOverRccl.calls}), first_ok=(out[0] == two),
                                   from_pbuf=all(c[0] == sched._pbuf.data_ptr() for c in TwoRowsOverRccl.calls) if on_device else None,
                                   points=[(pt.infinity, [int(v) for v in pt.x], [int(v) for v in pt.y]) for pt in out])
         ck.close()
         ctx.close()
         dist.destroy_process_group()
-        q.put(("ok", res[True], res[False]))
+        q.put(("ok", res["point"], res["host"], res["winsums"]))
     except BaseException as e:      # the parent reports it
         import traceback
         q.put(("error", repr(e), traceback.format_exc()[-3000:]))
@@ -432,11 +444,11 @@ def test_schedule_exchange_over_real_rccl_world1():
     if got[0] == "no_rccl":
         pytest.skip(f"RCCL did not come up on this box: {got[1]}")
     assert got[0] == "ok", got[1:]
-    dev, host = got[1], got[2]
-    for r in (dev, host):
+    dev, host, ws = got[1], got[2], got[3]
+    for r in (dev, host, ws):
         assert r["n"] == 29 and r["collectives"] == 5 and r["calls"] == 5 and r["devices"] == ["cuda:0"] and r["first_ok"]
-    assert dev["from_pbuf"] is True
-    assert dev["points"] == host["points"]
+    assert dev["from_pbuf"] is True and ws["from_pbuf"] is True
+    assert dev["points"] == host["points"] == ws["points"]
 
 
 @pytest.mark.gpu
@@ -496,3 +508,211 @@ def test_config3_size_two_concurrent_ranks_with_a_collective():
     d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and "2^22" in d2["metric"]
     assert d1["commitments_sha256"] == d2["commitments_sha256"]
+
+
+@pytest.mark.gpu
+def test_winsums_form_with_short_and_empty_jobs(ctx):
+    """The window-sum form of a round's result (round 5: zk_kzg_round_end_winsums_dev + zk_g1_sum_winsums_dev) with every kind of job:
+    table path, a vector too short for it (computed at begin: S_0 = the point, every other sum infinite), the point at infinity
+    (all-zero scalars); one "rank" = the blocking batch, two equal "ranks" = twice the commitment as the host form computes it."""
+    import torch
+    import ark_plonk_amd as zk
+    from ark_plonk_amd import _lib
+    cv = zk.get_curve(0)
+    n = 1 << 14
+    rng = np.random.default_rng(78)
+    ks = torch.from_numpy(rng.integers(1, 1 << 62, size=(n, 4), dtype=np.uint64).view(np.int64)).cuda()
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
+    ck = zk.CommitterKey(bases, cv, ctx).precompute()
+    c_bits, W, VW, VB = ck.winsums_geometry()
+    assert VW * VB == 1 << (c_bits - 1) and VW == 64
+    polys = [torch.from_numpy(rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64).view(np.int64)).cuda() for m in (n, 100, n - 1)]
+    polys.append(torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
+    want = ck.commit_batch(polys)
+    ww = ck.winsums_dev_words()
+    assert ww == 2 * VW * ck.partial_dev_words()
+    buf = torch.full((len(polys), ww), -1, dtype=torch.int64, device="cuda")
+    for p in polys:
+        ck.commit_begin([p])
+    ck.round_reduce_winsums_dev(buf)
+    with pytest.raises(RuntimeError):
+        ck.round_end(len(polys))                          # reduced towards the device: the host form refuses, the round stays open
+    with pytest.raises(RuntimeError):
+        ck.round_end_partial_dev(buf, len(polys))         # ... and so does the other device form
+    ck.round_end_winsums_dev(buf, len(polys))
+    got = ck.sum_winsums_dev(buf.reshape(1, -1), 1, len(polys))
+    assert got == want and got[3].infinity
+    two = ck.sum_winsums_dev(torch.cat([buf.reshape(1, -1)] * 2), 2, len(polys))
+    host2 = zk.sum_partials_batch(np.stack([ck.commit_batch_partial(polys)] * 2), 0)
+    assert two == host2
+    # three ranks whose sums cancel pairwise where they can: rank rows [P, P, 0] -> 2P again, through another row order
+    zero = torch.zeros_like(buf.reshape(1, -1))
+    assert ck.sum_winsums_dev(torch.cat([buf.reshape(1, -1), zero, buf.reshape(1, -1)]), 3, len(polys)) == host2
+    # the geometry is part of the contract between the ranks: another virtual-window count changes the buffer size
+    ctx.set_option("pre_vw", 32)
+    try:
+        assert ck.winsums_dev_words() == ww // 2 and ck.winsums_geometry()[2] == 32
+        buf32 = torch.zeros((2, ww // 2), dtype=torch.int64, device="cuda")
+        ck.commit_begin(polys[:2])
+        ck.round_end_winsums_dev(buf32, 2)
+        assert ck.sum_winsums_dev(buf32.reshape(1, -1), 1, 2) == want[:2]
+    finally:
+        ctx.set_option("pre_vw", 0)
+    ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["point", "winsums"])
+def test_device_forms_refused_before_anything_is_queued_c18(ctx, form):
+    """a table with window_bits >= 18 finishes its reduction towards the host only.  The device forms must say
+    ZK_ERR_UNSUPPORTED BEFORE the sort and the merged accumulation of the round's deferred jobs are queued -- otherwise the fall-back
+    the header names (zk_kzg_round_end_partial) re-plans jobs that already ran with the long-chunk plan and combines their
+    chunk-edge partials wrongly.  Two and three jobs at 2^18 (several rounds of lanes: long chunks differ from short ones)."""
+    import torch
+    import ark_plonk_amd as zk
+    from ark_plonk_amd import _lib
+    cv = zk.get_curve(0)
+    n = 1 << 18
+    rng = np.random.default_rng(79)
+    ks = torch.from_numpy(rng.integers(1, 1 << 62, size=(n, 4), dtype=np.uint64).view(np.int64)).cuda()
+    ks[:, 1:] = 0
+    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.use_torch_stream()
+    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
+    ck = zk.CommitterKey(bases, cv, ctx).precompute(18)
+    assert ck.table_window_bits() == 18 and ck.winsums_geometry() is None and ck.winsums_dev_words() == 0
+    polys = [torch.from_numpy(rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64).view(np.int64)).cuda() for m in (n, n - 1, n)]
+    want = ck.commit_batch(polys)
+    want_parts = ck.commit_batch_partial(polys)
+    buf = torch.zeros((3, 4096), dtype=torch.int64, device="cuda")
+    L = _lib.lib()
+    end_dev = L.zk_kzg_round_end_partial_dev if form == "point" else L.zk_kzg_round_end_winsums_dev
+    red_dev = L.zk_kzg_round_reduce_partial_dev if form == "point" else L.zk_kzg_round_reduce_winsums_dev
+    for k in (2, 3):
+        ck.commit_begin(polys[:k])
+        assert red_dev(ctx.handle, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED
+        assert end_dev(ctx.handle, k, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED
+        assert ck.round_pending() == k                                    # the round is as it was
+        parts = ck.round_end_partial(k)                                   # the fall-back the header names
+        assert np.array_equal(parts, want_parts[:k])
+        ck.commit_begin(polys[:k])
+        assert end_dev(ctx.handle, k, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED
+        assert ck.round_end(k) == want[:k]
+    ck.close()
+
+
+def _run_bench(args, timeout, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(env_extra or {})
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines, time.monotonic() - t0
+
+
+def test_bench_rehearsal_8_ranks_gloo():
+    """`bench.py --gpus 8` as the driver will start it -- eight processes, rendezvous on 127.0.0.1, the `ranks` handshake, barriers, the
+    max-over-ranks clock, five all-gathers per proof of the sharded exchange's real shapes (4|3|2|4|16 jobs x 32 KiB) with every
+    rank checking every row -- without a GPU and without compute (--rehearse; gloo).  One line, rc 0, bounded wall time."""
+    r, lines, wall = _run_bench(["--gpus", "8", "--backend", "gloo", "--rehearse", "--steps", "3", "--warmup", "1"], 240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1 and wall < 120
+    d = lines[0]
+    assert d["rehearsal"] is True and d["value"] is None and d["n_gpus"] == 8 and d["collectives_per_step"] == 5
+    rk = d["ranks"]
+    assert rk["world"] == 8 and rk["sum_check"] == 8 and rk["backend"] == "gloo" and len(rk["devices"]) == 8
+    assert [x.split(":")[0] for x in rk["devices"]] == [str(i) for i in range(8)]
+    assert d["bytes_per_rank_per_step"] == 29 * 32768
+
+
+@pytest.mark.parametrize("where", ["step", "leg"])
+def test_bench_rehearsal_killed_rank_ends_the_job(where):
+    """One of eight ranks dies between two collectives (os._exit, no clean-up): the job ends non-zero within a bound -- nobody hangs in
+    an all_gather.  Killed inside an extra leg (after the headline region was timed), rank 0 still prints the line it has, marked."""
+    r, lines, wall = _run_bench(["--gpus", "8", "--backend", "gloo", "--rehearse", "--steps", "3", "--warmup", "1", "--fault-rank", "5",
+                                 "--fault-at", where, "--dist-timeout", "60"], 240)
+    assert r.returncode != 0 and wall < 90, (r.returncode, wall)
+    assert "exitcode: 41" in r.stderr or "exitcode  : 41" in r.stderr
+    if where == "step":
+        assert lines == []                                     # no value existed yet: nothing may be printed
+    else:
+        assert len(lines) == 1 and lines[0]["aborted_in_leg"] == "rehearsal_leg" and lines[0]["ranks"]["world"] == 8
+
+
+def test_bench_nccl_refuses_ranks_without_a_card_each():
+    """Backend nccl with more ranks on the host than visible GPUs: every rank exits 2 BEFORE the rendezvous (no `local_rank % n_dev`
+    folding onto one card, nobody left waiting).  Here: two ranks, no GPU at all."""
+    r, lines, wall = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], 120,
+                                {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2", "MASTER_PORT": str(_free_port()),
+                                 "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode == 2 and lines == [] and "one GPU per rank" in r.stderr and wall < 60
+
+
+def test_ranks_handshake_counts_distinct_devices():
+    """The `ranks` object: distinct (host, device) pairs, the all-reduced sum, rank order -- with a stub dist that plays four ranks
+    of which two share a card."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class D:
+        class ReduceOp:
+            SUM = "sum"
+
+        @staticmethod
+        def all_gather_object(out, me):
+            devs = ["0000:05:00", "0000:15:00", "0000:15:00", "0000:25:00"]
+            for r in range(4):
+                out[3 - r] = dict(me, rank=r, local_rank=r, device=devs[r], pid=100 + r)      # arrives in any order
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            t.mul_(4)
+
+    info = bench.ranks_handshake(D, torch, "gloo", 4, 0, 0, None)
+    assert info["world"] == 4 and info["sum_check"] == 4 and info["distinct_devices"] == 3 and info["shared_card"] is True
+    assert [d.split(":")[0] for d in info["devices"]] == ["0", "1", "2", "3"] and info["hosts"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_gpus_4_one_card():
+    """The driver's N > 1 command on this box's ONE card: `bench.py --gpus 4 --backend gloo` (four ranks + this process = five on the
+    card, inside the pool's process guard; eight ranks are rehearsed without the GPU above).  Replicas with the msm_sharded leg riding
+    along, then the sharded form as the headline on both axes: the 29 commitments equal the single rank's, the line says what the
+    backend saw, wall time bounded."""
+    common = ["--log-n", "13", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--check"]
+    r1, l1, _ = _run_bench(common, 600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = l1[-1]
+    r4, l4, wall = _run_bench(common + ["--gpus", "4", "--backend", "gloo"], 900)
+    assert r4.returncode == 0, r4.stderr[-3000:]
+    assert len(l4) == 1 and wall < 600
+    d4 = l4[0]
+    assert d4["n_gpus"] == 4 and d4["scaling"] == "weak" and d4["commitments_sha256"] == d1["commitments_sha256"]
+    assert d4["ranks"]["world"] == 4 and d4["ranks"]["sum_check"] == 4 and d4["ranks"]["distinct_devices"] == 1
+    ms = d4["msm_sharded"]
+    assert ms.get("commitments_match_replicas") is True and ms["exchange"] == "winsums" and ms["collectives_per_proof"] == 5, ms
+    for axis in ("points", "windows"):
+        r, l, _ = _run_bench(common + ["--gpus", "4", "--backend", "gloo", "--mode", "shard", "--shard-axis", axis], 900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert l[-1]["scaling"] == "strong" and l[-1]["commitments_sha256"] == d1["commitments_sha256"], axis
+
+
+@pytest.mark.gpu
+def test_bench_killed_rank_inside_the_sharded_leg():
+    """Three ranks on the card, rank 1 dies at the start of the msm_sharded leg (after the replicas' headline region): the job ends
+    non-zero within a bound and rank 0's line -- the headline it had already measured -- is printed with `aborted_in_leg`."""
+    r, lines, wall = _run_bench(["--log-n", "13", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--gpus", "3", "--backend", "gloo",
+                                 "--fault-rank", "1", "--dist-timeout", "60"], 600)
+    assert r.returncode != 0 and wall < 300, (r.returncode, wall)
+    assert len(lines) == 1 and lines[0]["aborted_in_leg"] == "msm_sharded" and lines[0]["value"] > 0 and lines[0]["n_gpus"] == 3

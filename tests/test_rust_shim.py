@@ -19,7 +19,7 @@ def _c_class(ctype: str) -> str:
     t = ctype.replace("const", " ").replace("[4]", "*").replace("[]", "*")
     depth = t.count("*")
     base = t.replace("*", " ").split()[0]
-    widths = {"int": "i32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "char": "i8",
+    widths = {"int": "i32", "int64_t": "i64", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "char": "i8",
               "void": "void"}
     b = widths.get(base, "struct:" + base)
     return "ptr" * 0 + ("p" * depth + ":" + b if depth else b)

@@ -1,11 +1,13 @@
-"""A/B of library tuning hooks INSIDE one process: the pool's boxes drift by several per cent with their power state (a box is
+"""A/B of library tuning options INSIDE one process: the pool's boxes drift by several per cent with their power state (a box is
 slower right after a long run: tools/power_probe.py), so two bench.py runs one after the other cannot resolve a 1 % effect.  Here one
 SRS, one table and one schedule serve every configuration; the configurations alternate proof by proof and the report is the
 per-configuration median plus the paired differences against the first one.
 
-  python tools/ab_proof.py --pairs 12 ZK_MSM_MERGE=0 ZK_MSM_MERGE=1 "ZK_MSM_MERGE=1 ZK_LONG_ROUNDS=3"
+  python tools/ab_proof.py --pairs 12 msm_merge=0 msm_merge=1 "msm_merge=1 long_rounds=3"
 
-Each configuration is a space-separated list of VAR=VALUE (hooks the library reads at every call)."""
+Each configuration is a space-separated list of option=value -- the keys of zk_ctx_set_option (include/ark_plonk_amd.h), set on the
+ctx between proofs (never while a round is open); the ZK_* environment spellings of rounds 2-4 are accepted and mapped
+(ZK_MSM_MERGE=0 -> msm_merge=0): the library itself no longer reads the environment.  SCHED.name=value: a ProofSchedule keyword."""
 import argparse
 import os
 import statistics
@@ -28,11 +30,13 @@ def main():
     from ark_plonk_amd.prover_schedule import ProofSchedule
     from bench import build_srs
 
-    # VAR=VALUE: an environment hook of the library; SCHED.name=value: a keyword of ProofSchedule (one schedule object per distinct set)
+    # option=value: a tuning option of the ctx; SCHED.name=value: a keyword of ProofSchedule (one schedule object per distinct set)
     def conv(v):
         return {"True": True, "False": False}.get(v, int(v) if v.lstrip("-").isdigit() else v)
     raw = [dict(kv.split("=", 1) for kv in c.split()) for c in args.configs]
-    cfgs = [{k: v for k, v in c.items() if not k.startswith("SCHED.")} for c in raw]
+    def opt_key(k):
+        return k[3:].lower() if k.startswith("ZK_") else k
+    cfgs = [{opt_key(k): int(v) for k, v in c.items() if not k.startswith("SCHED.")} for c in raw]
     sched_kw = [tuple(sorted((k[6:], conv(v)) for k, v in c.items() if k.startswith("SCHED."))) for c in raw]
     keys = sorted({k for c in cfgs for k in c})
     ctx = zk.Context(0)
@@ -45,10 +49,11 @@ def main():
     ck.precompute(0)
     scheds = {kw: ProofSchedule(args.log_n, ctx, ck, cv, defer_calls=not args.block_every_call, **dict(kw)) for kw in set(sched_kw)}
 
+    defaults = {k: ctx.get_option(k) for k in keys}
+
     def use(c):
         for k in keys:
-            os.environ.pop(k, None)
-        os.environ.update(c)
+            ctx.set_option(k, c.get(k, defaults[k]))
 
     import hashlib
     digs = []

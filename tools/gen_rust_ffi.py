@@ -20,7 +20,7 @@ OUT = os.path.join(ROOT, "rust-shim", "plonk-gpu-sys", "src", "lib.rs")
 
 # C scalar -> Rust
 SCALAR = {
-    "int": "i32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
+    "int": "i32", "int64_t": "i64", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
     "char": "c_char", "void": "c_void",
 }
 OPAQUE = {"zk_ctx": "ZkCtx", "zk_srs": "ZkSrs", "zk_transcript": "ZkTranscript"}

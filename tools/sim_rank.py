@@ -1,8 +1,9 @@
 """Per-rank compute time of the sharded schedule, measured on ONE GPU: runs rank 0 of a world
 of W with a stand-in for torch.distributed whose all_gather returns W copies of the local tensor.
 No communication is timed -- this shows where a rank's time goes (NTT replica, MSM shard, reductions) for both shard axes
-(points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and both forms of the
-exchange (device-resident partials: zk_kzg_round_end_partial_dev + zk_g1_sum_partials_dev; host Jacobian partials: round 3's).
+(points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and the three forms of the
+exchange (winsums: the jobs' virtual-window sums, zk_kzg_round_end_winsums_dev + zk_g1_sum_winsums_dev; point: one device-resident point
+per job, zk_kzg_round_end_partial_dev + zk_g1_sum_partials_dev; host: round 3's Jacobian partials through the host).
 AN ESTIMATE, NOT A MEASUREMENT of N GPUs.
 
 usage: python tools/sim_rank.py [W ...]
@@ -48,7 +49,7 @@ def main():
         for axis in ("points", "windows"):
             if w == 1 and axis == "windows":
                 continue
-            for on_device in ((True,) if w == 1 else (True, False)):
+            for exchange in (("-",) if w == 1 else ("winsums", "point", "host")):
                 if axis == "points":
                     srs = build_srs(ctx, cv, n, 0, n // w, torch)
                     ck = zk.CommitterKey(srs, cv, ctx).precompute()
@@ -57,21 +58,21 @@ def main():
                     ck = zk.CommitterKey(srs, cv, ctx).precompute(rows=(0, w))
                 del srs
                 sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None, shard_axis=axis,
-                                      partials_on_device=on_device)
+                                      exchange=None if w == 1 else exchange)
                 sched.run_once()
                 torch.cuda.synchronize()
                 ctx.profile(True)
                 ctx.profile_reset()
-                steps = 3
+                steps = int(os.environ.get("STEPS", "5"))
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     sched.run_once()
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / steps * 1e3
                 ctx.profile(False)
-                parts = {k: ctx.profile_get(k)[0] / steps for k in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt_pass", "kzg_open_prep")}
-                form = "-" if w == 1 else ("device partials" if on_device else "host partials")
-                print(f"world={w} axis={axis:7s} exchange={form:15s}: {dt:6.2f} ms/step  " + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
+                parts = {k: ctx.profile_get(k)[0] / steps for k in ("msm_accumulate", "msm_sort", "msm_reduce", "msm_sum_winsums", "ntt_pass", "kzg_open_prep")}
+                form = exchange
+                print(f"world={w} axis={axis:7s} exchange={form:8s}: {dt:6.2f} ms/step  " + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
                 ck.close()
                 del sched
 

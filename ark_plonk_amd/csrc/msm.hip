@@ -2489,18 +2489,30 @@ int sum_partials_dev(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jo
 
 // element-wise sum over the ranks of every job's 2 VW virtual-window sums (ranks x n_jobs x 2 VW points as the all-gather leaves
 // them) -> n_jobs x 2 VW points in the arkworks layout in pinned host memory, where the single-GPU path's last reduction kernel
-// puts them: one quad per (job, sum), ranks - 1 dependent additions each, 2 VW n_jobs quads side by side -- throughput-shaped
+// puts them.  Q = 2^logq quads share one sum: quad j adds the ranks j, j + Q, ... (ranks / Q - 1 dependent additions), an LDS tree
+// adds the Q partial sums (logq more): 3 dependent additions for 8 ranks instead of 7 -- the launch is latency-shaped (2 VW n_jobs
+// points, at most a few thousand quads), so the chain is what it costs.
 template <class F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) g1_sum_winsums_q(const void* all, uint32_t ranks, uint32_t n_pts /* n_jobs * 2 VW */,
-                                                                                                     uint32_t* out_sat) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t k = tid >> 2, role = tid & 3;
-    const bool live = k < n_pts;                   // no early exit: wave shuffles inside qadd
+                                                                                                     uint32_t logq, uint32_t* out_sat) {
+    extern __shared__ uint4 sh[];
+    const uint32_t Q = 1u << logq;
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    const uint32_t per_block = (blockDim.x >> 2) >> logq;                      // points per workgroup
+    const uint32_t k = blockIdx.x * per_block + (quad >> logq), j = quad & (Q - 1);
+    const bool live = k < n_pts;                   // no early exit: wave shuffles inside qadd, barriers below
     F acc = F::zero();
 #pragma unroll 1
-    for (uint32_t r = 0; r < ranks; ++r) acc = qadd<F>(acc, live ? ld_coord<F>(all, (uint64_t)r * n_pts + k, role) : F::zero(), role);
+    for (uint32_t r = j; r < ranks; r += Q) acc = qadd<F>(acc, live ? ld_coord<F>(all, (uint64_t)r * n_pts + k, role) : F::zero(), role);
+    for (uint32_t d = Q >> 1; d >= 1; d >>= 1) {
+        st_coord<F>(sh, quad, role, acc);
+        __syncthreads();
+        const F o = j < d ? ld_coord<F>(sh, quad + d, role) : F::zero();
+        __syncthreads();
+        acc = qadd<F>(acc, o, role);               // quads with j >= d add the point at infinity: uniform control flow
+    }
     const bool inf = quad_is_inf(acc, role);
-    if (live) {
+    if (live && j == 0) {
         uint32_t* o = out_sat + (size_t)k * 4 * F::SAT + role * F::SAT;
         if (inf) {
             for (int i = 0; i < F::SAT; ++i) o[i] = 0;
@@ -2798,7 +2810,12 @@ int sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint3
     const uint32_t n_pts = n_jobs * 2 * VW;
     {
         ProfScope ps(c, "msm_sum_winsums", c->stream);
-        hipLaunchKernelGGL(g1_sum_winsums_q<F>, dim3((n_pts * 4 + 255) / 256), dim3(256), 0, c->stream, d_all, (uint32_t)ranks, n_pts, (uint32_t*)c->pinned);
+        constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+        uint32_t logq = 0;                                    // quads per sum: half the ranks (rounded up to a power of two), at most 16
+        while (logq < 4 && (2u << logq) < ranks) ++logq;
+        const uint32_t per_block = 64u >> logq;
+        hipLaunchKernelGGL(g1_sum_winsums_q<F>, dim3((n_pts + per_block - 1) / per_block), dim3(256), 64 * PT, c->stream, d_all, (uint32_t)ranks, n_pts, logq,
+                           (uint32_t*)c->pinned);
         ZK_HIP_TRY(hipGetLastError());
     }
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));

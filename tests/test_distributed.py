@@ -586,7 +586,6 @@ def test_device_forms_refused_before_anything_is_queued_c18(ctx, form):
     assert ck.table_window_bits() == 18 and ck.winsums_geometry() is None and ck.winsums_dev_words() == 0
     polys = [torch.from_numpy(rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64).view(np.int64)).cuda() for m in (n, n - 1, n)]
     want = ck.commit_batch(polys)
-    want_parts = ck.commit_batch_partial(polys)
     buf = torch.zeros((3, 4096), dtype=torch.int64, device="cuda")
     L = _lib.lib()
     end_dev = L.zk_kzg_round_end_partial_dev if form == "point" else L.zk_kzg_round_end_winsums_dev
@@ -597,7 +596,8 @@ def test_device_forms_refused_before_anything_is_queued_c18(ctx, form):
         assert end_dev(ctx.handle, k, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED
         assert ck.round_pending() == k                                    # the round is as it was
         parts = ck.round_end_partial(k)                                   # the fall-back the header names
-        assert np.array_equal(parts, want_parts[:k])
+        # a Jacobian triple is not canonical (its Z depends on the order of the additions): compare the points
+        assert [zk.sum_partials(parts[j:j + 1], 0) for j in range(k)] == want[:k]
         ck.commit_begin(polys[:k])
         assert end_dev(ctx.handle, k, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED
         assert ck.round_end(k) == want[:k]

@@ -45,36 +45,51 @@ def main():
     ctx = zk.Context(0)
     ctx.use_torch_stream()
     cv = zk.get_curve("bls12_381")
+    import statistics
+    visits = int(os.environ.get("VISITS", "6"))
+    per_visit = int(os.environ.get("STEPS", "2"))
     for w in worlds:
         for axis in ("points", "windows"):
             if w == 1 and axis == "windows":
                 continue
-            for exchange in (("-",) if w == 1 else ("winsums", "point", "host")):
-                if axis == "points":
-                    srs = build_srs(ctx, cv, n, 0, n // w, torch)
-                    ck = zk.CommitterKey(srs, cv, ctx).precompute()
-                else:
-                    srs = build_srs(ctx, cv, n, 0, n, torch)
-                    ck = zk.CommitterKey(srs, cv, ctx).precompute(rows=(0, w))
-                del srs
-                sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None, shard_axis=axis,
-                                      exchange=None if w == 1 else exchange)
-                sched.run_once()
-                torch.cuda.synchronize()
+            if axis == "points":
+                srs = build_srs(ctx, cv, n, 0, n // w, torch)
+                ck = zk.CommitterKey(srs, cv, ctx).precompute()
+            else:
+                srs = build_srs(ctx, cv, n, 0, n, torch)
+                ck = zk.CommitterKey(srs, cv, ctx).precompute(rows=(0, w))
+            del srs
+            forms = ("-",) if w == 1 else ("winsums", "point", "host")
+            # the forms ALTERNATE visit by visit over one key and one set of inputs (a box drifts by several per cent with its power
+            # state: configurations measured one after the other cannot resolve the ~2 % between the forms)
+            scheds = {f: ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None, shard_axis=axis,
+                                       exchange=None if w == 1 else f) for f in forms}
+            for f in forms:
+                scheds[f].run_once()
+            torch.cuda.synchronize()
+            times = {f: [] for f in forms}
+            for _ in range(visits):
+                for f in forms:
+                    scheds[f].run_once()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(per_visit):
+                        scheds[f].run_once()
+                    torch.cuda.synchronize()
+                    times[f].append((time.perf_counter() - t0) / per_visit * 1e3)
+            for f in forms:
                 ctx.profile(True)
                 ctx.profile_reset()
-                steps = int(os.environ.get("STEPS", "5"))
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    sched.run_once()
+                for _ in range(2):
+                    scheds[f].run_once()
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / steps * 1e3
                 ctx.profile(False)
-                parts = {k: ctx.profile_get(k)[0] / steps for k in ("msm_accumulate", "msm_sort", "msm_reduce", "msm_sum_winsums", "ntt_pass", "kzg_open_prep")}
-                form = exchange
-                print(f"world={w} axis={axis:7s} exchange={form:8s}: {dt:6.2f} ms/step  " + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
-                ck.close()
-                del sched
+                parts = {k: ctx.profile_get(k)[0] / 2 for k in ("msm_accumulate", "msm_sort", "msm_reduce", "msm_sum_winsums", "ntt_pass", "kzg_open_prep")}
+                t = times[f]
+                print(f"world={w} axis={axis:7s} exchange={f:8s}: median {statistics.median(t):6.2f}  min {min(t):6.2f} ms/step over {visits} alternating visits x {per_visit}  | "
+                      + "  ".join(f"{k}={v:.2f}" for k, v in parts.items()), flush=True)
+            ck.close()
+            del scheds
 
 
 if __name__ == "__main__":

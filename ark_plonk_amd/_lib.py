@@ -149,6 +149,7 @@ SYMBOLS = {
     "zk_dev_free": (c_int, [c_void_p, c_void_p]),
     "zk_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "zk_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "zk_dev_copy": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     # N4: wire formats + transcript (host only)
     "zk_fr_serialized_size": (c_size_t, [c_int]),
     "zk_g1_compressed_size": (c_size_t, [c_int]),

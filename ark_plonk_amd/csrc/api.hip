@@ -1387,6 +1387,13 @@ int zk_dev_download(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     return ZK_OK;
 }
 
+int zk_dev_copy(zk_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !d_src))) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (bytes) ZK_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));      // queued, not waited for
+    return ZK_OK;
+}
+
 // ------------------------------------------------------------------------------ N2: grand products
 int zk_perm_product_dev(zk_ctx* c, int curve_id, uint32_t log_n, const void* const* d_wires, const void* const* d_sigmas,
                         const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, uint64_t* last_mont) {

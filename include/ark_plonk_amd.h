@@ -507,6 +507,9 @@ int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr);
 int zk_dev_free(zk_ctx* ctx, void* d_ptr);
 int zk_dev_upload(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int zk_dev_download(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* device -> device on the ctx stream, queued in order with the kernels (no host wait): e.g. the four quarters of the quotient
+ * polynomial as vectors of their own (prover.rs:107-123 split_tx_poly) for a caller whose vector type has no sub-ranges */
+int zk_dev_copy(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* Library build info: returns "gfx950" etc. */
 const char* zk_build_info(void);

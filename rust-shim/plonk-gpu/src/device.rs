@@ -15,6 +15,12 @@
 //! * `PC::commit(t_1..t_4)`                                                       -- prover.rs:459-469
 //! * `PC::commit(aw)`, `PC::open(aw ++ w, z)`, `PC::commit(saw)`, `PC::open(saw, z omega)` -- prover.rs:579-618
 //!
+//! Round 5: the O(n) steps BETWEEN those calls too -- the round-2 multisets ([`lookup_query_dev`], [`combine_split_dev`]), both
+//! grand products ([`perm_product_dev`], [`lookup_product_dev`]: permutation/mod.rs:652-822 up to their `ifft`), the pointwise
+//! quotient ([`quotient_evals_dev`]: quotient_poly.rs:34-178 between its coset ffts and its `coset_ifft`), the 23 evaluations and the
+//! linearisation polynomial ([`evaluate_dev`], [`lincomb_dev`]: linearisation_poly.rs:164-350) -- and the prover key's vectors resident
+//! across proofs ([`resident`]), so that `prove_on_device` moves NO polynomial over PCIe between the witness upload and the proof.
+//!
 //! [`GpuBackend`] packages all of it behind `plonk_core::commitment::DeviceBackend`, the trait the patch adds to plonk-core, so the
 //! prover stays generic in `PC` and free of GPU types.  Shipped as source (no Rust toolchain in this repository's pipeline);
 //! `tests/test_rust_shim.py` checks every `sys::zk_*` call below against the header.
@@ -27,10 +33,11 @@ use ark_poly_commit::kzg10;
 use core::any::Any;
 use core::cell::RefCell;
 use core::ffi::c_void;
-use plonk_core::commitment::{DeviceBackend, DeviceVec, RoundItem, Transform};
+use plonk_core::commitment::{DeviceBackend, DeviceVec, QuotientChallenges, QuotientColumns, RoundItem, Transform};
 use plonk_core::error::Error as PlonkError;
 use plonk_gpu_sys as sys;
-use std::sync::Arc;
+use std::collections::HashMap;
+use std::sync::{Arc, Mutex, Once};
 
 const FR_BYTES: usize = 8 * FR_LIMBS;
 
@@ -186,6 +193,199 @@ impl GpuDomain {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// the O(n) steps between the transforms and the commitments (SURVEY.md 8f N1 / N2 and the rounds around them)
+
+fn fr_limbs(x: &Fr) -> *const u64 {
+    fr_ptr(core::slice::from_ref(x))
+}
+
+/// `count` elements of `v` from `first` on as a vector of its own: one device-to-device copy queued on the ctx stream
+/// (`Prover::split_tx_poly`, prover.rs:107-123).
+pub fn slice_dev(v: DevSlice<'_>, first: usize, count: usize) -> Result<DevicePoly, GpuError> {
+    let src = v.range(first, count);
+    let out = DevicePoly::alloc(src.len())?;
+    if !src.is_empty() {
+        check(unsafe { sys::zk_dev_copy(ctx(), out.ptr, src.ptr, src.len() * FR_BYTES) })?;
+    }
+    Ok(out)
+}
+
+/// `sum_k scalars[k] * polys[k]` over `out_len` coefficients (`zk_poly_lincomb_dev`, at most 32 terms): the scalar-times-polynomial
+/// sums of linearisation_poly.rs:288-336 and `MultiSet::compress` (prover.rs:229-237).
+pub fn lincomb_dev(polys: &[DevSlice<'_>], scalars: &[Fr], out_len: usize) -> Result<DevicePoly, GpuError> {
+    if polys.len() != scalars.len() || polys.len() > 32 {
+        return Err(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("lincomb: one scalar per polynomial, at most 32 terms") });
+    }
+    let (ptrs, lens) = ptrs_and_lens(polys);
+    let out = DevicePoly::alloc(out_len)?;
+    check(unsafe {
+        sys::zk_poly_lincomb_dev(ctx(), CURVE, polys.len() as u32, ptrs.as_ptr(), lens.as_ptr(), fr_ptr(scalars), out.ptr, out_len)
+    })?;
+    Ok(out)
+}
+
+/// `polys[k].evaluate(&points[k])` (`zk_poly_evaluate_dev`; linearisation_poly.rs:203-261 evaluates 16 polynomials at z and 7 at
+/// z omega): blocks until the values are on the host.
+pub fn evaluate_dev(polys: &[DevSlice<'_>], points: &[Fr]) -> Result<Vec<Fr>, GpuError> {
+    if polys.len() != points.len() {
+        return Err(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("evaluate: one point per polynomial") });
+    }
+    let mut out = vec![Fr::zero(); polys.len()];
+    let mut lo = 0;
+    while lo < polys.len() {
+        let hi = core::cmp::min(lo + 32, polys.len());
+        let (ptrs, lens) = ptrs_and_lens(&polys[lo..hi]);
+        check(unsafe {
+            sys::zk_poly_evaluate_dev(
+                ctx(),
+                CURVE,
+                (hi - lo) as u32,
+                ptrs.as_ptr(),
+                lens.as_ptr(),
+                fr_ptr(&points[lo..hi]),
+                crate::fr_mut_ptr(&mut out[lo..hi]),
+            )
+        })?;
+        lo = hi;
+    }
+    Ok(out)
+}
+
+/// The compressed query column of round 2 (prover.rs:244-279, `zk_lookup_query_dev`): n rows.
+pub fn lookup_query_dev(n: usize, q_lookup: DevSlice<'_>, wires: [DevSlice<'_>; 4], zeta: &Fr, compressed_table: DevSlice<'_>) -> Result<DevicePoly, GpuError> {
+    if compressed_table.is_empty() || wires.iter().any(|w| w.len() < n) {
+        return Err(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("lookup_query: columns shorter than n") });
+    }
+    let w = [wires[0].ptr, wires[1].ptr, wires[2].ptr, wires[3].ptr];
+    let out = DevicePoly::alloc(n)?;
+    check(unsafe {
+        sys::zk_lookup_query_dev(ctx(), CURVE, n, q_lookup.ptr, q_lookup.len(), w.as_ptr(), fr_limbs(zeta), compressed_table.ptr, out.ptr)
+    })?;
+    Ok(out)
+}
+
+/// `t.combine_split(&f)` (lookup/multiset.rs:131-176, `zk_lookup_combine_split_dev`) as (h_1, h_2); an element of f that t does
+/// not hold is the library's ZK_ERR_NOT_INDEXED (the reference's `Error::ElementNotIndexed`).
+pub fn combine_split_dev(t: DevSlice<'_>, f: DevSlice<'_>) -> Result<(DevicePoly, DevicePoly), GpuError> {
+    let half = (t.len() + f.len() + 1) / 2;
+    let mut h1 = DevicePoly::alloc(half)?;
+    let mut h2 = DevicePoly::alloc(half)?;
+    let (mut l1, mut l2) = (0usize, 0usize);
+    check(unsafe { sys::zk_lookup_combine_split_dev(ctx(), CURVE, t.ptr, t.len(), f.ptr, f.len(), h1.ptr, h2.ptr, &mut l1, &mut l2) })?;
+    h1.len = core::cmp::min(l1, half);
+    h2.len = core::cmp::min(l2, half);
+    Ok((h1, h2))
+}
+
+/// The n evaluations of the permutation polynomial z (`zk_perm_product_dev`): everything `compute_permutation_poly`
+/// (permutation/mod.rs:652-752) does before its `domain.ifft`.  A zero denominator is ZK_ERR_NOT_INVERTIBLE (the reference panics).
+pub fn perm_product_dev(log_n: u32, wires: [DevSlice<'_>; 4], sigma_evals: [DevSlice<'_>; 4], beta: &Fr, gamma: &Fr) -> Result<DevicePoly, GpuError> {
+    let n = 1usize << log_n;
+    if wires.iter().chain(sigma_evals.iter()).any(|v| v.len() < n) {
+        return Err(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("perm_product: columns shorter than n") });
+    }
+    let w = [wires[0].ptr, wires[1].ptr, wires[2].ptr, wires[3].ptr];
+    let s = [sigma_evals[0].ptr, sigma_evals[1].ptr, sigma_evals[2].ptr, sigma_evals[3].ptr];
+    let out = DevicePoly::alloc(n)?;
+    check(unsafe { sys::zk_perm_product_dev(ctx(), CURVE, log_n, w.as_ptr(), s.as_ptr(), fr_limbs(beta), fr_limbs(gamma), out.ptr, core::ptr::null_mut()) })?;
+    Ok(out)
+}
+
+/// The n evaluations of the lookup product z_2 (`zk_lookup_product_dev`; permutation/mod.rs:754-822): columns (f, t, h_1, h_2).
+pub fn lookup_product_dev(n: usize, columns: [DevSlice<'_>; 4], delta: &Fr, epsilon: &Fr) -> Result<DevicePoly, GpuError> {
+    if columns.iter().any(|v| v.len() < n) {
+        return Err(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("lookup_product: columns shorter than n") });
+    }
+    let out = DevicePoly::alloc(n)?;
+    check(unsafe {
+        sys::zk_lookup_product_dev(
+            ctx(),
+            CURVE,
+            n,
+            columns[0].ptr,
+            columns[1].ptr,
+            columns[2].ptr,
+            columns[3].ptr,
+            fr_limbs(delta),
+            fr_limbs(epsilon),
+            out.ptr,
+            core::ptr::null_mut(),
+        )
+    })?;
+    Ok(out)
+}
+
+fn limbs_of(x: &Fr) -> [u64; FR_LIMBS] {
+    let mut l = [0u64; FR_LIMBS];
+    // Fr = Fp256(BigInteger256([u64; 4])): the Montgomery limbs, as everywhere on this boundary (lib.rs `layout_checks`)
+    unsafe { core::ptr::copy_nonoverlapping(fr_limbs(x), l.as_mut_ptr(), FR_LIMBS) };
+    l
+}
+
+/// The 4n quotient evaluations over the coset (`zk_quotient_evals_dev`): every argument of `args` a vector of 4n evaluations.
+pub fn quotient_evals_dev(log_n: u32, args: &sys::ZkQuotientArgs) -> Result<DevicePoly, GpuError> {
+    let out = DevicePoly::alloc(4usize << log_n)?;
+    check(unsafe { sys::zk_quotient_evals_dev(ctx(), CURVE, log_n, args as *const sys::ZkQuotientArgs, out.ptr) })?;
+    Ok(out)
+}
+
+// ---- vectors that never change (the prover key): uploaded once per process, found again by the identity of the host slice.
+// Key: (address, length); the fingerprint -- 64 elements sampled across the vector -- catches an allocator handing the same
+// address to other data of the same length (a ProverKey is immutable once `Circuit::compile` has built it: its fields are
+// `pub(crate)` and plonk-core never writes to one).
+type ResidentMap = HashMap<(usize, usize), (u64, Arc<DevicePoly>)>;
+static RESIDENT_INIT: Once = Once::new();
+static mut RESIDENT: Option<Mutex<ResidentMap>> = None; // written once, under RESIDENT_INIT (the reference's pinned toolchain has no const Mutex::new)
+
+fn resident_map() -> &'static Mutex<ResidentMap> {
+    RESIDENT_INIT.call_once(|| unsafe { RESIDENT = Some(Mutex::new(HashMap::new())) });
+    unsafe { RESIDENT.as_ref().expect("initialised by call_once") }
+}
+
+fn fingerprint(v: &[Fr]) -> u64 {
+    let words = unsafe { core::slice::from_raw_parts(fr_ptr(v), v.len() * FR_LIMBS) };
+    let mut h: u64 = 0xcbf2_9ce4_8422_2325 ^ (v.len() as u64);
+    let step = core::cmp::max(v.len() / 64, 1);
+    let mut i = 0;
+    while i < v.len() {
+        for k in 0..FR_LIMBS {
+            h = (h ^ words[i * FR_LIMBS + k]).wrapping_mul(0x0000_0100_0000_01b3);
+        }
+        i += step;
+    }
+    if let Some(last) = v.len().checked_sub(1) {
+        for k in 0..FR_LIMBS {
+            h = (h ^ words[last * FR_LIMBS + k]).wrapping_mul(0x0000_0100_0000_01b3);
+        }
+    }
+    h
+}
+
+/// A shared handle to a resident vector.
+#[derive(Clone, Debug)]
+pub struct SharedPoly(pub Arc<DevicePoly>);
+
+/// The device copy of a vector that does not change for the life of the process (a column of the prover key).
+pub fn resident(v: &[Fr]) -> Result<SharedPoly, GpuError> {
+    let key = (v.as_ptr() as usize, v.len());
+    let fp = fingerprint(v);
+    let mut map = resident_map().lock().unwrap_or_else(|e| e.into_inner());
+    if let Some((have, poly)) = map.get(&key) {
+        if *have == fp {
+            return Ok(SharedPoly(poly.clone()));
+        }
+    }
+    let poly = Arc::new(DevicePoly::upload(v)?);
+    map.insert(key, (fp, poly.clone()));
+    Ok(SharedPoly(poly))
+}
+
+/// Drop every resident vector (a service that switches circuits calls this when it drops a prover key).
+pub fn forget_resident() {
+    resident_map().lock().unwrap_or_else(|e| e.into_inner()).clear();
+}
+
 fn ptrs_and_lens(polys: &[DevSlice<'_>]) -> (Vec<*const c_void>, Vec<usize>) {
     (polys.iter().map(|s| s.ptr).collect(), polys.iter().map(|s| s.len()).collect())
 }
@@ -288,6 +488,19 @@ impl DeviceVec<Fr> for DevicePoly {
     }
 }
 
+impl DeviceVec<Fr> for SharedPoly {
+    fn len(&self) -> usize {
+        self.0.len
+    }
+    fn to_host(&self) -> Result<Vec<Fr>, PlonkError> {
+        self.0.download().map_err(device_error)
+    }
+    fn as_any(&self) -> &dyn Any {
+        // the vector itself: `as_poly` finds a `DevicePoly` behind an owned and behind a shared handle alike
+        &*self.0
+    }
+}
+
 fn device_error(e: GpuError) -> PlonkError {
     PlonkError::DeviceError { error: e.to_string() }
 }
@@ -309,11 +522,11 @@ impl GpuBackend {
     }
 
     fn fail<T>(&self, e: GpuError) -> Result<T, PlonkError> {
-        // a failed call leaves the round open on the ctx: settle it, or every later blocking call returns ZK_ERR_PENDING
-        if !self.open_jobs.borrow().is_empty() {
-            GpuKZG10::round_abort();
-            self.open_jobs.borrow_mut().clear();
-        }
+        // a failed call may leave a round open on the ctx -- also one whose first `commit_begin` failed part-way, with jobs queued in
+        // the library and none recorded here (the ABI keeps the jobs queued so far open): settle it unconditionally (a no-op without
+        // an open round), or every later blocking call returns ZK_ERR_PENDING and the next proof appends to a stale round
+        GpuKZG10::round_abort();
+        self.open_jobs.borrow_mut().clear();
         Err(device_error(e))
     }
 }
@@ -396,6 +609,163 @@ impl DeviceBackend<Fr, GpuKZG10> for GpuBackend {
                     })
                     .collect())
             }
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn resident(&self, v: &[Fr]) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        match resident(v) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn slice(&self, v: &dyn DeviceVec<Fr>, first: usize, count: usize) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        match slice_dev(as_poly(v)?.as_slice(), first, count) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn lincomb(&self, terms: &[(&dyn DeviceVec<Fr>, usize, Fr)], out_len: usize) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        let mut slices = Vec::with_capacity(terms.len());
+        let mut scalars = Vec::with_capacity(terms.len());
+        for (v, len, s) in terms {
+            slices.push(as_poly(*v)?.truncated(*len));
+            scalars.push(*s);
+        }
+        match lincomb_dev(&slices, &scalars, out_len) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn evaluate(&self, polys: &[(&dyn DeviceVec<Fr>, usize, Fr)]) -> Result<Vec<Fr>, PlonkError> {
+        let mut slices = Vec::with_capacity(polys.len());
+        let mut points = Vec::with_capacity(polys.len());
+        for (v, len, p) in polys {
+            slices.push(as_poly(*v)?.truncated(*len));
+            points.push(*p);
+        }
+        match evaluate_dev(&slices, &points) {
+            Ok(v) => Ok(v),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn lookup_query(
+        &self,
+        n: usize,
+        q_lookup: (&dyn DeviceVec<Fr>, usize),
+        wires: [&dyn DeviceVec<Fr>; 4],
+        zeta: &Fr,
+        compressed_table: &dyn DeviceVec<Fr>,
+    ) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        let w = [as_poly(wires[0])?.as_slice(), as_poly(wires[1])?.as_slice(), as_poly(wires[2])?.as_slice(), as_poly(wires[3])?.as_slice()];
+        match lookup_query_dev(n, as_poly(q_lookup.0)?.truncated(q_lookup.1), w, zeta, as_poly(compressed_table)?.as_slice()) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn combine_split(&self, t: &dyn DeviceVec<Fr>, f: &dyn DeviceVec<Fr>) -> Result<(Box<dyn DeviceVec<Fr>>, Box<dyn DeviceVec<Fr>>), PlonkError> {
+        match combine_split_dev(as_poly(t)?.as_slice(), as_poly(f)?.as_slice()) {
+            Ok((h1, h2)) => Ok((Box::new(h1), Box::new(h2))),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn permutation_product(
+        &self,
+        n: usize,
+        wires: [&dyn DeviceVec<Fr>; 4],
+        sigma_evals: [&dyn DeviceVec<Fr>; 4],
+        beta: &Fr,
+        gamma: &Fr,
+    ) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        if !n.is_power_of_two() {
+            return self.fail(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("permutation_product: n must be a power of two") });
+        }
+        let w = [as_poly(wires[0])?.as_slice(), as_poly(wires[1])?.as_slice(), as_poly(wires[2])?.as_slice(), as_poly(wires[3])?.as_slice()];
+        let s = [
+            as_poly(sigma_evals[0])?.as_slice(),
+            as_poly(sigma_evals[1])?.as_slice(),
+            as_poly(sigma_evals[2])?.as_slice(),
+            as_poly(sigma_evals[3])?.as_slice(),
+        ];
+        match perm_product_dev(n.trailing_zeros(), w, s, beta, gamma) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn lookup_product(&self, n: usize, columns: [&dyn DeviceVec<Fr>; 4], delta: &Fr, epsilon: &Fr) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        let c = [
+            as_poly(columns[0])?.as_slice(),
+            as_poly(columns[1])?.as_slice(),
+            as_poly(columns[2])?.as_slice(),
+            as_poly(columns[3])?.as_slice(),
+        ];
+        match lookup_product_dev(n, c, delta, epsilon) {
+            Ok(p) => Ok(Box::new(p)),
+            Err(e) => self.fail(e),
+        }
+    }
+
+    fn quotient(&self, n: usize, columns: &QuotientColumns<'_, Fr>, challenges: &QuotientChallenges<Fr>) -> Result<Box<dyn DeviceVec<Fr>>, PlonkError> {
+        if !n.is_power_of_two() {
+            return self.fail(GpuError { code: sys::ZK_ERR_BAD_ARG, message: String::from("quotient: n must be a power of two") });
+        }
+        // every column holds the 4n evaluations over the coset
+        let col = |v: &dyn DeviceVec<Fr>| -> Result<*const c_void, PlonkError> {
+            let p = as_poly(v)?;
+            if p.len() < 4 * n {
+                return Err(PlonkError::DeviceError { error: String::from("quotient: a column holds fewer than 4n evaluations") });
+            }
+            Ok(p.ptr as *const c_void)
+        };
+        let args = sys::ZkQuotientArgs {
+            w_l: col(columns.wires[0])?,
+            w_r: col(columns.wires[1])?,
+            w_o: col(columns.wires[2])?,
+            w_4: col(columns.wires[3])?,
+            z: col(columns.z)?,
+            z2: col(columns.z2)?,
+            f: col(columns.f)?,
+            table: col(columns.table)?,
+            h1: col(columns.h1)?,
+            h2: col(columns.h2)?,
+            pi: col(columns.pi)?,
+            l1: col(columns.l1)?,
+            q_m: col(columns.arithmetic[0])?,
+            q_l: col(columns.arithmetic[1])?,
+            q_r: col(columns.arithmetic[2])?,
+            q_o: col(columns.arithmetic[3])?,
+            q_4: col(columns.arithmetic[4])?,
+            q_c: col(columns.arithmetic[5])?,
+            q_arith: col(columns.arithmetic[6])?,
+            q_range: col(columns.selectors[0])?,
+            q_logic: col(columns.selectors[1])?,
+            q_fixed_group_add: col(columns.selectors[2])?,
+            q_variable_group_add: col(columns.selectors[3])?,
+            q_lookup: col(columns.selectors[4])?,
+            sigma: [col(columns.sigma[0])?, col(columns.sigma[1])?, col(columns.sigma[2])?, col(columns.sigma[3])?],
+            alpha: limbs_of(&challenges.round[0]),
+            beta: limbs_of(&challenges.round[1]),
+            gamma: limbs_of(&challenges.round[2]),
+            delta: limbs_of(&challenges.round[3]),
+            epsilon: limbs_of(&challenges.round[4]),
+            zeta: limbs_of(&challenges.round[5]),
+            range_challenge: limbs_of(&challenges.separation[0]),
+            logic_challenge: limbs_of(&challenges.separation[1]),
+            fixed_base_challenge: limbs_of(&challenges.separation[2]),
+            var_base_challenge: limbs_of(&challenges.separation[3]),
+            lookup_challenge: limbs_of(&challenges.separation[4]),
+            coeff_a: limbs_of(&challenges.curve[0]),
+            coeff_d: limbs_of(&challenges.curve[1]),
+        };
+        match quotient_evals_dev(n.trailing_zeros(), &args) {
+            Ok(p) => Ok(Box::new(p)),
             Err(e) => self.fail(e),
         }
     }

@@ -126,6 +126,9 @@ def test_hand_written_crate_calls_declared_functions_with_the_right_arity():
     assert {"zk_dev_alloc", "zk_dev_upload", "zk_dev_download", "zk_dev_free", "zk_ntt_dev", "zk_ntt_batch_dev", "zk_kzg_commit_batch_dev",
             "zk_kzg_open_dev", "zk_kzg_round_begin_dev", "zk_kzg_open_begin_dev", "zk_kzg_round_reduce", "zk_kzg_round_end",
             "zk_kzg_round_abort"} <= used
+    # ... and the SURVEY.md 8f N1 / N2 entry points with the round-2 / round-5 builders around them
+    assert {"zk_perm_product_dev", "zk_lookup_product_dev", "zk_quotient_evals_dev", "zk_poly_evaluate_dev", "zk_poly_lincomb_dev",
+            "zk_lookup_query_dev", "zk_lookup_combine_split_dev", "zk_dev_copy"} <= used
 
 
 PATCH = os.path.join(ROOT, "rust-shim", "patches", "plonk-core-device-prover.patch")
@@ -147,8 +150,8 @@ def _added_lines(path_suffix):
 
 
 def test_the_prover_patch_applies_to_the_reference():
-    """patches/plonk-core-device-prover.patch (commitment.rs: the DeviceBackend hook; error.rs: its error; prover.rs:
-    prove_on_device) applies cleanly to the reference tree this repository was built against."""
+    """patches/plonk-core-device-prover.patch (commitment.rs: the DeviceBackend hook; error.rs: its error; linearisation_poly.rs:
+    compute_on_device; prover.rs: prove_on_device) applies cleanly to the reference tree this repository was built against."""
     import shutil
     import pytest
     if not os.path.isdir(REF) or shutil.which("patch") is None:
@@ -210,10 +213,23 @@ def test_device_backend_trait_and_its_gpu_implementation_agree():
             out[m.group(1)] = len(_split_top(src[m.end():i - 1]))
         return out
     t, g = methods(trait_src), methods(impl_src)
-    assert set(t) == {"upload", "transform_batch", "commit_begin", "open_begin", "round_reduce", "round_end"}
+    assert set(t) == {"upload", "transform_batch", "commit_begin", "open_begin", "round_reduce", "round_end",
+                      # round 5: the O(n) steps between the transforms and the commitments (SURVEY.md 8f N1 / N2 and the rounds around them)
+                      "resident", "slice", "lincomb", "evaluate", "lookup_query", "combine_split", "permutation_product", "lookup_product", "quotient"}
     assert {k: g.get(k) for k in t} == t
     prover = _added_lines("proof_system/prover.rs")
-    assert set(re.findall(r"\bdev\.(\w+)\(", prover)) - {"as_ref"} <= set(t)
+    lin = _added_lines("proof_system/linearisation_poly.rs")
+    called = (set(re.findall(r"\bdev\.(\w+)\(", prover)) | set(re.findall(r"\bdev\.(\w+)\(", lin))) - {"as_ref"}
+    assert called <= set(t)
+    # ... and every one of the new steps IS called: prove_on_device keeps z, z_2, the quotient, the evaluations and the linearisation
+    # polynomial on the device (permutation/mod.rs:652-801, quotient_poly.rs:34-178, linearisation_poly.rs:164-349)
+    assert {"resident", "slice", "lincomb", "evaluate", "lookup_query", "combine_split", "permutation_product", "lookup_product", "quotient"} <= called
+    # nothing of size n comes back: the patched prover never asks a device vector for a host copy, and never calls the host-side
+    # builders whose inputs and outputs are host polynomials
+    body = prover[prover.index("fn prove_on_device"):]
+    for host_call in ("to_host(", "host_poly(", "compute_permutation_poly(", "compute_lookup_permutation_poly(", "quotient_poly::compute",
+                      "linearisation_poly::compute::<", "combine_split(&", "MultiSet::compress("):
+        assert host_call not in body, host_call
     # the scheme's side of the hook
     kzg = open(os.path.join(SHIM_SRC, "kzg.rs")).read()
     assert "fn device_backend(ck: &Self::CommitterKey)" in kzg and "GpuBackend::new" in kzg
@@ -228,3 +244,26 @@ def test_gpu_kzg10_implements_every_required_method():
                  "fn setup", "fn trim", "fn commit", "fn open<", "fn open_individual_opening_challenges", "fn check<",
                  "fn check_individual_opening_challenges", "fn multi_scalar_mul"):
         assert item in src, item
+
+
+def test_device_linearisation_batches_what_the_python_prover_batches():
+    """`linearisation_poly::compute_on_device` (the patch) and ark_plonk_amd/linearisation.py -- the form the `-m gpu` suite proves
+    against the restated verifier -- issue the same 23 evaluations in the same order and the same 19 lincomb terms: the Rust side
+    cannot be compiled here, its structure can be read."""
+    from ark_plonk_amd import linearisation as lin
+    src = _added_lines("proof_system/linearisation_poly.rs")
+    src = src[src.index("pub fn compute_on_device"):]
+    ev = src[src.index("dev.evaluate(&["):]
+    ev = ev[:ev.index("])?;")]
+    pairs = re.findall(r"(?:on|at)\(&(?:polys\.)?([\w\[\]\.]+), (zw?)\)", ev)
+    rust_name = {"wires[0]": "w_l", "wires[1]": "w_r", "wires[2]": "w_o", "wires[3]": "w_4"}
+    names = [(rust_name.get(nm, nm), pt) for nm, pt in pairs]
+    assert [nm for nm, pt in names if pt == "z"] == list(lin.EVAL_AT_Z)
+    assert [nm for nm, pt in names if pt == "zw"] == list(lin.EVAL_AT_ZW)
+    assert len(names) == 23 and [pt for _, pt in names] == ["z"] * 16 + ["zw"] * 7
+    lc = src[src.index("dev.lincomb("):]
+    lc = lc[:lc.index("\n        ],\n")]
+    terms = re.findall(r"(?:on|at)\(&(?:polys\.)?([\w\[\]\.]+),", lc)
+    want = ["q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "q_range", "q_logic", "q_fixed", "q_variable", "z", "fourth_sigma", "q_lookup", "z2", "h1",
+            "quotient[0]", "quotient[1]", "quotient[2]", "quotient[3]"]
+    assert terms == want

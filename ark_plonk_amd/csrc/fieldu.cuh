@@ -112,6 +112,46 @@ struct Fu {
         return t;
     }
 
+    // ---- lazily normalised arithmetic (the NTT butterflies, ntt_pass.cuh) -------------------------------------------------
+    // Limbs are plain NON-NEGATIVE 32-bit numbers that are not swept after every operation; "k units" = every limb below the top
+    // one is < k * 2^29 (a swept value has 1 unit).  A Montgomery product takes a first operand of up to 6 units against a swept
+    // second one: a column is at most 9 * (6 * 2^29) * 2^29 + 9 * 2^58 + carry < 2^64.  A limb holds up to 8 units.
+    // sweep: the carry pass for non-negative limbs (logical shifts; `normalize` above reads limbs as signed).
+    ZK_HD static void sweep(Fu& t) {
+#pragma unroll
+        for (int i = 0; i < NL - 1; ++i) {
+            const uint32_t c = t.v[i] >> 29;
+            t.v[i] &= M;
+            t.v[i + 1] += c;
+        }
+    }
+    ZK_HD static Fu add_raw(const Fu& a, const Fu& b) {      // units(a) + units(b)
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] + b.v[i];
+        return t;
+    }
+    // a - b + k p with no limb ever below zero: b SWEPT (1 unit) and below 2p / 8p / 16p; the multiple of p has every limb under the top
+    // one in [2^29, 2^30) and a top limb that covers b's.  units(a) + 2.
+    ZK_HD static Fu sub_raw3(const Fu& a, const Fu& b) {     // b < 2p (a product)
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] + P::ZB3(i) - b.v[i];
+        return t;
+    }
+    ZK_HD static Fu sub_raw8(const Fu& a, const Fu& b) {     // b < 7p
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] + P::ZB8(i) - b.v[i];
+        return t;
+    }
+    ZK_HD static Fu sub_raw16(const Fu& a, const Fu& b) {    // b < 15p
+        Fu t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.v[i] = a.v[i] + P::ZB16(i) - b.v[i];
+        return t;
+    }
+
     // Montgomery product a*b/R' : interleaved product scanning.  Each column keeps the a*b products and
     // the m*p products in SEPARATE 64-bit accumulators: a dependent v_mad_u64_u32 chain issues only every
     // ~14 cycles per wave (measured: 7.0 cycles/mad/SIMD at 2 waves), two or three independent chains

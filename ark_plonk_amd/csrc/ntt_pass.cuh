@@ -9,9 +9,14 @@
 // field (fieldu.cuh): data stay in the arkworks Montgomery domain (R = 2^256) because every twiddle
 // table holds w * 2^261 mod r, and DIT butterflies (t = w*b; a + t, a - t + 2r) grow the lazily
 // reduced values only additively, so no reduction is needed inside a pass (a Montgomery product accepts
-// a * b < 69 r^2; the data stay below 40r and every twiddle below r).
+// a * b < 69 r^2; the data stay below 47r and every twiddle below r).
 // The butterflies of the first window whose twiddle is w^0 = 1 (all of stage 0, half of stage 1, a quarter
 // of stage 2) are done without a product.
+// Round 5: the butterflies are LAZILY NORMALISED too.  a + t and a - t + 3r are limb-wise operations with no carry sweep
+// (fieldu.cuh `add_raw` / `sub_raw3`: the multiple of r is held with limbs in [2^29, 2^30), so no limb of the difference goes
+// below zero); limbs grow by at most two "units" (2^29) per stage, a product takes a data operand of up to 6 units, a limb holds
+// 8: ONE sweep of the eight registers every third stage (`ntt_sweep_at`) instead of two per butterfly -- ~36 of the ~315 vector
+// instructions of a butterfly.  Passes other than the last store their products as they are (below 2r, not canonical).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_params.h"
@@ -75,6 +80,16 @@ ZK_D void st_u(void* base, uint64_t idx, const F& x) {
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// swept value below 2^256 -> 32-byte store with no reduction (between the passes of one transform)
+template <class F>
+ZK_D void st_u_raw(void* base, uint64_t idx, const F& x) {
+    uint32_t w[8];
+    x.pack_words(w);
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 // inner twiddles are stored as the 29-bit limbs the products consume (NL <= 12 words, padded to 48 B): the table is a few KiB
 // and L1-resident, and every butterfly of a pass reads one entry -- splitting 32-byte words into limbs at each use was ~27 of
 // the ~315 vector instructions of a butterfly
@@ -95,6 +110,20 @@ ZK_D F ld_limbs(const void* base, uint64_t idx) {
     }
     return r;
 }
+
+// limb units (fieldu.cuh) of the eight registers BEFORE stage t of a pass: fresh loads / products have 1; a stage adds 2; a sweep
+// (taken when a data operand would exceed the product's 6 units) brings them back to 1
+constexpr int ntt_units_before(int t) {
+    int b = 1;
+    for (int s = 0; s < t; ++s) {
+        if (b > 6) b = 1;
+        b += 2;
+    }
+    return b;
+}
+constexpr bool ntt_sweep_at(int t) { return ntt_units_before(t) > 6; }
+static_assert(ntt_units_before(1) == 3 && ntt_units_before(2) == 5 && ntt_units_before(3) == 7 && ntt_units_before(4) == 3, "two units per stage");
+static_assert(!ntt_sweep_at(0) && !ntt_sweep_at(2) && ntt_sweep_at(3) && !ntt_sweep_at(5) && ntt_sweep_at(6) && ntt_sweep_at(9), "a sweep every third stage");
 
 template <int B0>
 ZK_D uint32_t window_pos(uint32_t v, uint32_t e) {
@@ -123,39 +152,44 @@ ZK_D void dit_window(F (&x)[8], uint32_t v, const void* tw, bool quarter) {
 #pragma unroll
     for (int lb = LB_LO; lb < LB_HI; ++lb) {
         const int t = B0 + lb;   // position bit paired by this stage; twiddle w_{2^(t+1)}^(p mod 2^t)
+        if (ntt_sweep_at(t)) {   // compile-time after unrolling: every third stage
+#pragma unroll
+            for (int e = 0; e < 8; ++e) F::sweep(x[e]);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (e & (1 << lb)) continue;
             const int eo = e | (1 << lb);
             if constexpr (B0 == 0 && LB_LO == 0) {
-                // first stage of a pass (t = 0): every twiddle is w^0 = 1 and the operands are still < 2r
-                // (fresh loads / products), so the butterfly is a + b, a - b + 2r with no product at all
+                // first stage of a pass (t = 0): every twiddle is w^0 = 1 and the operands are swept and < 2r
+                // (fresh loads / products), so the butterfly is a + b, a - b + 3r with no product at all
                 if (lb < 2 && quarter) {   // the partner is zero (or a copy of a zero-partnered value): a + w*0, a - w*0
                     x[eo] = x[e];
                     continue;
                 }
                 if (lb == 0) {
                     const F b = x[eo];
-                    x[eo] = F::sub2(x[e], b);
-                    x[e] = F::add(x[e], b);
+                    x[eo] = F::sub_raw3(x[e], b);
+                    x[e] = F::add_raw(x[e], b);
                     continue;
                 }
                 // stages 1 and 2 of the first window: the twiddle index is (e mod 2^lb) << (S-1-lb), i.e. w^0 = 1
-                // for the pairs with e mod 2^lb == 0.  Their operands are no longer < 2r (< 4r after stage 0,
-                // < 12r after stage 1), hence the larger offsets; the pass still ends below 40r < 2^261.
+                // for the pairs with e mod 2^lb == 0.  Their subtrahend is no longer a product: below 5r after stage 0, below
+                // 13r after stage 1 -- swept here, and taken from 8r / 16r; the pass still ends below 47r < 69r.
                 if ((e & ((1 << lb) - 1)) == 0) {
-                    const F b = x[eo];
-                    x[eo] = lb == 1 ? F::sub8(x[e], b) : F::sub16(x[e], b);
-                    x[e] = F::add(x[e], b);
+                    F b = x[eo];
+                    F::sweep(b);
+                    x[eo] = lb == 1 ? F::sub_raw8(x[e], b) : F::sub_raw16(x[e], b);
+                    x[e] = F::add_raw(x[e], b);
                     continue;
                 }
             }
             const uint32_t plow = ((uint32_t)(e & ((1 << lb) - 1)) << B0) | vlow;
             const uint32_t j = plow << (S - 1 - t);
             F w = ld_limbs<F>(tw, j);
-            F m = F::mul(x[eo], w);            // < 2r
-            x[eo] = F::sub2(x[e], m);
-            x[e] = F::add(x[e], m);
+            F m = F::mul(x[eo], w);            // < 2r, swept
+            x[eo] = F::sub_raw3(x[e], m);
+            x[e] = F::add_raw(x[e], m);
         }
     }
 }
@@ -230,7 +264,9 @@ __global__ void __launch_bounds__(256) ntt_pass_mid(NttPassArgs a) {
     for (int e = 0; e < 8; ++e) {
         const uint64_t k = S >= 3 ? (((uint64_t)e << (S - 3)) | v) : e;
         F w = ld_u<F>(a.tw_pass, (k << a.log_m) + col);
-        st_u<F>(out, base + (k << a.log_m), F::mul(x[e], w));
+        if (ntt_units_before(S) > 6) F::sweep(x[e]);
+        // the next pass takes any representative below 2r: the product is stored as it is (swept limbs, 32 bytes)
+        st_u_raw<F>(out, base + (k << a.log_m), F::mul(x[e], w));
     }
 }
 
@@ -297,7 +333,8 @@ __global__ void __launch_bounds__(256) ntt_pass_final(NttPassArgs a) {
         const uint64_t k = S >= 3 ? (((uint64_t)e << (S - 3)) | v) : e;
         const uint64_t oidx = obase + (k << log_nb);
         // every output passes one Montgomery product: it carries 1/N or g^-j/N where needed and
-        // brings the lazily reduced value (< 20 r) back under 2r for the canonical store
+        // brings the lazily reduced value (< 47 r) back under 2r for the canonical store
+        if (ntt_units_before(S) > 6) F::sweep(x[e]);
         F y = F::mul(x[e], sc_mul);
         if (a.post_mul) y = F::mul(y, ld_u<F>(a.post_mul, oidx));
         st_u<F>(out, oidx, y);

@@ -256,3 +256,32 @@ def test_infinity_encodings_of_bases(cid, golden, ctx):
         two = np.stack([cancel.xy(), gen])
         got = zk.VariableBaseMSM.multi_scalar_mul(two, np.array([[5, 0, 0, 0], [1, 0, 0, 0]], dtype=np.uint64), cid, ctx=ctx)
         assert not got.infinity and np.array_equal(got.xy(), gen)
+
+
+def test_dev_helpers_alloc_upload_copy_download(ctx):
+    """The device-memory helpers a non-torch host binds (Rust `DevicePoly`, host/ark_plonk_amd.hpp): alloc / upload / copy (device to
+    device, queued on the ctx stream: `split_tx_poly`'s four quarters, rust-shim device.rs `slice_dev`) / download / free; a commit
+    of a copied quarter equals the commit of the same range of the source."""
+    import ctypes
+    import torch
+    import ark_plonk_amd as zk
+    from ark_plonk_amd import _lib
+    L = _lib.lib()
+    cv = zk.get_curve(0)
+    n = 1 << 13
+    rng = np.random.default_rng(5)
+    host = rng.integers(0, 1 << 62, size=(4 * n, 4), dtype=np.uint64)
+    src, dst = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(L.zk_dev_alloc(ctx.handle, 4 * n * 32, ctypes.byref(src)))
+    _lib.check(L.zk_dev_alloc(ctx.handle, n * 32, ctypes.byref(dst)))
+    _lib.check(L.zk_dev_upload(ctx.handle, src, host.ctypes.data_as(ctypes.c_void_p), 4 * n * 32))
+    back = np.zeros((n, 4), dtype=np.uint64)
+    for k in range(4):
+        _lib.check(L.zk_dev_copy(ctx.handle, dst, ctypes.c_void_p(src.value + k * n * 32), n * 32))
+        _lib.check(L.zk_dev_download(ctx.handle, back.ctypes.data_as(ctypes.c_void_p), dst, n * 32))       # waits for the stream
+        assert np.array_equal(back, host[k * n:(k + 1) * n]), k
+    assert L.zk_dev_copy(ctx.handle, dst, src, 0) == 0                       # nothing to do
+    assert L.zk_dev_copy(ctx.handle, None, src, 32) == _lib.ZK_ERR_BAD_ARG
+    assert L.zk_dev_copy(None, dst, src, 32) == _lib.ZK_ERR_BAD_ARG
+    _lib.check(L.zk_dev_free(ctx.handle, src))
+    _lib.check(L.zk_dev_free(ctx.handle, dst))

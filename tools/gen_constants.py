@@ -115,7 +115,17 @@ def unsat_struct(sname, p, nl, sat_words):
         "Z2": limbs29(2 * p, nl),
         "Z8": limbs29(8 * p, nl),
         "Z16": limbs29(16 * p, nl),
+        # the same multiples with every limb below the top one in [2^29, 2^30): a_i + z_i - b_i never goes below zero for a
+        # NORMALISED b (b_i < 2^29), so a difference needs no carry sweep of its own (ntt_pass.cuh: lazily normalised butterflies)
+        # (3p rather than 2p for the subtrahend below 2p: the TOP limb of a borrow-proof form is one less than the plain one, and
+        # must still cover the subtrahend's)
+        "ZB3": borrow_proof(3 * p, nl),
+        "ZB8": borrow_proof(8 * p, nl),
+        "ZB16": borrow_proof(16 * p, nl),
     }
+    # the borrow-proof multiples: the top limb (one less than the plain form's) must cover the subtrahend's -- below 2p, 7p, 15p
+    for k, below in ((3, 2), (8, 7), (16, 15)):
+        assert consts[f"ZB{k}"][-1] >= (below * p) >> (LB * (nl - 1)), (sname, k)
     for cname, vals in consts.items():
         out.append(f"    ZK_HD static constexpr uint32_t {cname}(int i) {{")
         out.append(f"        constexpr uint32_t t[{nl}] = {{{arr29(vals)}}};")

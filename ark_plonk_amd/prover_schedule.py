@@ -281,7 +281,7 @@ class ProofSchedule:
         self.msms_run += len(polys)
         if self.split_rounds:
             for p, kd in zip(polys, canonical or [False] * len(polys)):
-                self._on_group(lambda k, p=p, kd=kd: k.commit_begin([p], canonical=[kd]))
+                self._on_group(lambda k, p=p, kd=kd: k.commit_begin([p], canonical=[kd]), tensors=[p])
                 self._pending.append(("q", 1))
             return
         if self.world == 1:
@@ -307,14 +307,16 @@ class ProofSchedule:
             return
         self.msms_run += 1
         if self.split_rounds:
-            self._on_group(lambda k: k.open_begin(polys, self.z_mont, self.chi_mont))
+            self._on_group(lambda k: k.open_begin(polys, self.z_mont, self.chi_mont), tensors=list(polys))
         else:
             self.ck.open_begin(polys, self.z_mont, self.chi_mont)
         self._pending.append(("q", 1))
 
-    def _on_group(self, fn):
+    def _on_group(self, fn, tensors=()):
         """split_rounds: queue one job of the open round on this ctx (every m-th job) or on the second ctx / stream (the others; the
-        second stream first waits for what the main stream has queued so far -- the job's input)."""
+        second stream first waits for what the main stream has queued so far -- the job's input).  `tensors`: the main-stream
+        tensors the job reads -- told to the caching allocator (record_stream) so that a block freed on the main stream is not handed
+        out again while the side stream still reads it."""
         which = "a" if len(self._order) % self.split_rounds == 0 else "b"
         self._order.append(which)
         if which == "a":
@@ -323,6 +325,8 @@ class ProofSchedule:
         torch = self.torch
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(self.side)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             fn(self.ck2)
@@ -344,6 +348,15 @@ class ProofSchedule:
             done = torch.cuda.Event()
             done.record(self.side)
         self._side_done.append(done)
+        # results allocated under the side stream are consumed on the main one: tell the caching allocator, or a block freed there
+        # could be handed back to side-stream work while main-stream kernels still read it
+        stack = [out]
+        while stack:
+            o = stack.pop()
+            if isinstance(o, (list, tuple)):
+                stack.extend(o)
+            elif hasattr(o, "record_stream"):
+                o.record_stream(main)
         return out
 
     def _join_side(self):

@@ -3,8 +3,9 @@
   * by points  -- rank g owns SRS[g n/G, (g+1) n/G) and that slice of every coefficient vector (ragged vectors leave late ranks short or
                   empty), its own whole window table;
   * by windows -- rank g owns rows g, g+G, ... of the window table over the whole SRS (c = 16 or 17) and sees whole vectors;
-and the exchange in both forms: Jacobian partials through the host (`round_end_partial` + `sum_partials_batch`) or internal partials
-left on the device (`round_end_partial_dev`, a (G, jobs x words) tensor as the all-gather would leave it, `sum_partials_dev`).
+and the exchange in its three forms: Jacobian partials through the host (`round_end_partial` + `sum_partials_batch`), one internal point per
+job left on the device (`round_end_partial_dev`, a (G, jobs x words) tensor as the all-gather would leave it, `sum_partials_dev`), or --
+round 5 -- every job's virtual-window sums left on the device and added element-wise (`round_end_winsums_dev`, `sum_winsums_dev`).
 The sum over the ranks must be the commitment of the CPU restatement, limb for limb.
 usage: [SEED=..] [MAX_LOG_N=17] python tests/stress/stress_shards.py [seconds]   (a short budget runs under tests/test_stress_gpu.py)"""
 import os
@@ -38,7 +39,8 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
         n = 1 << log_n
         G = int(rng.choice([2, 3, 4, 5, 8]))
         axis = "windows" if rng.random() < 0.5 else "points"
-        on_device = bool(rng.random() < 0.6)
+        form = str(rng.choice(["host", "point", "winsums", "winsums"]))
+        on_device = form != "host"
         ks = np.zeros((n, 4), dtype=np.uint64)
         ks[:, 0] = rng.integers(1, 1 << 40, size=n, dtype=np.uint64)
         bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
@@ -66,7 +68,7 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
             if axis == "points":
                 lo, hi = g * n // G, (g + 1) * n // G
                 ck = zk.CommitterKey(bases[lo:hi].contiguous(), cid, ctx)
-                if hi - lo >= 8192 or rng.random() < 0.5:
+                if hi - lo >= 8192 or form == "winsums" or rng.random() < 0.5:      # the window-sum form needs every rank's table (one geometry)
                     ck.precompute(c_bits)
                 mine = [p[lo:max(lo, min(hi, p.shape[0]))] for p in d_polys]
             else:
@@ -76,15 +78,17 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
                 mine = d_polys
             live = [q for q in mine if q.shape[0] > 0]
             if on_device:
-                words = ck.partial_dev_words()
+                ws = form == "winsums"
+                words = ck.winsums_dev_words() if ws else ck.partial_dev_words()
+                assert words > 0, (form, axis, c_bits)
                 buf = torch.zeros((k, words), dtype=torch.int64, device="cuda")       # all-zero row = the point at infinity (empty shard)
                 if live:
                     sub = torch.empty((len(live), words), dtype=torch.int64, device="cuda")
                     for q in live:
                         ck.commit_begin([q])
                     if rng.random() < 0.5:
-                        ck.round_reduce_partial_dev(sub)
-                    ck.round_end_partial_dev(sub, len(live))
+                        (ck.round_reduce_winsums_dev if ws else ck.round_reduce_partial_dev)(sub)
+                    (ck.round_end_winsums_dev if ws else ck.round_end_partial_dev)(sub, len(live))
                     idx = torch.tensor([j for j, q in enumerate(mine) if q.shape[0] > 0], dtype=torch.int64, device="cuda")
                     buf.index_copy_(0, idx, sub)
                 dev_parts.append(buf.reshape(-1))
@@ -97,16 +101,18 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
             keep = ck          # the summing call needs any key of the curve on this ctx
             if g < G - 1:
                 ck.close()
-        if on_device:
+        if form == "winsums":
+            got = keep.sum_winsums_dev(torch.stack(dev_parts), G, k)
+        elif on_device:
             got = keep.sum_partials_dev(torch.stack(dev_parts), G, k)
         else:
             got = zk.sum_partials_batch(np.stack(host_parts), cid)
         keep.close()
         for p, pt in zip(polys, got):
             exp_xy, exp_inf = cpu.kzg_commit(cid, bases_h, p)
-            assert pt.infinity == bool(exp_inf) and np.array_equal(pt.xy(), exp_xy), (cid, n, G, axis, on_device, c_bits, len(p))
+            assert pt.infinity == bool(exp_inf) and np.array_equal(pt.xy(), exp_xy), (cid, n, G, axis, form, c_bits, len(p))
             checks += 1
-        seen.add((axis, on_device))
+        seen.add((axis, form))
         rounds += 1
     if own:
         ctx.close()

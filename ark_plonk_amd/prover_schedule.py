@@ -73,7 +73,7 @@ class ProofSchedule:
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
                  ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
-                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool = True, split_rounds: int = 0,
+                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool | None = None, split_rounds: int = 0,
                  exchange: str | None = None):
         import torch
         self.torch = torch
@@ -230,15 +230,18 @@ class ProofSchedule:
             self.lo = rank * n // world
             self.hi = (rank + 1) * n // world
         # The exchange of a sharded round (world > 1), three forms, same points:
-        #   "winsums" (default)  every job's 2 VW virtual-window sums, written by the reduction kernel the single-GPU path ends with, straight
+        #   "winsums"            every job's 2 VW virtual-window sums, written by the reduction kernel the single-GPU path ends with, straight
         #                        into the collective's send buffer; all-gathered (32 KiB per job); added element-wise by one kernel; ONE
         #                        host wait, the combine per job on the host pool (zk_kzg_round_end_winsums_dev / zk_g1_sum_winsums_dev)
         #   "point"              round 4's device form: one more dependent quad launch forms every job's sum, 256 B per job gathered
         #                        (zk_kzg_round_end_partial_dev / zk_g1_sum_partials_dev)
-        #   "host"               round 3's: window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
+        #   "host" (default)     round 3's: window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
+        # Default = the fastest on ONE card (profiles/r05_sim_rank.txt: "host" by 1-2 % over "winsums", "point" last); on a node the
+        # device forms save a host round trip before and after every collective -- bench.py times both there.  `partials_on_device=True`
+        # without `exchange` selects "winsums".
         # The device forms need the deferred rounds, a table with c <= 17 and no commitment cache; otherwise "host" is used.
         if exchange is None:
-            exchange = "winsums" if partials_on_device else "host"
+            exchange = "winsums" if partials_on_device is True else "host"
         if exchange not in ("winsums", "point", "host"):
             raise ValueError("exchange: 'winsums', 'point' or 'host'")
         geom = ck.winsums_geometry() if world > 1 else None

@@ -458,8 +458,11 @@ def parse_args():
                     help="sharded MSMs (N > 1): 'points' = rank g owns SRS[g n/G, (g+1) n/G) and that slice of every polynomial (SURVEY.md 8e's "
                          "preferred axis); 'windows' = rank g holds the whole SRS and the table rows of the windows g, g + G, ... "
                          "(BASELINE.json north_star's wording; zk_srs_precompute_rows)")
-    ap.add_argument("--exchange", default="winsums", choices=["winsums", "point", "host"],
-                    help="sharded MSMs, what the ranks all-gather per group of PC calls: 'winsums' (default) = every job's 2 VW virtual-window sums as "
+    ap.add_argument("--exchange", default="host", choices=["winsums", "point", "host"],
+                    help="sharded MSMs, what the ranks all-gather per group of PC calls (default 'host': the fastest of the three on ONE card with a "
+                         "stand-in collective, profiles/r05_sim_rank.txt -- by 1-2 %% over 'winsums', which removes a host round trip before and "
+                         "after every collective that a one-card run cannot see; an N > 1 run times BOTH, legs msm_sharded and "
+                         "msm_sharded_winsums): 'winsums' = every job's 2 VW virtual-window sums as "
                          "the last reduction kernel of the single-GPU path leaves them on the device (32 KiB per job), added element-wise by one "
                          "kernel, one host combine per job (zk_kzg_round_end_winsums_dev -> all_gather_into_tensor -> zk_g1_sum_winsums_dev); "
                          "'point' = round 4's device form, one more dependent launch per group forms each job's sum (256 B per job; "
@@ -1111,11 +1114,17 @@ def main():
     if world > 1 and mode == "replica" and not args.no_sharded_leg:
         # the same proofs with every MSM point-sharded over the ranks (one RCCL all-gather of Jacobian partials per
         # prover round) -- single-proof latency
-        def shard_leg(lg):
+        def shard_leg(lg, exchange=None):
             def run():
                 if rank == args.fault_rank:
                     os._exit(41)              # test hook: a rank lost inside an extra leg (tests/test_distributed.py)
-                rs = timed_region(True, log_n=lg)
+                saved = args.exchange
+                if exchange:
+                    args.exchange = exchange
+                try:
+                    rs = timed_region(True, log_n=lg)
+                finally:
+                    args.exchange = saved
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
                      "collective": "all_gather of the jobs' partials, one per group of PC calls (5 per proof; 11 with --block-every-call): "
                                    + {"host": "3L-limb host Jacobian partials (--exchange host)",
@@ -1137,6 +1146,9 @@ def main():
                 return d
             return run
         leg("msm_sharded", shard_leg(log_n))
+        # the same with the other form of the exchange: which of the two wins on a real node is this run's to measure
+        other = "winsums" if args.exchange != "winsums" else "host"
+        leg("msm_sharded_" + other, shard_leg(log_n, other))
         n22 = args.sharded_n22_leg == "on" or (args.sharded_n22_leg == "auto" and log_n == 20 and cv.curve_id == 0)
         if n22 and log_n != 22:
             leg("msm_sharded_n22", shard_leg(22))

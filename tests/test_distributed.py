@@ -149,12 +149,14 @@ def test_bench_two_ranks_matches_one_rank():
     assert d1["commitments_sha256"] == d4["commitments_sha256"]
     d5 = two_ranks(["--mode", "shard", "--shard-axis", "windows", "--host-partials"])
     assert d1["commitments_sha256"] == d5["commitments_sha256"]
-    # the three forms of the exchange: window sums (default), one point per job (round 4), host Jacobians (round 3)
-    assert "'winsums'" in d3["config"]["parallelism"] and "'winsums'" in d4["config"]["parallelism"] and "'host'" in d5["config"]["parallelism"]
+    # the three forms of the exchange: host Jacobians (round 3; the default: fastest on one card), one point per job (round 4), window sums (round 5)
+    assert "'host'" in d3["config"]["parallelism"] and "'host'" in d4["config"]["parallelism"] and "'host'" in d5["config"]["parallelism"]
     d6 = two_ranks(["--mode", "shard", "--exchange", "point"])
     assert "'point'" in d6["config"]["parallelism"] and d1["commitments_sha256"] == d6["commitments_sha256"]
+    d7 = two_ranks(["--mode", "shard", "--exchange", "winsums", "--shard-axis", "windows"])
+    assert "'winsums'" in d7["config"]["parallelism"] and d1["commitments_sha256"] == d7["commitments_sha256"]
     # every N > 1 line says what the backend saw: two processes, ONE card here (a gloo rehearsal), the all-reduced sum of ones
-    for d in (d2, d3, d4, d5, d6):
+    for d in (d2, d3, d4, d5, d6, d7):
         rk = d["ranks"]
         assert rk["world"] == 2 and rk["sum_check"] == 2 and rk["distinct_devices"] == 1 and rk["shared_card"] is True and len(rk["devices"]) == 2
     assert "ranks" not in d1
@@ -701,9 +703,11 @@ def test_bench_gpus_4_one_card():
     assert d4["n_gpus"] == 4 and d4["scaling"] == "weak" and d4["commitments_sha256"] == d1["commitments_sha256"]
     assert d4["ranks"]["world"] == 4 and d4["ranks"]["sum_check"] == 4 and d4["ranks"]["distinct_devices"] == 1
     ms = d4["msm_sharded"]
-    assert ms.get("commitments_match_replicas") is True and ms["exchange"] == "winsums" and ms["collectives_per_proof"] == 5, ms
-    for axis in ("points", "windows"):
-        r, l, _ = _run_bench(common + ["--gpus", "4", "--backend", "gloo", "--mode", "shard", "--shard-axis", axis], 900)
+    assert ms.get("commitments_match_replicas") is True and ms["exchange"] == "host" and ms["collectives_per_proof"] == 5, ms
+    mw = d4["msm_sharded_winsums"]          # the same leg with the other form of the exchange: an N > 1 run times both
+    assert mw.get("commitments_match_replicas") is True and mw["exchange"] == "winsums" and mw["collectives_per_proof"] == 5, mw
+    for axis, form in (("points", "winsums"), ("windows", "host")):
+        r, l, _ = _run_bench(common + ["--gpus", "4", "--backend", "gloo", "--mode", "shard", "--shard-axis", axis, "--exchange", form], 900)
         assert r.returncode == 0, r.stderr[-3000:]
         assert l[-1]["scaling"] == "strong" and l[-1]["commitments_sha256"] == d1["commitments_sha256"], axis
 

@@ -191,6 +191,44 @@ struct Fu {
         r.v[NL - 1] = (uint32_t)carry;
         return r;
     }
+    // `mul` with every column's chain STARTED from the carry of the column below: the first partial sum (carry + first product) is
+    // passed through an empty, non-volatile asm, which the optimiser cannot look through -- so it cannot compute the columns as
+    // independent chains and add the carries afterwards (one v_lshl_add_u64 and most of a v_mov per column in `mul`'s code).
+    // Costs nothing itself; the chains of the several products a caller has in flight still interleave.
+    ZK_HD static uint64_t fence64(uint64_t t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(t));
+#endif
+        return t;
+    }
+    ZK_HD static Fu mul_fenced(const Fu& a, const Fu& b) {
+        uint32_t m[NL];
+        Fu r;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            uint64_t t = fence64(carry + (uint64_t)a.v[0] * b.v[k]);
+#pragma unroll
+            for (int i = 1; i <= k; ++i) t += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = 0; i < k; ++i) t += (uint64_t)m[i] * P::MOD(k - i);
+            m[k] = ((uint32_t)t * P::PINV) & M;
+            t += (uint64_t)m[k] * P::MOD(0);
+            carry = t >> 29;
+        }
+#pragma unroll
+        for (int k = NL; k < 2 * NL - 1; ++k) {
+            uint64_t t = fence64(carry + (uint64_t)a.v[k - NL + 1] * b.v[NL - 1]);
+#pragma unroll
+            for (int i = k - NL + 2; i < NL; ++i) t += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = k - NL + 1; i < NL; ++i) t += (uint64_t)m[i] * P::MOD(k - i);
+            r.v[k - NL] = (uint32_t)t & M;
+            carry = t >> 29;
+        }
+        r.v[NL - 1] = (uint32_t)carry;
+        return r;
+    }
     // a*a/R' : cross products once, against pre-doubled limbs; same accumulator split
     ZK_HD static Fu sqr(const Fu& a) {
         uint32_t m[NL], a2[NL];

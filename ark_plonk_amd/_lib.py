@@ -66,6 +66,9 @@ SYMBOLS = {
     "zk_ctx_use_own_stream": (c_int, [c_void_p]),
     "zk_ctx_sync": (c_int, [c_void_p]),
     "zk_ctx_set_msm_window": (c_int, [c_void_p, c_int]),
+    "zk_ctx_set_residency_cache": (c_int, [c_void_p, c_int, c_size_t, c_size_t]),
+    "zk_residency_cache_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint64)]),
     "zk_ctx_set_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "zk_ctx_get_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "zk_profile_enable": (c_int, [c_void_p, c_int]),

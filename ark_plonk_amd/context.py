@@ -99,6 +99,15 @@ class Context:
         check(lib().zk_commit_cache_stats(self.handle, *[ctypes.byref(x) for x in v]), "zk_commit_cache_stats")
         return {"hits": v[0].value, "misses": v[1].value, "entries": v[2].value}
 
+    # -- residency cache of the host-pointer entry points (vectors this ctx produced or uploaded are not sent again)
+    def set_residency_cache(self, on: bool = True, capacity_bytes: int = 0, max_vector_bytes: int = 0):
+        check(lib().zk_ctx_set_residency_cache(self.handle, 1 if on else 0, int(capacity_bytes), int(max_vector_bytes)), "zk_ctx_set_residency_cache")
+
+    def residency_cache_stats(self) -> dict:
+        v = [ctypes.c_uint64() for _ in range(4)]
+        check(lib().zk_residency_cache_stats(self.handle, *[ctypes.byref(x) for x in v]), "zk_residency_cache_stats")
+        return {"hits": v[0].value, "misses": v[1].value, "entries": v[2].value, "bytes": v[3].value}
+
     # -- host-pointer entry points: PCIe volume and staging mode
     def io_stats(self, reset: bool = False) -> dict:
         a, b = ctypes.c_uint64(), ctypes.c_uint64()

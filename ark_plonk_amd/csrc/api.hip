@@ -138,6 +138,135 @@ int ensure_pinned_jobs(zk_ctx* c) {
     return ZK_OK;
 }
 
+// ---- residency cache of the host-pointer entry points (ctx lock held) ------------------------------------------------
+constexpr uint64_t RES_SEED = 0x52455349444Eull;
+
+inline bool res_wants(const zk_ctx* c, size_t bytes) { return c->res_on && bytes >= 4096 && bytes <= c->res_max_vec; }
+
+// every host-pointer call that consults the cache starts a new epoch: what it touches stays until it returns
+inline void res_begin_call(zk_ctx* c) { ++c->res_epoch; }
+
+zk_ctx::ResEntry* res_find(zk_ctx* c, size_t bytes, const uint64_t dig[4]) {
+    for (auto it = c->res.begin(); it != c->res.end(); ++it)
+        if (it->valid && it->bytes == bytes && memcmp(it->dig, dig, 32) == 0) {
+            it->epoch = c->res_epoch;
+            if (it != c->res.begin()) c->res.splice(c->res.begin(), c->res, it);
+            ++c->res_hits;
+            return &c->res.front();
+        }
+    ++c->res_misses;
+    return nullptr;
+}
+
+// a fresh entry of `bytes` at the front of the list (not yet valid), or nullptr when nothing may be evicted / allocated: the
+// caller then takes the uncached path.  Evicted buffers are kept for reuse (hipFree synchronises the device).
+zk_ctx::ResEntry* res_new(zk_ctx* c, size_t bytes) {
+    while (c->res_bytes + bytes > c->res_cap) {
+        auto it = c->res.end();
+        bool found = false;
+        while (it != c->res.begin()) {
+            --it;
+            if (it->epoch != c->res_epoch) {
+                found = true;
+                break;
+            }
+        }
+        if (!found) return nullptr;
+        c->res_bytes -= it->bytes;
+        if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
+        else it->buf.release();
+        c->res.erase(it);
+    }
+    DevBuf buf;
+    for (size_t i = 0; i < c->res_free.size(); ++i)
+        if (c->res_free[i].cap >= bytes && (buf.cap == 0 || c->res_free[i].cap < buf.cap)) buf = c->res_free[i];
+    if (buf.cap) {
+        for (size_t i = 0; i < c->res_free.size(); ++i)
+            if (c->res_free[i].p == buf.p) {
+                c->res_free.erase(c->res_free.begin() + (long)i);
+                break;
+            }
+    } else if (buf.ensure(bytes) != ZK_OK) {
+        return nullptr;
+    }
+    c->res.emplace_front();
+    zk_ctx::ResEntry& e = c->res.front();
+    e.bytes = bytes;
+    e.buf = buf;
+    e.epoch = c->res_epoch;
+    e.valid = false;
+    c->res_bytes += bytes;
+    return &e;
+}
+
+void res_drop(zk_ctx* c, zk_ctx::ResEntry* e) {        // an entry whose production failed
+    for (auto it = c->res.begin(); it != c->res.end(); ++it)
+        if (&*it == e) {
+            c->res_bytes -= it->bytes;
+            if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
+            else it->buf.release();
+            c->res.erase(it);
+            return;
+        }
+}
+
+// a failed call: whatever it touched or created may hold bytes that never arrived
+void res_fail_call(zk_ctx* c) {
+    for (auto it = c->res.begin(); it != c->res.end();) {
+        if (it->epoch == c->res_epoch) {
+            c->res_bytes -= it->bytes;
+            if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
+            else it->buf.release();
+            it = c->res.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+void res_clear(zk_ctx* c) {
+    for (auto& e : c->res) e.buf.release();
+    c->res.clear();
+    for (auto& b : c->res_free) b.release();
+    c->res_free.clear();
+    c->res_bytes = 0;
+}
+
+// Inputs of one host-pointer call: for every vector the cache may hold (res_wants), its digest (all of them as ONE batch of work on
+// the ctx's host pool) and, on a hit, the device copy.  On a miss a fresh entry takes the upload (the caller copies into *d_ptr and
+// the vector is resident from then on); where the cache cannot take it, *d_ptr stays null and the caller uses its own staging buffer.
+struct ResInput {
+    const void* d_ptr = nullptr;   // device copy to use (hit, or the fresh entry a miss uploads into)
+    bool upload = true;            // the bytes still have to go up
+};
+void res_resolve(zk_ctx* c, uint32_t n, const void* const* h_ptrs, const size_t* bytes, ResInput* out) {
+    const void* hp[16];
+    size_t hb[16];
+    uint32_t idx[16], m = 0;
+    for (uint32_t k = 0; k < n && k < 16; ++k) {
+        out[k] = ResInput();
+        if (res_wants(c, bytes[k]) && h_ptrs[k]) {
+            hp[m] = h_ptrs[k];
+            hb[m] = bytes[k];
+            idx[m++] = k;
+        }
+    }
+    if (!m) return;
+    uint64_t dig[16][4];
+    host_digest256_multi(c->pool.get(), hp, hb, m, RES_SEED, dig);
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t k = idx[j];
+        if (zk_ctx::ResEntry* e = res_find(c, hb[j], dig[j])) {
+            out[k].d_ptr = e->buf.p;
+            out[k].upload = false;
+        } else if (zk_ctx::ResEntry* f = res_new(c, hb[j])) {
+            memcpy(f->dig, dig[j], 32);
+            f->valid = true;            // its bytes go up in stream order before anything reads them
+            out[k].d_ptr = f->buf.p;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,6 +331,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_tmp};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < 16; ++i) c->mb[i].release();
+        res_clear(c);
         for (int i = 0; i < 16; ++i)
             if (c->ev_job[i]) (void)hipEventDestroy(c->ev_job[i]);
         if (c->round_ev) (void)hipEventDestroy(c->round_ev);
@@ -293,6 +423,28 @@ int zk_ctx_get_option(zk_ctx* c, const char* key, int64_t* value) {
     return ZK_OK;
 }
 
+int zk_ctx_set_residency_cache(zk_ctx* c, int enable, size_t capacity_bytes, size_t max_vector_bytes) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (round_open(c)) return ZK_ERR_PENDING;
+    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (capacity_bytes) c->res_cap = capacity_bytes;
+    if (max_vector_bytes) c->res_max_vec = max_vector_bytes;
+    c->res_on = enable != 0;
+    if (!c->res_on) res_clear(c);
+    return ZK_OK;
+}
+
+int zk_residency_cache_stats(zk_ctx* c, uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* bytes) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (hits) *hits = c->res_hits;
+    if (misses) *misses = c->res_misses;
+    if (entries) *entries = c->res.size();
+    if (bytes) *bytes = c->res_bytes;
+    return ZK_OK;
+}
+
 int zk_profile_enable(zk_ctx* c, int on) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
@@ -370,14 +522,64 @@ int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in
     const size_t n = (size_t)1 << log_n;
     if (in_len > n) return ZK_ERR_BAD_ARG;
     int rc;
-    if ((rc = c->io_a.ensure((in_len ? in_len : 1) * 32))) return rc;
-    if ((rc = c->io_b.ensure(n * 32))) return rc;
-    if (in_len && (rc = zk_h2d(c, c->io_a.p, in, in_len * 32, c->stream))) return rc;
-    rc = ntt_run_dev(c, curve_id, kind, log_n, c->io_a.p, in_len, c->io_b.p);
-    if (rc) return rc;
-    if ((rc = zk_d2h(c, out, c->io_b.p, n * 32, c->stream))) return rc;
-    ZK_HIP_TRY(hipStreamSynchronize(c->stream));
-    return ZK_OK;
+    // residency cache.  Which vectors come back is a property of the transforms' direction: the OUTPUT of an inverse transform is a
+    // coefficient vector -- what PC::commit, PC::open and the coset transforms take next (prover.rs:196-213, quotient_poly.rs:72-120)
+    // -- so it is produced into a cache entry and named by the digest of the bytes the caller receives; the INPUT of a forward
+    // transform is a coefficient vector, so it is looked up (and not inserted on a miss: only commitments insert what they upload).
+    // Inputs of inverse transforms and outputs of forward ones are evaluation vectors, made and consumed by host code: never digested.
+    // (A policy about time only: a vector that is not looked up is simply uploaded.)
+    const bool inverse = kind == ZK_NTT_IFFT || kind == ZK_NTT_COSET_IFFT;
+    const void* d_in = nullptr;
+    bool need_upload = in_len != 0;
+    zk_ctx::ResEntry* out_entry = nullptr;
+    if (c->res_on) {
+        res_begin_call(c);
+        if (!inverse && res_wants(c, in_len * 32)) {
+            const void* hp = in;
+            const size_t hb = in_len * 32;
+            uint64_t dig[1][4];
+            host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
+            if (zk_ctx::ResEntry* e = res_find(c, hb, dig[0])) {
+                d_in = e->buf.p;
+                need_upload = false;
+            }
+        }
+        if (inverse && res_wants(c, n * 32)) out_entry = res_new(c, n * 32);
+    }
+    if (!d_in) {
+        if ((rc = c->io_a.ensure((in_len ? in_len : 1) * 32))) return rc;
+        d_in = c->io_a.p;
+    }
+    void* d_out = out_entry ? out_entry->buf.p : nullptr;
+    if (!d_out) {
+        if ((rc = c->io_b.ensure(n * 32))) return rc;
+        d_out = c->io_b.p;
+    }
+    if (need_upload && (rc = zk_h2d(c, const_cast<void*>(d_in), in, in_len * 32, c->stream))) {
+        if (c->res_on) res_fail_call(c);
+        return rc;
+    }
+    rc = ntt_run_dev(c, curve_id, kind, log_n, d_in, in_len, d_out);
+    if (!rc) rc = zk_d2h(c, out, d_out, n * 32, c->stream);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    if (rc && c->res_on) {
+        (void)hipStreamSynchronize(c->stream);
+        res_fail_call(c);
+        out_entry = nullptr;
+    }
+    if (out_entry) {
+        if (rc) {
+            res_drop(c, out_entry);
+        } else {
+            const void* hp = out;
+            const size_t hb = n * 32;
+            uint64_t dig[1][4];
+            host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
+            memcpy(out_entry->dig, dig[0], 32);
+            out_entry->valid = true;
+        }
+    }
+    return rc;
 }
 
 int zk_ntt_batch(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const uint64_t* const* ins, const size_t* in_lens,
@@ -1227,13 +1429,38 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
     int rc = ensure_copy_stream(c);
     if (rc) return rc;
     const void* d_in[16];
+    // residency cache: polynomials this ctx produced (zk_ntt outputs) or uploaded before are used where they lie; the others go up
+    // into a fresh entry (resident from then on) or, where the cache cannot take them, into the job's staging buffer.  Polynomial k is
+    // digested right before job k is queued, i.e. while the GPU runs job k - 1: like the uploads, the digests hide under the MSMs.
+    // Every job gets a stable input pointer up front (a fresh entry or its staging buffer); a hit copies nothing into it and points the
+    // job at the resident copy instead -- d_in[k] is read when job k is queued, after up(k) has run.
+    const void* d_in[16];
+    bool cached[16] = {false};
+    if (c->res_on) res_begin_call(c);
     for (uint32_t k = 0; k < n_polys; ++k) {
         if (lens[k] > s->n) return ZK_ERR_BAD_ARG;
+        cached[k] = res_wants(c, lens[k] * 32);
         if ((rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
         d_in[k] = c->mb[k].upload.p;
     }
     BeforeJob up = [&](uint32_t k) -> int {
-        int r = zk_h2d(c, c->mb[k].upload.p, coeffs_mont[k], lens[k] * 32, c->copy_stream);
+        if (lens[k] == 0) return ZK_OK;
+        if (cached[k]) {
+            const void* hp = coeffs_mont[k];
+            const size_t hb = lens[k] * 32;
+            uint64_t dig[1][4];
+            host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
+            if (zk_ctx::ResEntry* e = res_find(c, hb, dig[0])) {
+                d_in[k] = e->buf.p;                    // resident: nothing crosses PCIe, nothing to wait for
+                return ZK_OK;
+            }
+            if (zk_ctx::ResEntry* f = res_new(c, hb)) {
+                memcpy(f->dig, dig[0], 32);
+                f->valid = true;                       // its bytes go up in stream order before anything reads them
+                d_in[k] = f->buf.p;
+            }
+        }
+        int r = zk_h2d(c, const_cast<void*>(d_in[k]), coeffs_mont[k], lens[k] * 32, c->copy_stream);
         if (r) return r;
         ZK_HIP_TRY(hipEventRecord(c->ev_up[k], c->copy_stream));
         ZK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
@@ -1244,7 +1471,12 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
             if ((rc = up(k))) return rc;
         return batch_cached_locked(c, s, n_polys, d_in, lens, nullptr, out_xy, out_inf);
     }
-    return batch_locked(c, s, n_polys, d_in, lens, nullptr, nullptr, out_xy, out_inf, &up);
+    rc = batch_locked(c, s, n_polys, d_in, lens, nullptr, nullptr, out_xy, out_inf, &up);
+    if (rc && c->res_on) {
+        (void)hipStreamSynchronize(c->stream);
+        res_fail_call(c);
+    }
+    return rc;
 }
 
 int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
@@ -1278,14 +1510,38 @@ int zk_kzg_open(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* p
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
     const void* d_in[16];
-    for (uint32_t k = 0; k < n_polys; ++k) {
+    ResInput ri[16];
+    for (uint32_t k = 0; k < n_polys; ++k)
         if (lens[k] && !polys_mont[k]) return ZK_ERR_BAD_ARG;
-        int rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32);
-        if (rc) return rc;
-        if ((rc = zk_h2d(c, c->mb[k].upload.p, polys_mont[k], lens[k] * 32, c->stream))) return rc;
-        d_in[k] = c->mb[k].upload.p;
+    if (c->res_on) {      // the eleven / seven polynomials of an opening were all transformed or committed before (prover.rs:582-618)
+        res_begin_call(c);
+        const void* hp[16];
+        size_t hb[16];
+        for (uint32_t k = 0; k < n_polys; ++k) {
+            hp[k] = polys_mont[k];
+            hb[k] = lens[k] * 32;
+        }
+        res_resolve(c, n_polys, hp, hb, ri);
     }
-    return zk_kzg_open_dev(c, s, n_polys, d_in, lens, z_mont, challenge_mont, out_xy, out_inf);
+    for (uint32_t k = 0; k < n_polys; ++k) {
+        int rc;
+        if (ri[k].d_ptr) {
+            d_in[k] = ri[k].d_ptr;
+        } else {
+            if ((rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
+            d_in[k] = c->mb[k].upload.p;
+        }
+        if (ri[k].upload && (rc = zk_h2d(c, const_cast<void*>(d_in[k]), polys_mont[k], lens[k] * 32, c->stream))) {
+            if (c->res_on) res_fail_call(c);
+            return rc;
+        }
+    }
+    const int rc2 = zk_kzg_open_dev(c, s, n_polys, d_in, lens, z_mont, challenge_mont, out_xy, out_inf);
+    if (rc2 && c->res_on) {
+        (void)hipStreamSynchronize(c->stream);
+        res_fail_call(c);
+    }
+    return rc2;
 }
 
 int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,

@@ -273,6 +273,23 @@ struct zk_ctx {
     DevBuf digest_dev;                        // 16 jobs x 4 u64
     uint64_t digest_key[4] = {0, 0, 0, 0};    // zk_process_key mixed with the ctx's address: keys the device digests of this cache
 
+    // Residency cache of the HOST-POINTER entry points (zk_ctx_set_residency_cache; opt-in): device copies of vectors this ctx
+    // produced (zk_ntt outputs of at most res_max_vec bytes) or uploaded, keyed by (bytes, keyed 256-bit digest of the HOST bytes).
+    // A later zk_ntt / zk_kzg_commit_batch / zk_kzg_open input with the same bytes uses the copy instead of crossing PCIe again
+    // (prover.rs:196-213: an `ifft` output goes straight back up as a `commit` input, then into `coset_fft`, `open`, ...).
+    struct ResEntry {
+        size_t bytes = 0;
+        uint64_t dig[4] = {0, 0, 0, 0};
+        bool valid = false;          // dig names the buffer's contents (false while an output is still being produced)
+        uint64_t epoch = 0;          // the call that last used it: entries of the running call are never evicted
+        DevBuf buf;
+    };
+    bool res_on = false;
+    size_t res_cap = (size_t)2 << 30, res_max_vec = (size_t)64 << 20, res_bytes = 0;
+    std::list<ResEntry> res;         // most recently used first
+    std::vector<DevBuf> res_free;    // buffers of evicted entries, reused before anything is allocated
+    uint64_t res_epoch = 0, res_hits = 0, res_misses = 0;
+
     // open round (zk_kzg_round_begin_dev / zk_kzg_open_begin_dev ... zk_kzg_round_end): jobs whose sort + accumulate are queued
     // on the stream and whose reduction waits for the round to close, in submission order.  Job k lives in buffer set mb[k].
     struct PendingJob {
@@ -415,6 +432,8 @@ int zk_d2h(zk_ctx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t 
 void zk_io_release(zk_ctx* c);
 // 256-bit digest of a host buffer (4 lanes; block-parallel on the ctx-less pool)
 void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]);
+// the same digest for several buffers at once on a given pool (all 1 MiB blocks of all buffers as one batch of work items)
+void host_digest256_multi(HostPool* pool, const void* const* ptrs, const size_t* bytes, uint32_t n, uint64_t seed, uint64_t (*out)[4]);
 // 256-bit multiset digests of n_jobs device vectors of 32-byte elements -> d_out[job][4] (async on st)
 // keyed with `key` (the ctx's digest_key): see hostio.hip
 int dev_digest256(const void* const* d_ptrs, const size_t* lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st, const uint64_t key[4]);

@@ -170,6 +170,33 @@ void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4])
     block_digest((const uint8_t*)parts.data(), parts.size() * 8, seed ^ (uint64_t)bytes, key, out);
 }
 
+void host_digest256_multi(HostPool* pool, const void* const* ptrs, const size_t* bytes, uint32_t n, uint64_t seed, uint64_t (*out)[4]) {
+    constexpr size_t BLOCK = (size_t)1 << 20;
+    uint64_t key[4];
+    zk_process_key(key);
+    std::vector<uint32_t> first(n + 1, 0);
+    for (uint32_t k = 0; k < n; ++k) first[k + 1] = first[k] + (uint32_t)((bytes[k] + BLOCK - 1) / BLOCK);
+    std::vector<uint64_t> parts((size_t)first[n] * 4);
+    auto item = [&](uint32_t i) {
+        uint32_t k = 0;
+        while (first[k + 1] <= i) ++k;                       // n <= 16
+        const uint32_t b = i - first[k];
+        const size_t off = (size_t)b * BLOCK;
+        const size_t len = bytes[k] - off < BLOCK ? bytes[k] - off : BLOCK;
+        block_digest((const uint8_t*)ptrs[k] + off, len, seed ^ (P4 * (uint64_t)(b + 1)), key, &parts[(size_t)i * 4]);
+    };
+    if (pool) pool->run(first[n], item);
+    else host_parallel_for(first[n], item);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t nb = first[k + 1] - first[k];
+        if (nb == 0) {
+            block_digest(nullptr, 0, seed, key, out[k]);
+            continue;
+        }
+        block_digest((const uint8_t*)&parts[(size_t)first[k] * 4], (size_t)nb * 32, seed ^ (uint64_t)bytes[k], key, out[k]);
+    }
+}
+
 int dev_digest256(const void* const* d_ptrs, const size_t* d_lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st, const uint64_t key[4]) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > 16) return ZK_ERR_BAD_ARG;

@@ -756,7 +756,36 @@ def main():
         torch.cuda.synchronize()
         dt_cache = time.perf_counter() - t0
         ctx.set_commit_cache(False)
-        out = {"proofs_per_s": k / dt, "proofs_per_s_with_commit_cache": k / dt_cache, "ms_per_proof": dt / k * 1e3, "steps": k,
+        # the same caller with the library's residency cache switched on (one more call in the shim): vectors the library produced or has
+        # seen are not uploaded again -- every proof has its own witness, so the evaluation vectors still miss, as they would in production
+        res = None
+        try:
+            ctx.set_residency_cache(True)
+            for _ in range(5):                  # until the cache has reached its capacity: from then on evicted buffers are reused and
+                sched.run_once()                # no call allocates device memory any more (the steady state of a proving service)
+            ctx.io_stats(reset=True)
+            st0 = ctx.residency_cache_stats()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                sched.run_once()
+            torch.cuda.synchronize()
+            dt_res = time.perf_counter() - t0
+            io_r = ctx.io_stats()
+            st1 = ctx.residency_cache_stats()
+            pts_r = sched.run_once(proof_id=0) if args.check else None
+            res = {"proofs_per_s": k / dt_res, "ms_per_proof": dt_res / k * 1e3, "h2d_bytes_per_proof": io_r["h2d_bytes"] // k,
+                   "d2h_bytes_per_proof": io_r["d2h_bytes"] // k, "hits_per_proof": (st1["hits"] - st0["hits"]) / k,
+                   "misses_per_proof": (st1["misses"] - st0["misses"]) / k, "resident_bytes": st1["bytes"],
+                   "same_points_as_uncached": (digest(pts_r) == digest(pts)) if args.check else None,
+                   "how": "zk_ctx_set_residency_cache(ctx, 1, 0, 0): zk_ntt keeps the device copy of every output of at most 64 MiB under a keyed 256-bit "
+                          "digest of the bytes the caller receives; zk_ntt / zk_kzg_commit_batch / zk_kzg_open digest their inputs on the host pool and "
+                          "use the resident copy on a match (prover.rs:196-213,569-618: an ifft output goes back up as a commit, coset_fft and "
+                          "opening input)"}
+        except Exception as e:
+            res = {"error": repr(e)}
+        finally:
+            ctx.set_residency_cache(False)
+        out = {"proofs_per_s": k / dt, "proofs_per_s_with_commit_cache": k / dt_cache, "with_residency_cache": res, "ms_per_proof": dt / k * 1e3, "steps": k,
                "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
                "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,
                "srs_register_ms_first": t_reg * 1e3, "srs_register_ms_cached": t_hit * 1e3, "srs_cache": zk.srs_cache_stats(),

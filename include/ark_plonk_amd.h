@@ -97,6 +97,20 @@ int zk_ctx_set_staging(zk_ctx* ctx, int mode);
  * ZK_ERR_UNSUPPORTED: unknown key; ZK_ERR_BAD_ARG: value out of range; ZK_ERR_PENDING: a deferred round is open (a job's plan must
  * not change between its accumulation and its reduction).  The library reads NO environment variable on a compute path
  * (ZK_VERBOSE and ZK_HOST_TIMING switch diagnostics on stderr only). */
+/* Residency cache of the HOST-POINTER entry points (opt-in, per ctx; round 5).  The reference's call structure sends the same
+ * vector across PCIe again and again: an `ifft` output goes straight back up as a `PC::commit` input (prover.rs:196-213), then as a
+ * `coset_fft` input (quotient_poly.rs:72-120), then into the last round's commitments and openings (prover.rs:569-618) -- about 58 of
+ * the 83 vectors an unchanged Prover::prove uploads per proof.  With the cache on, zk_ntt keeps the device copy of every output of at
+ * most max_vector_bytes (named by a keyed 256-bit digest of the bytes the caller receives) and zk_ntt / zk_kzg_commit_batch / zk_kzg_open
+ * digest every input of at most that size on the ctx's host pool and use the resident copy on a match; a miss uploads into a fresh
+ * entry, so a second use of any vector hits too (the prover key's sigma polynomials, proof after proof).  A digest runs at ~190 GB/s
+ * against PCIe's 56, so a hit costs a third of an upload and a miss a third more (profiles/r05_notes.md).  Results are identical by
+ * construction: a hit is taken on equality of (length, digest) of the caller's CURRENT bytes -- the trust model of zk_srs_register's
+ * registry.  capacity_bytes = device memory the entries may hold (0 = leave unchanged; default 2 GiB, least recently used evicted;
+ * entries of the running call are never evicted); max_vector_bytes: 0 = leave unchanged (default 64 MiB: at n = 2^20 the n-sized
+ * vectors are cached, the 4n-sized coset evaluations -- consumed by host code, never sent back -- are not).  enable = 0 drops every entry. */
+int zk_ctx_set_residency_cache(zk_ctx* ctx, int enable, size_t capacity_bytes, size_t max_vector_bytes);
+int zk_residency_cache_stats(zk_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* bytes);
 int zk_ctx_set_option(zk_ctx* ctx, const char* key, int64_t value);
 int zk_ctx_get_option(zk_ctx* ctx, const char* key, int64_t* value);
 

@@ -232,6 +232,25 @@ int main() {
                         reader.join();
                         TCHECK(zk_ctx_set_option(c, "msm_merge", 1) == ZK_OK && zk_ctx_set_option(c, "pre_vw", 0) == ZK_OK);
                     }
+                    // the residency cache of the host-pointer calls: outputs kept, inputs digested and found again, a cache of two
+                    // vectors evicting under a batch of four, off = everything returned
+                    {
+                        const uint64_t* hp[4] = {polys[0].data(), polys[1].data(), polys[2].data(), polys[3].data()};
+                        size_t hl[4] = {n, n, n - 1, 64};
+                        TCHECK(zk_ctx_set_residency_cache(c, 1, (it & 1) ? 2 * n * 32 : 0, 0) == ZK_OK);
+                        std::vector<uint64_t> v(polys[t % 4]);
+                        TCHECK(zk_ntt(c, CURVE, ZK_NTT_IFFT, 13, v.data(), n, v.data()) == ZK_OK);          // in place: digested before it is overwritten
+                        TCHECK(zk_kzg_commit_batch(c, srs, 4, hp, hl, xy, inf) == ZK_OK);
+                        TCHECK(zk_kzg_commit_batch(c, srs, 4, hp, hl, xy, inf) == ZK_OK);
+                        TCHECK(zk_kzg_open(c, srs, 3, hp, hl, z, ch, xy, inf) == ZK_OK);
+                        uint64_t rh = 0, rm = 0, re = 0, rb = 0;
+                        TCHECK(zk_residency_cache_stats(c, &rh, &rm, &re, &rb) == ZK_OK && rh >= 3 && re >= 1 && rb <= ((it & 1) ? 2 * n * 32 : ((size_t)2 << 30)));
+                        TCHECK(zk_kzg_round_begin_dev(c, srs, 1, in, lens, nullptr) == ZK_OK);
+                        TCHECK(zk_ctx_set_residency_cache(c, 0, 0, 0) == ZK_ERR_PENDING);
+                        TCHECK(zk_kzg_round_abort(c) == ZK_OK);
+                        TCHECK(zk_ctx_set_residency_cache(c, 0, 0, 0) == ZK_OK);
+                        TCHECK(zk_residency_cache_stats(c, nullptr, nullptr, &re, &rb) == ZK_OK && re == 0 && rb == 0);
+                    }
                     // the commitment cache: second batch is all hits
                     TCHECK(zk_ctx_set_commit_cache(c, 1, 8) == ZK_OK);
                     TCHECK(zk_kzg_commit_batch_dev(c, srs, 4, in, lens, xy, inf) == ZK_OK);

@@ -285,3 +285,68 @@ def test_dev_helpers_alloc_upload_copy_download(ctx):
     assert L.zk_dev_copy(None, dst, src, 32) == _lib.ZK_ERR_BAD_ARG
     _lib.check(L.zk_dev_free(ctx.handle, src))
     _lib.check(L.zk_dev_free(ctx.handle, dst))
+
+
+@pytest.mark.parametrize("log_n", [10, 13])
+def test_residency_cache_of_the_host_pointer_calls(log_n, ctx, oracle_cpu):
+    """zk_ctx_set_residency_cache (round 5): the unchanged caller's schedule with the cache on gives the same 29 points while the
+    vectors the library itself produced (ifft outputs -> commit / coset_fft / open inputs) and the ones it has seen (the prover key's
+    sigma polynomials) are not uploaded again; a host buffer REWRITTEN after it was produced is a miss and gives the right result
+    (a hit is taken on the caller's current bytes, never on the pointer); a cache too small to hold a proof still gives the same
+    points; switching the cache off drops every entry."""
+    n = 1 << log_n
+    cv = zk.get_curve(0)
+    pw_c, _ = tau_powers(oracle_cpu, 0, n)
+    bases = srs_from_powers(ctx, 0, pw_c)
+    ck = zk.CommitterKey(bases.cpu().numpy().view(np.uint64), cv, ctx).precompute()
+    sched = DropInSchedule(log_n, ctx, ck, cv)
+    ref = sched.run_once(proof_id=0)
+    ctx.io_stats(reset=True)
+    sched.run_once(proof_id=1)
+    plain_h2d = ctx.io_stats()["h2d_bytes"]
+    try:
+        ctx.set_residency_cache(True, 0, 32 * n)              # n-sized vectors are cached, the 4n-sized coset evaluations are not
+        s0 = ctx.residency_cache_stats()
+        assert sched.run_once(proof_id=0) == ref
+        ctx.io_stats(reset=True)
+        assert sched.run_once(proof_id=0) == ref              # second proof of the same witness: sigma polys etc. resident from the first
+        io = ctx.io_stats()
+        s1 = ctx.residency_cache_stats()
+        assert s1["hits"] - s0["hits"] >= 2 * 58 - 8 and s1["entries"] > 0 and s1["bytes"] <= 2 << 30
+        # what still goes up: the 13 evaluation vectors (new every proof: here the same, so they hit too), the 4n quotient evaluations,
+        # the four quarters of t -- far less than the uncached schedule's 17 + 13 + 4 + 27 + 18 vectors
+        assert io["h2d_bytes"] <= 32 * n * (4 + 4 + 13) and io["h2d_bytes"] < plain_h2d // 3
+        assert io["d2h_bytes"] == 32 * n * (17 + 13 * 4 + 4)          # every result still comes down
+        # soundness: a transform's output rewritten by the caller before it is committed -- the pointer is the same, the bytes are not
+        d = sched.dom_n
+        ev = np.ascontiguousarray(sched.evals[0])
+        coeffs = np.zeros((n, 4), dtype=np.uint64)
+        d._run(1, ev, out=coeffs)
+        want = ck.commit_batch([coeffs])[0]
+        h_before = ctx.residency_cache_stats()["hits"]
+        assert ck.commit_batch([coeffs])[0] == want and ctx.residency_cache_stats()["hits"] == h_before + 1      # resident: a hit
+        coeffs[5, 0] ^= np.uint64(1)
+        changed = ck.commit_batch([coeffs])[0]
+        assert changed != want                                                  # the rewritten vector was committed, not the resident copy
+        exp_xy, exp_inf = oracle_cpu.kzg_commit(0, bases.cpu().numpy().view(np.uint64), coeffs)
+        assert np.array_equal(changed.xy(), exp_xy) and changed.infinity == bool(exp_inf)
+        # in-place transform (ark's fft_in_place: in == out): the input is digested before it is overwritten
+        buf = np.ascontiguousarray(sched.evals[1]).copy()
+        exp = np.zeros((n, 4), dtype=np.uint64)
+        d._run(1, np.ascontiguousarray(sched.evals[1]), out=exp)
+        d._run(1, buf, out=buf)
+        assert np.array_equal(buf, exp)
+        # a cache that cannot hold a proof (room for three vectors): same points, entries bounded
+        ctx.set_residency_cache(True, 3 * 32 * n, 32 * n)
+        ctx.set_residency_cache(False)
+        ctx.set_residency_cache(True, 3 * 32 * n, 32 * n)
+        assert sched.run_once(proof_id=0) == ref
+        st = ctx.residency_cache_stats()
+        assert st["entries"] <= 3 and st["bytes"] <= 3 * 32 * n
+    finally:
+        ctx.set_residency_cache(False)
+        ctx.set_residency_cache(True, 2 << 30, 64 << 20)      # the defaults back ...
+        ctx.set_residency_cache(False)                        # ... and off
+    assert ctx.residency_cache_stats()["entries"] == 0
+    assert sched.run_once(proof_id=0) == ref
+    ck.close()

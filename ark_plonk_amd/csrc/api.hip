@@ -1428,7 +1428,6 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
     SrsRead rl(s->mu);
     int rc = ensure_copy_stream(c);
     if (rc) return rc;
-    const void* d_in[16];
     // residency cache: polynomials this ctx produced (zk_ntt outputs) or uploaded before are used where they lie; the others go up
     // into a fresh entry (resident from then on) or, where the cache cannot take them, into the job's staging buffer.  Polynomial k is
     // digested right before job k is queued, i.e. while the GPU runs job k - 1: like the uploads, the digests hide under the MSMs.

@@ -73,16 +73,21 @@ def schedule_breakdown():
     sched = DropInSchedule(log_n, ctx, ck, cv)
     acc = collections.defaultdict(float)
     cnt = collections.defaultdict(int)
+    hm = collections.defaultdict(lambda: [0, 0])
 
     def wrap(obj, name, key_fn):
         orig = getattr(obj, name)
 
         def f(*a, **k):
+            s0 = ctx.residency_cache_stats()
             t0 = time.perf_counter()
             r = orig(*a, **k)
             key = key_fn(*a, **k)
             acc[key] += time.perf_counter() - t0
             cnt[key] += 1
+            s1 = ctx.residency_cache_stats()
+            hm[key][0] += s1["hits"] - s0["hits"]
+            hm[key][1] += s1["misses"] - s0["misses"]
             return r
         setattr(obj, name, f)
     wrap(sched.dom_n, "_run", lambda kind, x, out=None: f"ntt_n kind {kind}")
@@ -94,12 +99,15 @@ def schedule_breakdown():
         sched.run_once()
         acc.clear()
         cnt.clear()
+        hm.clear()
         k = 3
         t0 = time.perf_counter()
         for _ in range(k):
             sched.run_once()
         dt = (time.perf_counter() - t0) / k * 1e3
         print(f"cache {'on ' if on else 'off'}: {dt:7.2f} ms per proof | " + "  ".join(f"{key}: {cnt[key] // k} x {acc[key] / cnt[key] * 1e3:.2f}" for key in sorted(acc)), flush=True)
+        if on:
+            print("   hits / misses per proof: " + "  ".join(f"{key}: {hm[key][0] / k:.0f} / {hm[key][1] / k:.0f}" for key in sorted(hm)), flush=True)
     ctx.set_residency_cache(False)
 
 

@@ -92,6 +92,12 @@ pub fn ctx() -> *mut sys::ZkCtx {
             if std::env::var("ARK_PLONK_AMD_COMMIT_CACHE").map(|v| v == "1").unwrap_or(false) {
                 let _ = unsafe { sys::zk_ctx_set_commit_cache(c, 1, 0) };
             }
+            // opt-in: the host-pointer hooks stop re-uploading what the library itself produced -- an `ifft` output that comes back as a
+            // `PC::commit`, `coset_fft` or `PC::open` input is found by a digest of its bytes and used where it lies (58 of the 83
+            // vectors an unchanged Prover::prove uploads per proof; see the header for the trust model and the sizes)
+            if std::env::var("ARK_PLONK_AMD_RESIDENCY_CACHE").map(|v| v == "1").unwrap_or(false) {
+                let _ = unsafe { sys::zk_ctx_set_residency_cache(c, 1, 0, 0) };
+            }
         }
     });
     unsafe { CTX.0 }

@@ -539,13 +539,15 @@ def main():
     n_dev = torch.cuda.device_count()
     ranks_info = None
     if world > 1:
-        # One process per GPU.  With RCCL a rank without a card of its own is an error on EVERY rank before the rendezvous (all of
-        # them see the same LOCAL_WORLD_SIZE and device count, so nobody is left waiting); folding ranks onto one card
-        # (local_rank % n_dev) is for the gloo rehearsals on a one-card box only and is reported in the line (`ranks.shared_card`).
+        # One process per GPU.  With RCCL a rank that sees no GPU at all is an error before the rendezvous (exit 2).  Fewer visible
+        # devices than local ranks is NOT decided here -- a launcher may show every rank one card of its own -- but by the handshake
+        # below: every rank sees the same gathered list of (host, PCI address), and with backend nccl fewer distinct cards than ranks
+        # is exit 3 on all of them.  Folding ranks onto one card (local_rank % n_dev) is for the gloo rehearsals on a one-card box and
+        # is reported in the line (`ranks.shared_card`).
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        if args.backend == "nccl" and local_world > n_dev:
-            print(f"bench.py: {local_world} ranks on this host but {n_dev} GPU(s) visible: backend nccl needs one GPU per rank "
-                  f"(rank {rank}); use --backend gloo for a one-card rehearsal", file=sys.stderr)
+        if args.backend == "nccl" and n_dev == 0:
+            print(f"bench.py: {local_world} ranks on this host but no GPU visible: backend nccl needs one GPU per rank "
+                  f"(rank {rank}); use --backend gloo --rehearse for a CPU rehearsal", file=sys.stderr)
             sys.exit(2)
         if rank == 0:
             install_sigterm_line_printer()        # before HIP / the backend start their threads: they must inherit the blocked mask

@@ -650,8 +650,8 @@ def test_bench_rehearsal_killed_rank_ends_the_job(where):
 
 
 def test_bench_nccl_refuses_ranks_without_a_card_each():
-    """Backend nccl with more ranks on the host than visible GPUs: every rank exits 2 BEFORE the rendezvous (no `local_rank % n_dev`
-    folding onto one card, nobody left waiting).  Here: two ranks, no GPU at all."""
+    """Backend nccl on a host that shows a rank no GPU: exit 2 BEFORE the rendezvous (nobody left waiting).  Ranks that share a card
+    are caught by the handshake after it (exit 3 on every rank: `test_ranks_handshake_counts_distinct_devices` checks the count)."""
     r, lines, wall = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], 120,
                                 {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2", "MASTER_PORT": str(_free_port()),
                                  "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})

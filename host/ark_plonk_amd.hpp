@@ -48,6 +48,19 @@ class Context {
         check(zk_ctx_get_option(h_, key, &v), "zk_ctx_get_option");
         return v;
     }
+    // the host-pointer calls stop re-uploading what the library produced or has seen (an ifft output that comes back as a commit /
+    // coset_fft / open input): opt-in, hits on a keyed digest of the caller's current bytes; 0 = leave a size unchanged
+    void set_residency_cache(bool on, size_t capacity_bytes = 0, size_t max_vector_bytes = 0) {
+        check(zk_ctx_set_residency_cache(h_, on ? 1 : 0, capacity_bytes, max_vector_bytes), "zk_ctx_set_residency_cache");
+    }
+    struct ResidencyStats {
+        uint64_t hits = 0, misses = 0, entries = 0, bytes = 0;
+    };
+    ResidencyStats residency_stats() const {
+        ResidencyStats s;
+        check(zk_residency_cache_stats(h_, &s.hits, &s.misses, &s.entries, &s.bytes), "zk_residency_cache_stats");
+        return s;
+    }
 
   private:
     zk_ctx* h_ = nullptr;

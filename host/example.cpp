@@ -92,6 +92,22 @@ int main(int argc, char** argv) {
         zk::CommitterKey again(ctx, srs);                 // PC::trim on the next gen_proof: the same bytes -> the resident SRS and table
         auto ev_commit = again.commit(ev);
         std::printf("host_batch %s\n", (host_round[0].xy == single.xy && host_round[2].xy == single.xy && host_round[1].xy == ev_commit.xy) ? "ok" : "MISMATCH");
+        // the same host batch with the residency cache on: the second call finds its three vectors on the device (two distinct ones
+        // uploaded by the first), a rewritten vector is a miss -- same points either way
+        {
+            ctx.set_residency_cache(true);
+            auto first = ck.commit({&coeffs, &ev, &coeffs});
+            const auto before = ctx.residency_stats();
+            auto second = ck.commit({&coeffs, &ev, &coeffs});
+            const auto after = ctx.residency_stats();
+            std::vector<uint64_t> changed(coeffs);
+            changed[4] ^= 1;
+            auto third = ck.commit({&changed});
+            ctx.set_residency_cache(false);
+            std::printf("residency_cache %s\n", (first[0].xy == single.xy && second[0].xy == single.xy && second[1].xy == ev_commit.xy &&
+                                                 second[2].xy == single.xy && after.hits - before.hits == 3 && third[0].xy != single.xy &&
+                                                 ctx.residency_stats().entries == 0) ? "ok" : "MISMATCH");
+        }
         // round 1 of the prover's transcript: four wire commitments in, zeta out (prover.rs:217-226)
         zk::Transcript pre("example");
         pre.circuit_domain_sep(n);

@@ -43,6 +43,7 @@ def test_cpp_example_matches_python_mirror(tmp_path, ctx):
     assert lines["roundtrip"] == "ok" and lines["commit_round"] == "ok" and lines["host_batch"] == "ok" and lines["deferred_round"] == "ok"
     assert lines["device_partials"] == "ok"
     assert lines["device_winsums"] == "ok"
+    assert lines["residency_cache"] == "ok"
     n = 1 << log_n
     ev = _inputs(n)
     dom = zk.Radix2EvaluationDomain.new(n, 0, ctx)

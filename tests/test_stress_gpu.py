@@ -39,3 +39,7 @@ def test_stress_prover_short(ctx, oracle_cpu):
 
 def test_stress_shards_short(ctx, oracle_cpu):
     assert _load("stress_shards").run(budget=20.0, seed=60, ctx=ctx, max_log_n=15) >= 4
+
+
+def test_stress_residency_short(ctx, oracle_cpu):
+    assert _load("stress_residency").run(budget=15.0, seed=70, ctx=ctx, max_log_n=13) >= 20

@@ -22,7 +22,8 @@ N = 1 adds, also never part of `value`:
   concurrent_streams  the same GPU with 4 proofs in flight (one thread + zk_ctx + HIP stream each, ONE shared SRS);
   drop_in             the same schedule through the host-pointer calls a Rust shim binds (zk_ntt, zk_kzg_commit_batch,
                       zk_kzg_open on pageable buffers, SRS registered once): the unchanged-caller number, with the
-                      PCIe bytes it moves;
+                      PCIe bytes it moves; `with_residency_cache` = the library keeps what it produced, `concurrent_callers` = four
+                      such callers (threads) at once, one's transfers under the others' kernels;
   dedup               the schedule with the library's content-addressed commitment cache (SURVEY.md 8f N3);
   no_precompute       the per-window MSM path (no window table), for the table's cost/benefit.
 
@@ -458,6 +459,7 @@ def parse_args():
                     help="sharded MSMs (N > 1): 'points' = rank g owns SRS[g n/G, (g+1) n/G) and that slice of every polynomial (SURVEY.md 8e's "
                          "preferred axis); 'windows' = rank g holds the whole SRS and the table rows of the windows g, g + G, ... "
                          "(BASELINE.json north_star's wording; zk_srs_precompute_rows)")
+    ap.add_argument("--drop-in-callers", type=int, default=4, help="drop_in leg: host threads calling the host-pointer entry points at once")
     ap.add_argument("--exchange", default="host", choices=["winsums", "point", "host"],
                     help="sharded MSMs, what the ranks all-gather per group of PC calls (default 'host': the fastest of the three on ONE card with a "
                          "stand-in collective, profiles/r05_sim_rank.txt -- by 1-2 %% over 'winsums', which removes a host round trip before and "
@@ -787,7 +789,53 @@ def main():
             res = {"error": repr(e)}
         finally:
             ctx.set_residency_cache(False)
-        out = {"proofs_per_s": k / dt, "proofs_per_s_with_commit_cache": k / dt_cache, "with_residency_cache": res, "ms_per_proof": dt / k * 1e3, "steps": k,
+        # T unchanged callers at once (a proving service running `Prover::prove` in T worker threads): one zk_ctx, one proof and one set
+        # of pageable vectors per thread, ONE resident SRS; a caller's transfers run under the other callers' kernels
+        callers = None
+        try:
+            import threading
+            T = args.drop_in_callers
+            ctxs = [zk.Context(ctx.device) for _ in range(T)]
+            cks = [zk.CommitterKey(srs, cv, c) for c in ctxs]
+            scheds = [DropInSchedule(log_n, c, ckc, cv) for c, ckc in zip(ctxs, cks)]
+            for s_ in scheds:
+                s_.run_once()
+            bar = threading.Barrier(T + 1)
+            errs = []
+
+            def caller(s_):
+                try:
+                    bar.wait()
+                    for _ in range(k):
+                        s_.run_once()
+                    torch.cuda.synchronize()
+                except Exception as e:      # noqa: BLE001
+                    errs.append(repr(e))
+                finally:
+                    bar.wait()
+            ths = [threading.Thread(target=caller, args=(s_,)) for s_ in scheds]
+            for t_ in ths:
+                t_.start()
+            bar.wait()
+            t0 = time.perf_counter()
+            bar.wait()
+            dt_c = time.perf_counter() - t0
+            for t_ in ths:
+                t_.join()
+            same = all(digest(s_.run_once(proof_id=0)) == digest(pts) for s_ in scheds) if args.check else None
+            callers = {"callers": T, "proofs_per_s": T * k / dt_c, "ms_per_proof_per_caller": dt_c / k * 1e3, "proofs_each": k,
+                       "same_points_as_one_caller": same, "errors": errs or None,
+                       "how": "T host threads, each with its own zk_ctx, proof and pageable vectors, all calling zk_ntt / zk_kzg_commit_batch / zk_kzg_open "
+                              "against one GPU and one resident SRS (residency cache off); tools/drop_in_callers.py sweeps T = 1..8"}
+            for ckc in cks:
+                ckc.close()
+            for c in ctxs:
+                c.close()
+            del scheds
+        except Exception as e:
+            callers = {"error": repr(e)}
+        out = {"proofs_per_s": k / dt, "proofs_per_s_with_commit_cache": k / dt_cache, "with_residency_cache": res, "concurrent_callers": callers,
+               "ms_per_proof": dt / k * 1e3, "steps": k,
                "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
                "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,
                "srs_register_ms_first": t_reg * 1e3, "srs_register_ms_cached": t_hit * 1e3, "srs_cache": zk.srs_cache_stats(),

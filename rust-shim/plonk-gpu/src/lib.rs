@@ -76,30 +76,75 @@ unsafe impl Send for CtxCell {}
 
 static INIT: Once = Once::new();
 static mut CTX: CtxCell = CtxCell(core::ptr::null_mut());
+static mut PER_THREAD: bool = false;
 
-/// The process-wide `zk_ctx` on GPU `ARK_PLONK_AMD_DEVICE` (default 0); null when no usable device exists, in which case every
-/// hook reports "not handled" and the caller's CPU path runs.
+fn env_is_one(name: &str) -> bool {
+    std::env::var(name).map(|v| v == "1").unwrap_or(false)
+}
+
+/// A `zk_ctx` on GPU `ARK_PLONK_AMD_DEVICE` (default 0) with the shim's opt-in caches applied; null when no usable device exists.
+fn new_ctx() -> *mut sys::ZkCtx {
+    let device = std::env::var("ARK_PLONK_AMD_DEVICE").ok().and_then(|v| v.parse::<i32>().ok()).unwrap_or(0);
+    let mut c: *mut sys::ZkCtx = core::ptr::null_mut();
+    let rc = unsafe { sys::zk_ctx_create(device, &mut c) };
+    if rc != sys::ZK_OK {
+        return core::ptr::null_mut();
+    }
+    // opt-in: the twelve polynomials prover.rs:569-607 commits a second time are served from the library's
+    // content-addressed commitment cache (17 MSMs per proof instead of 29; see the header for the trust model)
+    if env_is_one("ARK_PLONK_AMD_COMMIT_CACHE") {
+        let _ = unsafe { sys::zk_ctx_set_commit_cache(c, 1, 0) };
+    }
+    // opt-in: the host-pointer hooks stop re-uploading what the library itself produced -- an `ifft` output that comes back as a
+    // `PC::commit`, `coset_fft` or `PC::open` input is found by a digest of its bytes and used where it lies (58 of the 83
+    // vectors an unchanged Prover::prove uploads per proof; see the header for the trust model and the sizes)
+    if env_is_one("ARK_PLONK_AMD_RESIDENCY_CACHE") {
+        let _ = unsafe { sys::zk_ctx_set_residency_cache(c, 1, 0, 0) };
+    }
+    c
+}
+
+/// The calling thread's own `zk_ctx` (`ARK_PLONK_AMD_CTX_PER_THREAD=1`), destroyed when the thread ends.
+struct ThreadCtx(core::cell::Cell<*mut sys::ZkCtx>, core::cell::Cell<bool>);
+
+impl Drop for ThreadCtx {
+    fn drop(&mut self) {
+        let c = self.0.get();
+        if !c.is_null() {
+            unsafe { sys::zk_ctx_destroy(c) };
+        }
+    }
+}
+
+thread_local! {
+    static THREAD_CTX: ThreadCtx = ThreadCtx(core::cell::Cell::new(core::ptr::null_mut()), core::cell::Cell::new(false));
+}
+
+/// The `zk_ctx` the hooks of the calling thread use; null when no usable device exists, in which case every hook reports "not handled"
+/// and the caller's CPU path runs.  By default ONE process-wide context: the library serialises the calls of all threads on it.
+/// With `ARK_PLONK_AMD_CTX_PER_THREAD=1` every thread that calls a hook gets its own context (its own HIP stream, staging buffers and
+/// caches; the registered SRS and its window table belong to the GPU and are shared): a service that runs `Prover::prove` in T worker
+/// threads then has one thread's PCIe transfers under the other threads' kernels -- 5.7 proofs/s with one caller, 9.4-9.8 with four,
+/// 11.0 with eight on one MI355X at n = 2^20 (profiles/r05_drop_in_callers.txt).  Meant for callers that drive the prover from a few
+/// long-lived threads (prover.rs calls every hook from the thread that called `prove`), not from a large work-stealing pool.
 pub fn ctx() -> *mut sys::ZkCtx {
     INIT.call_once(|| {
         layout_checks();
-        let device = std::env::var("ARK_PLONK_AMD_DEVICE").ok().and_then(|v| v.parse::<i32>().ok()).unwrap_or(0);
-        let mut c: *mut sys::ZkCtx = core::ptr::null_mut();
-        let rc = unsafe { sys::zk_ctx_create(device, &mut c) };
-        if rc == sys::ZK_OK {
+        unsafe { PER_THREAD = env_is_one("ARK_PLONK_AMD_CTX_PER_THREAD") };
+        if !unsafe { PER_THREAD } {
+            let c = new_ctx();
             unsafe { CTX = CtxCell(c) };
-            // opt-in: the twelve polynomials prover.rs:569-607 commits a second time are served from the library's
-            // content-addressed commitment cache (17 MSMs per proof instead of 29; see the header for the trust model)
-            if std::env::var("ARK_PLONK_AMD_COMMIT_CACHE").map(|v| v == "1").unwrap_or(false) {
-                let _ = unsafe { sys::zk_ctx_set_commit_cache(c, 1, 0) };
-            }
-            // opt-in: the host-pointer hooks stop re-uploading what the library itself produced -- an `ifft` output that comes back as a
-            // `PC::commit`, `coset_fft` or `PC::open` input is found by a digest of its bytes and used where it lies (58 of the 83
-            // vectors an unchanged Prover::prove uploads per proof; see the header for the trust model and the sizes)
-            if std::env::var("ARK_PLONK_AMD_RESIDENCY_CACHE").map(|v| v == "1").unwrap_or(false) {
-                let _ = unsafe { sys::zk_ctx_set_residency_cache(c, 1, 0, 0) };
-            }
         }
     });
+    if unsafe { PER_THREAD } {
+        return THREAD_CTX.with(|t| {
+            if !t.1.get() {
+                t.1.set(true); // one attempt per thread: a thread without a usable device stays on the CPU path
+                t.0.set(new_ctx());
+            }
+            t.0.get()
+        });
+    }
     unsafe { CTX.0 }
 }
 

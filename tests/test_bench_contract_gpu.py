@@ -35,6 +35,9 @@ def test_bench_json_contract():
     di = d["drop_in"]
     assert di["commitments_match_resident"] is True and di["proofs_per_s"] > 0 and di["h2d_bytes_per_proof"] > 0 and di["d2h_bytes_per_proof"] > 0
     assert di["srs_cache"]["hits"] >= 1
+    assert di["with_residency_cache"]["same_points_as_uncached"] is True and di["with_residency_cache"]["hits_per_proof"] > 0
+    cc = di["concurrent_callers"]
+    assert cc["callers"] == 4 and cc["same_points_as_one_caller"] is True and cc["errors"] is None and cc["proofs_per_s"] > 0
     assert d["dedup"]["commitments_match"] is True and d["dedup"]["msms_computed_per_proof"] == 17
     assert d["no_precompute"]["commitments_match"] is True
     # a real proof of a satisfied circuit, end to end on the device, and the rounds' O(n) glue inside the synthetic step

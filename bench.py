@@ -352,6 +352,7 @@ def emit_line_so_far():
     if _LINE["line"] is not None and not _LINE["printed"]:
         line = dict(_LINE["line"])
         line["aborted_in_leg"] = _LINE["leg"]
+        line["aborted_why"] = _LINE.get("why") or "the job was torn down (SIGTERM / an exception) during the leg"
         _LINE["printed"] = True
         print(json.dumps(line), flush=True)
 
@@ -367,6 +368,34 @@ def install_sigterm_line_printer():
         os._exit(143)
 
     threading.Thread(target=waiter, daemon=True).start()
+
+
+class LegDeadline:
+    """rank 0 of an N > 1 run, around every EXTRA leg: ranks that are alive but out of step inside a collective kill nobody, so torchrun
+    tears nothing down, and the backend's own timeout ends in abort() -- which no handler survives.  `seconds` (below --dist-timeout)
+    after the leg began, the headline line that already exists is printed with `aborted_in_leg` / `aborted_why` and rank 0 exits
+    non-zero, which makes torchrun end the other ranks.  Other ranks and N = 1: nothing."""
+
+    def __init__(self, seconds: float, active: bool):
+        self.seconds, self.active, self.timer = seconds, active and seconds > 0, None
+
+    def _fire(self):
+        _LINE["why"] = f"the leg did not return within {self.seconds:.0f} s (--leg-timeout)"
+        emit_line_so_far()
+        os._exit(42)
+
+    def __enter__(self):
+        if self.active:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *a):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
 
 
 REHEARSAL_GROUPS = (4, 3, 2, 4, 16)        # jobs per group of PC calls of one proof (prover.rs:213 | 289-317 | 361-389 | 459-469 | 579-618)
@@ -396,6 +425,8 @@ def rehearse(args, world: int, rank: int, local_rank: int) -> int:
     def one_proof(step: int):
         for gi, jobs in enumerate(REHEARSAL_GROUPS):
             if rank == args.fault_rank and gi == 2 and step == (1 if args.fault_at == "step" else 3):
+                if args.fault_at == "hang":
+                    time.sleep(10 ** 6)                        # alive, but never reaches the next collective
                 os._exit(41)                                   # a rank lost between two collectives of a proof
             mine = torch.full((jobs * REHEARSAL_WORDS,), (rank + 1) * 1000 + gi, dtype=torch.int64)
             out = torch.empty((world, jobs * REHEARSAL_WORDS), dtype=torch.int64)
@@ -427,8 +458,9 @@ def rehearse(args, world: int, rank: int, local_rank: int) -> int:
                 "collectives_per_step": len(REHEARSAL_GROUPS), "bytes_per_rank_per_step": sum(REHEARSAL_GROUPS) * REHEARSAL_WORDS * 8, "ranks": info}
         _LINE["line"], _LINE["leg"] = line, "rehearsal_leg"
     # an "extra leg" after the timed region, as the real run has them: a job torn down in here still gets its headline line out
-    one_proof(3)
-    barrier()
+    with LegDeadline(args.leg_timeout, world > 1 and rank == 0):
+        one_proof(3)
+        barrier()
     if rank == 0:
         _LINE["leg"] = None
         _LINE["printed"] = True
@@ -484,7 +516,12 @@ def parse_args():
                          "between two collectives (--fault-at step) or inside the extra leg that follows the timed region (--fault-at leg); "
                          "otherwise inside the msm_sharded leg.  The job must end non-zero within --dist-timeout, not hang; killed inside a leg, "
                          "rank 0 still prints the headline line it already has, with `aborted_in_leg`")
-    ap.add_argument("--fault-at", default="step", choices=["step", "leg"], help="see --fault-rank")
+    ap.add_argument("--fault-at", default="step", choices=["step", "leg", "hang"],
+                    help="see --fault-rank; 'hang' (--rehearse): the rank stays alive inside the extra leg and never reaches its next collective")
+    ap.add_argument("--leg-timeout", type=float, default=150.0,
+                    help="N > 1, rank 0: an extra leg (msm_sharded ...) that has not returned after this many seconds no longer holds the headline "
+                         "line back -- it is printed with `aborted_in_leg` and the job ends non-zero.  Keep it below --dist-timeout (the backend's "
+                         "own timeout aborts the process); a leg takes seconds")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="a tuning option of the library (zk_ctx_set_option: msm_merge, pre_vw, pre_logg, chunk_l, long_rounds, combine_sg, pre_max_log_n), "
                          "set on every zk_ctx of the run and recorded in config.options; the library reads no environment variable")
@@ -997,13 +1034,14 @@ def main():
     def leg(name, fn):
         """an extra leg never takes the headline down; every rank agrees on its outcome first"""
         _LINE["leg"] = name
-        try:
-            res = fn()
-            ok = True
-        except Exception as e:
-            res, ok = {"error": repr(e)}, False
-        if not all_ok(ok) and ok:
-            res = {"error": "another rank failed this leg"}
+        with LegDeadline(args.leg_timeout, world > 1 and rank == 0):
+            try:
+                res = fn()
+                ok = True
+            except Exception as e:
+                res, ok = {"error": repr(e)}, False
+            if not all_ok(ok) and ok:
+                res = {"error": "another rank failed this leg"}
         line[name] = res
 
     extra = args.extra_legs == "on" or (args.extra_legs == "auto" and log_n >= 16)

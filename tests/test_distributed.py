@@ -649,6 +649,17 @@ def test_bench_rehearsal_killed_rank_ends_the_job(where):
         assert len(lines) == 1 and lines[0]["aborted_in_leg"] == "rehearsal_leg" and lines[0]["ranks"]["world"] == 8
 
 
+def test_bench_rehearsal_rank_out_of_step_inside_a_leg():
+    """Nobody dies: one of four ranks stays alive inside the extra leg and never reaches its next collective -- torchrun has nothing to tear
+    down and the backend's timeout would end in abort().  Rank 0's leg deadline prints the headline line it already has, marked, and
+    ends the job non-zero well before --dist-timeout."""
+    r, lines, wall = _run_bench(["--gpus", "4", "--backend", "gloo", "--rehearse", "--steps", "2", "--warmup", "1", "--fault-rank", "2",
+                                 "--fault-at", "hang", "--leg-timeout", "8", "--dist-timeout", "120"], 240)
+    assert r.returncode != 0 and wall < 90, (r.returncode, wall)
+    assert len(lines) == 1 and lines[0]["aborted_in_leg"] == "rehearsal_leg" and "--leg-timeout" in lines[0]["aborted_why"]
+    assert lines[0]["ranks"]["world"] == 4 and lines[0]["ms_per_step"] > 0
+
+
 def test_bench_nccl_refuses_ranks_without_a_card_each():
     """Backend nccl on a host that shows a rank no GPU: exit 2 BEFORE the rendezvous (nobody left waiting).  Ranks that share a card
     are caught by the handshake after it (exit 3 on every rank: `test_ranks_handshake_counts_distinct_devices` checks the count)."""

@@ -92,7 +92,7 @@ class CommitterKey:
 
     def precompute(self, window_bits: int = 0, rows=None):
         """Build the window-multiples table; later MSMs share one bucket set.  window_bits: 0 = default (c = 16, 16 rows, below 2^19
-        points; c = 17 from there on: 15 rows for 255-bit scalars, which are folded to k <= (r - 1) / 2), else 16 .. 21 (fewer rows =
+        points; c = 17 from there on: 15 rows for 255-bit scalars, which are folded to k <= (r - 1) / 2; c = 20, 13 rows, from 2^22 points on), else 16 .. 21 (fewer rows =
         fewer additions per scalar, more buckets to reduce).
         rows = (g, G): the multi-GPU form sharded by WINDOWS -- this rank builds only the rows of the windows g, g + G, ... of the
         whole SRS, and every MSM / commit over the key returns the rank's partial (zk_srs_precompute_rows)."""

@@ -191,7 +191,9 @@ int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const
  * size in HBM (1.9 GiB per 2^20 BLS12-381 points; the card has 288 GB).  MSMs over the SRS then use a
  * single bucket set: no per-window reduction and no host-side doublings.  Results are unchanged.  Idempotent.
  * Default window: c = 16 (16 rows) below 2^19 points, c = 17 from there on -- 15 rows for the 255-bit scalars of BLS12-381,
- * because a scalar k > (r - 1) / 2 is treated as -(r - k): one mixed addition per scalar fewer, 2^16 buckets instead of 2^15. */
+ * because a scalar k > (r - 1) / 2 is treated as -(r - k): one mixed addition per scalar fewer, 2^16 buckets instead of 2^15;
+ * from 2^22 points on, c = 20 (13 rows, 2^19 buckets): two more additions per scalar saved outweigh the wider bucket reduction there
+ * (the device-resident exchange forms below are not available on such a table: ZK_ERR_UNSUPPORTED, use the host form). */
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 /* Same with the table's window c chosen: 16 (default; 16 rows, 2^15 shared buckets) .. 21.  A larger window means fewer
  * rows (15 at c = 17, 13 at c = 20: mixed additions per scalar, table rows) but 2^(c-1) buckets to reduce.

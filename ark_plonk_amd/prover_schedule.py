@@ -245,16 +245,21 @@ class ProofSchedule:
         if exchange not in ("winsums", "point", "host"):
             raise ValueError("exchange: 'winsums', 'point' or 'host'")
         geom = ck.winsums_geometry() if world > 1 else None
-        if not (world > 1 and defer_calls and not (self.dedup or self.dedup_abi) and geom is not None):
+        device_form_ok = world > 1 and defer_calls and not (self.dedup or self.dedup_abi) and geom is not None
+        if world > 1 and dist is not None and hasattr(dist, "all_gather_object"):
+            # once per schedule, on EVERY rank (a rank that skipped this collective would leave the others waiting in it): element-wise sums
+            # of window sums mean something only if every rank reduces in the same geometry, and a rank whose table has no device form
+            # (20-bit windows: shards of 2^22 points and more) takes everybody to the host form
+            seen = [None] * world
+            dist.all_gather_object(seen, (exchange, bool(device_form_ok)) + tuple(geom or ()))
+            if not all(s_[1] for s_ in seen):
+                device_form_ok = False
+            elif len(set(seen)) != 1:
+                raise RuntimeError(f"ranks disagree on the exchange form / table geometry (window bits, windows, virtual windows, buckets): {seen}")
+        if not device_form_ok:
             exchange = "host"
         self.exchange = exchange
         self.partials_on_device = exchange != "host"
-        if world > 1 and dist is not None and geom is not None and hasattr(dist, "all_gather_object"):
-            # once per schedule: element-wise sums of window sums mean something only if every rank reduces in the same geometry
-            seen = [None] * world
-            dist.all_gather_object(seen, (exchange,) + tuple(geom))
-            if len(set(seen)) != 1:
-                raise RuntimeError(f"ranks disagree on the exchange form / table geometry (window bits, windows, virtual windows, buckets): {seen}")
         if self.partials_on_device:
             self._pw = ck.winsums_dev_words() if exchange == "winsums" else ck.partial_dev_words()
             self._pbuf = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)       # partials of the library's pending jobs

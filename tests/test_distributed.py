@@ -95,6 +95,72 @@ def _worker_gpu(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_mixed_tables(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import ark_plonk_amd as zk
+    from ark_plonk_amd.prover_schedule import ProofSchedule
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log_n = 15
+    n = 1 << log_n
+    ctx = zk.Context(0)
+    ctx.use_torch_stream()
+    ks = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    ks[:, 0] = torch.arange(3, 3 + 2 * n, 2, device="cuda")
+    srs = torch.empty((n, 12), dtype=torch.int64, device="cuda")
+    zk._lib.check(zk._lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, srs.data_ptr()))
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    ck = zk.CommitterKey(srs[lo:hi].contiguous(), 0, ctx).precompute(18 if rank == 0 else 0)   # rank 0: a table without a device form
+    sched = ProofSchedule(log_n, ctx, ck, 0, rank=rank, world=world, dist=dist, exchange="winsums")
+    pts = sched.run_once()
+    dig = hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in pts)).hexdigest()
+    q.put((rank, sched.exchange, ck.winsums_geometry() is None, dig))
+    ck.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_schedule_takes_the_host_form_when_one_rank_has_no_device_form():
+    """Two ranks ask for the window-sum exchange; rank 0's table has 18-bit windows (no device form: what the default is for shards of 2^22
+    points and more).  The agreement collective of the schedule runs on BOTH ranks and takes both to the host form -- nobody waits in a
+    collective the other skipped -- and the 29 points equal the single rank's."""
+    import hashlib
+    import torch
+    import torch.multiprocessing as mp
+    import ark_plonk_amd as zk
+    from ark_plonk_amd.prover_schedule import ProofSchedule
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_mixed_tables, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["host", "host"] and [r[2] for r in res] == [True, False] and res[0][3] == res[1][3]
+    log_n = 15
+    n = 1 << log_n
+    ctx = zk.Context(0)
+    ctx.use_torch_stream()
+    ks = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    ks[:, 0] = torch.arange(3, 3 + 2 * n, 2, device="cuda")
+    srs = torch.empty((n, 12), dtype=torch.int64, device="cuda")
+    zk._lib.check(zk._lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, srs.data_ptr()))
+    ck = zk.CommitterKey(srs, 0, ctx).precompute()
+    pts = ProofSchedule(log_n, ctx, ck, 0).run_once()
+    assert hashlib.sha256(b"".join(p.xy().tobytes() + bytes([p.infinity]) for p in pts)).hexdigest() == res[0][3]
+    ck.close()
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_sharded_msm_two_ranks_one_gpu():
     import torch.multiprocessing as mp

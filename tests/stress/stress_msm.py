@@ -39,8 +39,8 @@ def run(budget: float = 120.0, seed: int = 1, ctx=None, max_log_n: int = 17):
         ck = zk.CommitterKey(bases, cid, ctx)
         if rng.random() < 0.8:
             # default window, or the forms the default only takes at 2^19 points and above: c = 17 (folded scalars on BLS12-381,
-            # int32 sort), and now and then the wide reduction (c = 18)
-            ck.precompute(int(rng.choice([0, 0, 17, 17, 18])))
+            # int32 sort), and the wide reduction (c = 18 .. 21; 20 is the default from 2^22 points on)
+            ck.precompute(int(rng.choice([0, 0, 17, 17, 18, 20, 20, 19, 21])))
         k = int(rng.integers(1, 8))
         polys = []
         for _ in range(k):

@@ -332,3 +332,18 @@ def test_patched_prover_declares_what_it_uses():
         used.setdefault(m.group(1), m.start())
     for name, pos in used.items():
         assert name in declared and declared[name] <= pos, f"{name} used at offset {pos} before any `let`"
+
+
+def test_shim_context_per_thread_option_is_complete():
+    """`ARK_PLONK_AMD_CTX_PER_THREAD=1` (T unchanged callers on one card): the per-thread context is created by the
+    same function as the process-wide one (so the opt-in caches apply to both), lives in a thread_local whose Drop destroys it, is tried
+    once per thread, and the default path still hands out the one process-wide context."""
+    src = open(os.path.join(SHIM_SRC, "lib.rs")).read()
+    body = src[src.index("fn new_ctx()"):src.index("pub fn layout_checks")]
+    assert "zk_ctx_create" in body and "zk_ctx_set_commit_cache" in body and "zk_ctx_set_residency_cache" in body
+    assert re.search(r"impl Drop for ThreadCtx \{[^}]*fn drop\(&mut self\) \{[^}]*zk_ctx_destroy", body, re.S)
+    assert "thread_local!" in body and "ARK_PLONK_AMD_CTX_PER_THREAD" in body
+    ctx_fn = body[body.index("pub fn ctx()"):]
+    assert ctx_fn.count("new_ctx()") == 2                       # the process-wide one under the Once, the thread's under its own flag
+    assert "t.1.set(true)" in ctx_fn and "unsafe { CTX.0 }" in ctx_fn
+    assert src.count("fn new_ctx") == 1 and src.count("zk_ctx_create") == 1

@@ -32,6 +32,24 @@ def test_published_roots_of_unity(ctx, oracle_cpu):
             assert np.array_equal(oracle_cpu.ntt(cid, 0, k, x), np.array(want, dtype=np.uint64)), (cid, k)
 
 
+def test_reference_to_polynomial_fixture(ctx):
+    """lookup/multiset.rs:290-309 `test_to_polynomial`, the reference's one deterministic test through `ifft`: seven evaluations 1..7 on the
+    eight-point domain (zero-extended by the call: in_len = 7) interpolate to degree 7 -- through the device's host-pointer and
+    device-pointer entry points, all eight coefficients equal to the big-integer restatement's."""
+    import torch
+    for cid in (0, 1):
+        cv = bo.CURVES[cid]
+        want = bo.ntt(cv, bo.KIND_IFFT, 3, [1, 2, 3, 4, 5, 6, 7])
+        x = np.array([bo.int_to_limbs(bo.to_mont(v, cv.r, 1 << 256), 4) for v in range(1, 8)], dtype=np.uint64)
+        dom = zk.Radix2EvaluationDomain.new(7 + 1, cid, ctx)
+        assert dom.size() == 8
+        got = dom.ifft(x)
+        got_dev = dom.ifft(torch.from_numpy(x.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+        for g in (got, got_dev):
+            vals = [bo.from_mont(bo.limbs_to_int(r), cv.r, 1 << 256) for r in g]
+            assert vals == want and vals[7] != 0
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_golden_vectors(cid, golden, ctx):
     g = golden[cid]

@@ -234,6 +234,25 @@ def test_combine_split_oracle_on_the_reference_vector():
         bo.combine_split([1, 2, 3], [4])
 
 
+def test_to_polynomial_oracle_on_the_reference_fixture():
+    """The reference's one deterministic test THROUGH `ifft` (lookup/multiset.rs:290-309 `test_to_polynomial`, run there for BLS12-381 and
+    BLS12-377 Fr): the multiset {1, ..., 7} on `EvaluationDomain::new(7 + 1)` -- seven evaluations, zero-extended to the eight-point domain
+    by `ifft` (multiset.rs:194-202) -- interpolates to a polynomial of degree 7.  It pins little (the top coefficient is not zero) but it is
+    reference-held: both restatements reproduce it, agree on all eight coefficients, and those evaluate back to (1, ..., 7, 0)."""
+    from oracle import cpu
+    cpu.build()
+    for cid in (0, 1):
+        cv = bo.CURVES[cid]
+        p = cv.r
+        coeffs = bo.ntt(cv, bo.KIND_IFFT, 3, [1, 2, 3, 4, 5, 6, 7])
+        assert len(coeffs) == 8 and coeffs[7] != 0                                       # s_poly.degree() == 7
+        w = cv.root_of_unity(3)
+        assert [bo.horner(coeffs, pow(w, i, p), p) for i in range(8)] == [1, 2, 3, 4, 5, 6, 7, 0]
+        x = np.array([bo.int_to_limbs(bo.to_mont(v, p, 1 << 256), 4) for v in range(1, 8)], dtype=np.uint64)
+        got = cpu.ntt(cid, 1, 3, x)                                                      # in_len = 7 < 8: the C++ restatement extends too
+        assert [bo.from_mont(bo.limbs_to_int(r), p, 1 << 256) for r in got] == coeffs
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_oracle_prover_and_oracle_verifier_agree(cid):
     """No GPU: `Prover::prove_with_preprocessed` restated on integers (oracle/prover_oracle.py) produces a proof of a satisfied

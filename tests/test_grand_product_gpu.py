@@ -81,6 +81,28 @@ def test_vs_bigint_oracle(cid, log_n, ctx):
     assert zk.curves.fr_from_mont(cid, host(coeffs)) == bo.ntt(cv, bo.KIND_IFFT, log_n, ep)
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_reference_fixture_only_left_wires(cid, ctx):
+    """permutation/mod.rs:971-1092: the reference's deterministic four-gate permutation (sigma encodings and wire values as its test spells
+    them out) through zk_perm_product_dev and the device iFFT, under the checks of mod.rs:1243-1380 with seeded beta / gamma: equal to the
+    restatement, z[0] = 1, the product closes, z(1) = 1, degree 3."""
+    from test_oracle import _reference_fixture_only_left_wires, _reference_fixture_two_gates
+    cv = bo.CURVES[cid]
+    # ... and the two-gate one of `test_basic_slow_permutation_poly` (mod.rs:1201-1233) on the two-point domain
+    for log_n, (wires, sig) in ((2, _reference_fixture_only_left_wires(cv)), (1, _reference_fixture_two_gates(cv))):
+        n = 1 << log_n
+        dom = zk.Radix2EvaluationDomain.new(n, cid, ctx)
+        dw, ds = [dev(mont(cid, c)) for c in wires], [dev(mont(cid, c)) for c in sig]
+        for seed in range(5):
+            beta, gamma = bo.seeded_scalars(cv, 0x9A0 + seed, 2)
+            z, last = permutation.permutation_evals(dom, dw, ds, mont(cid, [beta])[0], mont(cid, [gamma])[0], return_last=True)
+            zi = zk.curves.fr_from_mont(cid, host(z))
+            assert zi == bo.perm_product(cv, log_n, wires, sig, beta, gamma)[0] and zi[0] == 1
+            assert zk.curves.fr_from_mont(cid, last.reshape(1, 4))[0] == 1
+            zp = zk.curves.fr_from_mont(cid, host(dom.ifft(z)))
+            assert bo.horner(zp, 1, cv.r) == 1 and zp[n - 1] != 0
+
+
 def test_lookup_length_not_a_power_of_two(ctx):
     cv = bo.CURVES[0]
     n = 1000

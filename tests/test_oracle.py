@@ -154,6 +154,61 @@ def test_grand_product_oracle_matches_fixtures(cid):
     assert z[0] == 1 and last == 1 and z == ints(gp[f"{pre}_z"]) and len(set(z)) > 8
 
 
+
+def _reference_fixture_only_left_wires(cv):
+    """permutation/mod.rs:971-1092 `test_permutation_compute_sigmas_only_left_wires`: four gates, var_zero on L0 R0 L1 L2 L3, var_nine on F0..F3;
+    the sigma encodings the test spells out (:1040-1076; K1, K2, K3 = 7, 13, 17: permutation/constants.rs:12-22) and its wire values (:1078-1082)."""
+    p = cv.r
+    w = cv.root_of_unity(2)
+    w2, w3 = w * w % p, w * w % p * w % p
+    sig = [[7, w2, w3, 1],                                # left  = {R0, L2, L3, L0}
+           [w, w * 7 % p, w2 * 7 % p, w3 * 7 % p],        # right = {L1, R1, R2, R3}
+           [13, w * 13 % p, w2 * 13 % p, w3 * 13 % p],    # out   = {O0, O1, O2, O3}
+           [w * 17 % p, w2 * 17 % p, w3 * 17 % p, 17]]    # fourth = {F1, F2, F3, F0}
+    wires = [[2, 2, 2, 2], [2, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1, 1]]
+    return wires, sig
+
+
+def _reference_fixture_two_gates(cv):
+    """permutation/mod.rs:1201-1233 `test_basic_slow_permutation_poly`: two gates (v1 v2 v3 v4 | v3 v2 v1 v4), wire values as the test gives
+    them; the sigma encodings follow from the map by the rule the four-gate test spells out (a wire maps to the next wire of its variable:
+    v1 = {L0, O1}, v2 = {R0, R1}, v3 = {O0, L1}, v4 = {F0, F1}; w = -1 on the two-point domain)."""
+    p = cv.r
+    w = cv.root_of_unity(1)
+    assert w == p - 1
+    sig = [[w * 13 % p, 13],     # left   = {O1, O0}
+           [w * 7 % p, 7],       # right  = {R1, R0}
+           [w, 1],               # out    = {L1, L0}
+           [w * 17 % p, 17]]     # fourth = {F1, F0}
+    wires = [[1, 3], [2, 2], [3, 1], [1, 1]]
+    return wires, sig
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_grand_product_oracle_on_the_reference_fixture(cid):
+    """The reference's two deterministic permutation fixtures (above) under the checks of its `test_correct_permutation_poly` (mod.rs:1243-1380),
+    which draws beta and gamma at random -- here five seeded pairs: z[0] = 1, the products of the numerators and denominators are equal
+    (the value after the last row is 1), z(X) = ifft(z) has z(1) = 1 and degree n - 1, and z(X w) * den(X) = z(X) * num(X) on every root."""
+    cv = bo.CURVES[cid]
+    p = cv.r
+    for log_n, (wires, sig) in ((2, _reference_fixture_only_left_wires(cv)), (1, _reference_fixture_two_gates(cv))):
+        n = 1 << log_n
+        w = cv.root_of_unity(log_n)
+        for seed in range(5):
+            beta, gamma = bo.seeded_scalars(cv, 0x9A0 + seed, 2)
+            z, last = bo.perm_product(cv, log_n, wires, sig, beta, gamma)
+            assert len(z) == n and z[0] == 1 and last == 1
+            zp = bo.ntt(cv, bo.KIND_IFFT, log_n, z)
+            assert bo.horner(zp, 1, p) == 1 and bo.horner(zp, pow(w, n, p), p) == 1 and zp[n - 1] != 0
+            for i in range(n):
+                root = pow(w, i, p)
+                num = den = 1
+                for k in range(4):
+                    num = num * (wires[k][i] + beta * bo.PERM_K[k] * root + gamma) % p
+                    den = den * (wires[k][i] + beta * sig[k][i] + gamma) % p
+                assert bo.horner(zp, root * w % p, p) * den % p == bo.horner(zp, root, p) * num % p
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_quotient_oracle_matches_fixtures(cid):
     """oracle/bigint_oracle.py quotient_evals (quotient_poly.rs:34-178 + widgets) vs tests/golden/quotient.npz."""

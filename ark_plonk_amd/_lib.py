@@ -134,6 +134,7 @@ SYMBOLS = {
     "zk_kzg_round_end_winsums_dev": (c_int, [c_void_p, c_u32, c_void_p]),
     "zk_g1_sum_winsums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_abort": (c_int, [c_void_p]),
+    "zk_round_mem_stats": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
     "zk_kzg_round_batch_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p, c_void_p]),
     "zk_kzg_commit_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p]),
     "zk_kzg_round_batch_partial_dev": (c_int, [c_void_p, c_void_p, c_u32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_void_p, c_void_p]),

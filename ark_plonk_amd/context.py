@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -28,6 +29,12 @@ class Context:
         self._stream_thread = None
         if stream is not None:
             self.set_stream(stream)
+        # several ranks on one host (torchrun sets LOCAL_WORLD_SIZE): the ranks' host pools share the cores instead of each starting
+        # min(15, cores - 1) helpers.  The library itself reads no environment variable; its host-side mirror does.
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+        if lws > 1:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            self.set_option("host_workers", max(0, min(15, cores // lws - 1)))
 
     # -- lifetime
     def close(self):
@@ -80,7 +87,8 @@ class Context:
         check(lib().zk_ctx_set_msm_window(self.handle, int(c)), "zk_ctx_set_msm_window")
 
     # -- tuning options of the MSM planner (zk_ctx_set_option; the ZK_* environment hooks of rounds 2-4 are gone)
-    OPTIONS = ("msm_merge", "pre_vw", "pre_logg", "chunk_l", "long_rounds", "combine_sg", "pre_max_log_n")
+    OPTIONS = ("msm_merge", "pre_vw", "pre_logg", "chunk_l", "long_rounds", "combine_sg", "pre_max_log_n", "mem_reserve_mb",
+               "round_mem_limit_mb", "host_workers")
 
     def set_option(self, key: str, value: int):
         check(lib().zk_ctx_set_option(self.handle, key.encode(), int(value)), f"zk_ctx_set_option({key})")
@@ -89,6 +97,13 @@ class Context:
         v = ctypes.c_int64()
         check(lib().zk_ctx_get_option(self.handle, key.encode(), ctypes.byref(v)), f"zk_ctx_get_option({key})")
         return v.value
+
+    def round_mem_stats(self) -> dict:
+        """Memory budget of the deferred rounds (zk_round_mem_stats): early closes so far, bytes held by the job buffer sets, and the
+        device's free / total memory as the budget sees it."""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        check(lib().zk_round_mem_stats(self.handle, *[ctypes.byref(x) for x in v]), "zk_round_mem_stats")
+        return {"early_closes": v[0].value, "set_bytes": v[1].value, "device_free": v[2].value, "device_total": v[3].value}
 
     # -- N3: content-addressed commitment cache (prover.rs:569-607 re-commits 12 polynomials)
     def set_commit_cache(self, on: bool = True, capacity: int = 0):

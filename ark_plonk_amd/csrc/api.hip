@@ -307,7 +307,11 @@ int zk_ctx_create(int device, zk_ctx** out) {
         return ZK_ERR_HIP;
     }
     c->stream = c->own_stream;
-    c->pool.reset(new HostPool(15));
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        c->tune.host_workers = hc > 16 ? 15 : hc > 1 ? (int)hc - 1 : 0;     // + the calling thread; option "host_workers" resizes it
+        c->pool.reset(new HostPool((unsigned)c->tune.host_workers));
+    }
     zk_process_key(c->digest_key);
     c->digest_key[0] ^= (uint64_t)(uintptr_t)c * 0x9E3779B97F4A7C15ull;      // caches are per ctx: so are their keys
     for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
@@ -328,7 +332,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         zk_prof_collect(c);
         for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
         ntt_ctx_free(c);
-        DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_tmp};
+        DevBuf* bufs[] = {&c->io_a, &c->io_b, &c->msm_tmp, &c->stage_shared, &c->witness};
         for (DevBuf* b : bufs) b->release();
         for (int i = 0; i < 16; ++i) c->mb[i].release();
         res_clear(c);
@@ -386,7 +390,8 @@ static int* tune_field(zk_ctx* c, const char* key, int64_t* lo, int64_t* hi) {
         {"msm_merge", &ZkTune::msm_merge, 0, 1},         {"pre_vw", &ZkTune::pre_vw, 0, 512},
         {"pre_logg", &ZkTune::pre_logg, -1, 5},          {"chunk_l", &ZkTune::chunk_l, 0, 1024},
         {"long_rounds", &ZkTune::long_rounds, 1, 16},    {"combine_sg", &ZkTune::combine_sg, 0, 4},
-        {"pre_max_log_n", &ZkTune::pre_max_log_n, 0, 25},
+        {"pre_max_log_n", &ZkTune::pre_max_log_n, 0, 25}, {"mem_reserve_mb", &ZkTune::mem_reserve_mb, 0, 1 << 20},
+        {"round_mem_limit_mb", &ZkTune::round_mem_limit_mb, 0, 1 << 20},
     };
     for (const Row& r : rows)
         if (strcmp(key, r.key) == 0) {
@@ -402,6 +407,12 @@ int zk_ctx_set_option(zk_ctx* c, const char* key, int64_t value) {
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
     int64_t lo = 0, hi = 0;
+    if (strcmp(key, "host_workers") == 0) {
+        if (value < 0 || value > 63) return ZK_ERR_BAD_ARG;
+        c->pool.reset(new HostPool((unsigned)value));      // joins the old workers first (no batch is running: the ctx lock is held)
+        c->tune.host_workers = (int)value;
+        return ZK_OK;
+    }
     int* f = tune_field(c, key, &lo, &hi);
     if (!f) return ZK_ERR_UNSUPPORTED;
     if (value < lo || value > hi) return ZK_ERR_BAD_ARG;
@@ -417,6 +428,10 @@ int zk_ctx_get_option(zk_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return ZK_ERR_BAD_ARG;
     Guard g(c);
     int64_t lo = 0, hi = 0;
+    if (strcmp(key, "host_workers") == 0) {
+        *value = c->tune.host_workers;
+        return ZK_OK;
+    }
     int* f = tune_field(c, key, &lo, &hi);
     if (!f) return ZK_ERR_UNSUPPORTED;
     *value = *f;
@@ -1107,6 +1122,49 @@ static void round_clear(zk_ctx* c) {
     c->round_reduced = 0;
 }
 
+// The memory budget closes the jobs queued so far: sorted, accumulated, reduced and combined NOW, their points parked
+// in the pending entries in call order; their buffer sets are free for the jobs that follow.  The round itself stays open and
+// zk_kzg_round_end returns the same points.  The caller holds the SRS lock.
+static int round_flush_locked(zk_ctx* c) {
+    zk_srs* s = c->pend_srs;
+    uint32_t slots[16], nq = 0;
+    size_t qlens[16];
+    for (uint32_t k = 0; k < c->pend_n; ++k)
+        if (c->pend[k].queued) {
+            slots[nq] = k;
+            qlens[nq] = c->pend[k].n;
+            ++nq;
+        }
+    if (!nq) return ZK_OK;
+    const int L = fq_limbs64(s->curve);
+    uint64_t q_xyz[16 * 18];
+    int rc = msm_batch_pre_end_dev(c, s, nq, slots, qlens, q_xyz, nullptr, nullptr);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    for (uint32_t q = 0; q < nq; ++q) {
+        zk_ctx::PendingJob& pj = c->pend[slots[q]];
+        pj.queued = false;
+        pj.have_xyz = true;
+        memcpy(pj.xyz, q_xyz + (size_t)q * 3 * L, sizeof(uint64_t) * 3 * L);
+    }
+    ++c->round_flushes;
+    return ZK_OK;
+}
+
+// one table-path job into the buffer set of its slot, under the memory budget: no room -> close what is queued and reuse its sets;
+// still no room -> give back every free set's buffers; only then ZK_ERR_OOM
+static int round_begin_job_locked(zk_ctx* c, zk_srs* s, uint32_t slot, const void* d_in, size_t len, uint8_t kind) {
+    int rc = msm_batch_pre_begin_dev(c, s, slot, 1, &d_in, &len, &kind, nullptr);
+    if (rc != ZK_ERR_OOM) return rc;
+    if ((rc = round_flush_locked(c))) return rc;
+    rc = msm_batch_pre_begin_dev(c, s, slot, 1, &d_in, &len, &kind, nullptr);
+    if (rc != ZK_ERR_OOM) return rc;
+    zk_release_free_work(c, (int)slot);
+    return msm_batch_pre_begin_dev(c, s, slot, 1, &d_in, &len, &kind, nullptr);
+}
+
 // jobs [0, n_jobs) appended to the open round; inputs on the device
 static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void* const* d_inputs, const size_t* lens, const uint8_t* kinds) {
     if (c->pend_n && c->pend_srs != s) return ZK_ERR_BAD_ARG;
@@ -1140,14 +1198,24 @@ static int round_append_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
         pj = zk_ctx::PendingJob();
         pj.n = lens[k];
         if (table && lens[k] >= ZK_PRE_MIN_N && lens[k] <= zk_pre_max_n(c)) {
-            const uint8_t kind = kinds ? kinds[k] : 0;
-            if ((rc = msm_batch_pre_begin_dev(c, s, slot, 1, d_inputs + k, lens + k, &kind, nullptr))) return rc;
+            c->pend_srs = s;
+            if ((rc = round_begin_job_locked(c, s, slot, d_inputs[k], lens[k], kinds ? kinds[k] : 0))) return rc;
             pj.queued = true;
         } else {
             // short vector / no table: computed now, in this job's own buffer set (set 0 may belong to a queued job)
-            if (slot) std::swap(c->mb[0], c->mb[slot]);
-            rc = commit_one_locked(c, s, d_inputs[k], lens[k], kinds && kinds[k], pj.xyz);
-            if (slot) std::swap(c->mb[0], c->mb[slot]);
+            auto run_now = [&]() {
+                if (slot) std::swap(c->mb[0], c->mb[slot]);
+                const int r = commit_one_locked(c, s, d_inputs[k], lens[k], kinds && kinds[k], pj.xyz);
+                if (slot) std::swap(c->mb[0], c->mb[slot]);
+                return r;
+            };
+            rc = run_now();
+            if (rc == ZK_ERR_OOM) {        // the memory budget, as for a table-path job: close what is queued, give its sets back, once more
+                c->pend_srs = s;
+                if ((rc = round_flush_locked(c))) return rc;
+                zk_release_free_work(c, -1);
+                rc = run_now();
+            }
             if (rc) return rc;
             pj.have_xyz = true;
         }
@@ -1172,9 +1240,16 @@ int zk_kzg_open_begin_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* co
     SrsRead rl(s->mu);
     if (c->pend_reduced) return ZK_ERR_PENDING;
     if (c->pend_n >= 16) return ZK_ERR_UNSUPPORTED;
+    if (c->pend_n && c->pend_srs != s) return ZK_ERR_BAD_ARG;
     void* d_w = nullptr;
     size_t wlen = 0;
-    int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen, c->pend_n);
+    int rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
+    if (rc == ZK_ERR_OOM) {
+        // the combination / witness vectors (2 x 32 B per coefficient) found no room: close what is queued, free its sets, once more
+        if ((rc = round_flush_locked(c))) return rc;
+        zk_release_free_work(c, -1);
+        rc = kzg_open_prepare_dev(c, s->curve, n_polys, d_polys, lens, z_mont, challenge_mont, &d_w, &wlen);
+    }
     if (rc) return rc;
     if (wlen > s->n) return ZK_ERR_BAD_ARG;
     const void* in = d_w;
@@ -1397,6 +1472,24 @@ int zk_kzg_round_pending(zk_ctx* c, uint32_t* n_jobs) {
     if (!c || !n_jobs) return ZK_ERR_BAD_ARG;
     Guard g(c);
     *n_jobs = c->pend_n;
+    return ZK_OK;
+}
+
+int zk_round_mem_stats(zk_ctx* c, uint64_t* flushes, uint64_t* set_bytes, uint64_t* device_free, uint64_t* device_total) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (flushes) *flushes = c->round_flushes;
+    if (set_bytes) {
+        uint64_t t = c->stage_shared.cap;
+        for (int k = 0; k < 16; ++k) t += c->mb[k].work_bytes();
+        *set_bytes = t;
+    }
+    if (device_free || device_total) {
+        size_t fr = 0, tot = 0;
+        ZK_HIP_TRY(hipMemGetInfo(&fr, &tot));
+        if (device_free) *device_free = fr;
+        if (device_total) *device_total = tot;
+    }
     return ZK_OK;
 }
 

@@ -141,12 +141,20 @@ void host_parallel_for(uint32_t n, const std::function<void(uint32_t)>& fn);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // what ensure(bytes) allocates: a little slack so that lengths differing by a few elements (n, n - 1, n + 2: stripped zeros, the
+    // openings) reuse the buffer.  The slack is bounded: an eighth of a 2.6 GB sort buffer was 330 MB per job of a 2^25 round.
+    static size_t want_for(size_t bytes) {
+        const size_t slack = bytes / 8 < ((size_t)8 << 20) ? bytes / 8 : ((size_t)8 << 20);
+        return bytes + slack + 256;
+    }
+    // bytes ensure(bytes) would newly take from the device (0 when the buffer is already large enough)
+    size_t need_for(size_t bytes) const { return bytes <= cap ? 0 : want_for(bytes); }
     int ensure(size_t bytes) {
         if (bytes <= cap) return ZK_OK;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
+        size_t want = want_for(bytes);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
@@ -171,8 +179,36 @@ struct MsmBufs {
     // was refused after the accumulation had run was re-planned with the other chunk length)
     uint32_t acc_chunk_l = 0, acc_n_lanes = 0;
     void release() {
-        DevBuf* all[] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg2, &seg3, &win, &tmp, &scalars, &stage, &upload};
-        for (DevBuf* b : all) b->release();
+        release_work();
+        scalars.release();
+        upload.release();
+    }
+    // The WORK buffers of a set: everything a table-path job sorts, accumulates and reduces in.  `scalars` (into_repr output of the
+    // single-MSM paths) and `upload` (the host-pointer batch's copy of job k's coefficients) belong to the SLOT, not to the job's work:
+    // callers hold pointers into them across the begin of other jobs, so they are neither swapped nor released by the memory budget.
+    void work_bufs(DevBuf* (&out)[12]) {
+        DevBuf* all[12] = {&counts, &offsets, &entries, &buckets, &part_pt, &part_key, &seg, &seg2, &seg3, &win, &tmp, &stage};
+        for (int i = 0; i < 12; ++i) out[i] = all[i];
+    }
+    size_t work_bytes() {
+        DevBuf* w[12];
+        work_bufs(w);
+        size_t t = 0;
+        for (DevBuf* b : w) t += b->cap;
+        return t;
+    }
+    void release_work() {
+        DevBuf* w[12];
+        work_bufs(w);
+        for (DevBuf* b : w) b->release();
+    }
+    // a free set's work buffers handed to another slot (deferred rounds under a memory budget: msm_batch_pre_begin)
+    void swap_work(MsmBufs& o) {
+        DevBuf* a[12];
+        DevBuf* b[12];
+        work_bufs(a);
+        o.work_bufs(b);
+        for (int i = 0; i < 12; ++i) std::swap(*a[i], *b[i]);
     }
 };
 
@@ -208,6 +244,13 @@ struct ZkTune {
     int long_rounds = 1;     // rounds of resident lanes for a non-final job of a merged accumulation launch
     int combine_sg = 0;      // lanes per small bucket in msm_combine when a launch has > 2 jobs (0 = default 1; 2; 4)
     int pre_max_log_n = 0;   // vectors longer than 2^this leave the window-table path (0 = the built-in 2^26); test hook, 13 .. 25
+    // Memory budget of the table path.  A job's buffer set is taken only if the device has room for it (hipMemGetInfo
+    // minus mem_reserve_mb); otherwise the jobs queued so far are closed first -- sorted, accumulated, reduced, their points parked on
+    // the host in call order -- and their sets reused.  round_mem_limit_mb (test hook, 0 = off): additionally pretend that the sets of
+    // the queued jobs together may hold at most this many MiB, so that the flush can be exercised at small sizes.
+    int mem_reserve_mb = 1024;
+    int round_mem_limit_mb = 0;
+    int host_workers = -1;   // helper threads of the ctx's host pool (-1 = min(15, cores / LOCAL_WORLD_SIZE - 1)); read when the pool starts
 };
 
 struct zk_ctx {
@@ -241,6 +284,10 @@ struct zk_ctx {
     size_t pinned_cap = 0;
     void* pinned_small = nullptr;   // 4 KiB: digests of the commitment cache
     DevBuf msm_tmp;       // infinity flags staging (SRS registration)
+    DevBuf stage_shared;  // the partition sort's staging area for jobs too large to own one (msm plan: shared_stage): the jobs of a round
+                          // are then placed one after the other instead of by one launch per kernel
+    DevBuf witness;       // the witness polynomial of zk_kzg_open*: read by the digit kernel of its MSM in stream order, so one per ctx
+    uint64_t round_flushes = 0;   // times the memory budget closed the queued jobs of a round early (zk_round_mem_stats)
 
     // host-pointer entry points (the drop-in boundary): pinned staging ring + a copy stream so that the upload of
     // polynomial k+1 runs under the MSM of polynomial k (hostio.hip)
@@ -310,6 +357,20 @@ struct zk_ctx {
     zk_srs* pend_srs = nullptr;
     PendingJob pend[16];
 };
+
+// Give back the work buffers of every buffer set no job lives in (and the shared staging area): the last resort of the memory
+// budget before a call returns ZK_ERR_OOM.  hipFree waits for the device, so kernels still reading them are safe.  ctx lock held.
+inline size_t zk_release_free_work(zk_ctx* c, int keep_slot) {
+    size_t freed = 0;
+    for (int j = 0; j < 16; ++j) {
+        if (j == keep_slot || c->mb[j].stage_of_job != 0) continue;
+        freed += c->mb[j].work_bytes();
+        c->mb[j].release_work();
+    }
+    freed += c->stage_shared.cap;
+    c->stage_shared.release();
+    return freed;
+}
 
 // An SRS belongs to a DEVICE, not to a ctx: every zk_ctx of that device may use it (several proof streams share one
 // copy of the bases and of the window table).  Readers (the MSM entry points) hold `mu` shared from reading the
@@ -420,9 +481,9 @@ int poly_evaluate_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const*
                       uint64_t* out_mont);
 int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs_mont,
                      void* d_out, size_t out_len);
-// the witness lands in c->mb[slot].scalars (slot: the buffer set of the MSM that will consume it)
+// the witness lands in c->witness: its MSM's digit kernel reads it in stream order, before the next call can overwrite it
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
-                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen, uint32_t slot = 0);
+                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen);
 
 // hostio.hip: staged host<->device copies and digests
 // Copies run on `st`; h2d returns once the host buffer has been read (the device copy may still be in flight on st),

@@ -278,10 +278,10 @@ int poly_lincomb(zk_ctx* c, uint32_t n_terms, const void* const* d_polys, const 
 
 template <class C>
 int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,
-                 const uint64_t* chal_mont, void** d_w, size_t* wlen, uint32_t slot) {
+                 const uint64_t* chal_mont, void** d_w, size_t* wlen) {
     typedef typename C::Fr Fr;
     typedef typename C::FrU FU;
-    if (n_polys > (uint32_t)MAX_POLYS || slot >= 16) return ZK_ERR_UNSUPPORTED;
+    if (n_polys > (uint32_t)MAX_POLYS) return ZK_ERR_UNSUPPORTED;
     uint64_t m = 0;
     for (uint32_t k = 0; k < n_polys; ++k) m = lens[k] > m ? lens[k] : m;
     *wlen = m > 0 ? m - 1 : 0;
@@ -313,7 +313,7 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     int rc;
     if ((rc = c->io_a.ensure(m * 32))) return rc;                       // comb
     if ((rc = c->io_b.ensure((n_chunks * 2 + (size_t)SCAN_T * 3) * 48))) return rc;   // H | A | the scan's (h, q) pairs and carries (limb vectors)
-    if ((rc = c->mb[slot].scalars.ensure(m * 32))) return rc;             // witness, canonical
+    if ((rc = c->witness.ensure(m * 32))) return rc;                      // witness, canonical
     void* comb = c->io_a.p;
     void* H = c->io_b.p;
     void* A = (char*)c->io_b.p + n_chunks * 48;
@@ -330,9 +330,9 @@ int open_prepare(zk_ctx* c, uint32_t n_polys, const void* const* d_polys, const 
     hipLaunchKernelGGL(kzg_scan_local<FU>, dim3(SCAN_T / 64), dim3(64), 0, st, H, n_chunks, zkp, HQ);
     hipLaunchKernelGGL(kzg_scan_cross<FU>, dim3(1), dim3(SCAN_T), shmem, st, HQ, CR);
     hipLaunchKernelGGL(kzg_scan_replay<FU>, dim3(SCAN_T / 64), dim3(64), 0, st, H, n_chunks, zkp, CR, A);
-    hipLaunchKernelGGL(kzg_witness<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, A, c->mb[slot].scalars.p, n_chunks);
+    hipLaunchKernelGGL(kzg_witness<FU>, dim3((unsigned)((n_chunks + T - 1) / T)), dim3(T), 0, st, comb, m, zp, A, c->witness.p, n_chunks);
     ZK_HIP_TRY(hipGetLastError());
-    *d_w = c->mb[slot].scalars.p;
+    *d_w = c->witness.p;
     return ZK_OK;
 }
 
@@ -353,8 +353,8 @@ int poly_lincomb_dev(zk_ctx* c, int curve, uint32_t n_terms, const void* const* 
 }
 
 int kzg_open_prepare_dev(zk_ctx* c, int curve, uint32_t n_polys, const void* const* d_polys, const size_t* lens,
-                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen, uint32_t slot) {
-    if (curve == ZK_CURVE_BLS12_381) return open_prepare<CurveBls>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen, slot);
-    if (curve == ZK_CURVE_BN254) return open_prepare<CurveBn>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen, slot);
+                         const uint64_t* z_mont, const uint64_t* chal_mont, void** d_witness_canonical, size_t* wlen) {
+    if (curve == ZK_CURVE_BLS12_381) return open_prepare<CurveBls>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen);
+    if (curve == ZK_CURVE_BN254) return open_prepare<CurveBn>(c, n_polys, d_polys, lens, z_mont, chal_mont, d_witness_canonical, wlen);
     return ZK_ERR_BAD_ARG;
 }

@@ -2084,12 +2084,20 @@ int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits, uint32_t w0, 
 struct PrePlan {
     MsmGeom g, g1, gv;
     uint64_t nf;
-    uint32_t chunk_l, n_lanes, S;
+    uint32_t chunk_l, n_lanes, max_lanes;
     size_t win_bytes;
     bool wide;          // c > 16: int32 digits, 2^(c-9) buckets per sort partition
     bool wide_red;      // more than 2^16 shared buckets: three-level device reduction (up to 2^16 the virtual-window reduction of the
                         // c = 16 table serves, with virtual windows of 1024 buckets)
+    bool shared_stage;  // the sort's staging area (5-6 B per reference) is the ctx's, not the job's: the jobs of a round are placed one
+                        // after the other (pre_queue_sort_rest) instead of by one launch per kernel
 };
+
+// From this many references per job (n = 2^24 at c = 20) the plan trades the last per cent of speed for memory: one staging area
+// for all jobs of a round (2.6 GB per job at 2^25) and at most PRE_BIG_ROUNDS rounds of resident lanes (the chunk-edge partials of
+// 26 rounds were 1.7 GB per job).  Sixteen deferred jobs of a 2^25 round then hold 41 GB instead of 194.
+constexpr uint64_t PRE_BIG_NF = 1ull << 27;
+constexpr uint32_t PRE_BIG_ROUNDS = 8;
 
 // the reduction's view of the shared bucket set: a function of the table's window (pl.g.B buckets) and the ctx's options only
 inline void pre_reduce_geom(const zk_ctx* c, PrePlan& pl) {
@@ -2121,12 +2129,11 @@ inline void pre_reduce_geom(const zk_ctx* c, PrePlan& pl) {
 
 // long_chunks: the job is followed by another one inside a merged accumulation launch (msm_accumulate_batch): one round of
 // resident lanes with one long chunk each instead of several rounds of short ones.  The buffers are sized for the larger plan.
+// pre_plan_geom derives the plan and allocates nothing; pre_sizes / pre_need / pre_ensure are its buffers.
 template <class Cv>
-int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long_chunks = false) {
+int pre_plan_geom(const zk_ctx* c, const zk_srs* s, size_t n, PrePlan& pl, bool long_chunks = false) {
     typedef typename Cv::Fq Fq;
-    typedef typename Cv::FqU F;
     typedef XYZZ<Fq> PH;
-    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
     if (n > zk_pre_max_n(c)) return ZK_ERR_UNSUPPORTED;      // the callers (api.hip) send longer vectors down the per-window path
     pl.g = make_geom<typename Cv::FrP>(n, (int)s->pre_c, PRE_C_MAX);
     if (pl.g.W != s->pre_W || pl.g.W > 32) return ZK_ERR_UNSUPPORTED;
@@ -2141,6 +2148,7 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     pl.g1.W = 1;
     pl.g1.nb = pl.g.B;
     pre_reduce_geom(c, pl);
+    pl.shared_stage = pl.nf >= PRE_BIG_NF;
     // references per lane: as long as possible (fewer chunk-edge partials) while keeping >= 2 rounds of
     // resident lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131072 at the kernel's VGPR count), so that
     // lanes finishing early are replaced instead of idling through the tail (measured at 2^20:
@@ -2160,12 +2168,13 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
     // partials per bucket instead of 5, net +0.5 .. 0.8 % proofs/s; 30 and 24 per lane give the accumulation another 1 % and
     // the combine more than that back: profiles/r03_notes.md).  A job that is not the last one of a merged launch has no end of
     // its own: one round (option "long_rounds": tuning hook), a third of the partials.
-    uint32_t max_lanes = pl.n_lanes;
+    pl.max_lanes = pl.n_lanes;
     {
         constexpr uint32_t ROUND = 131072;
         if (pl.n_lanes > ROUND) {
             uint32_t rounds = (pl.n_lanes + ROUND - 1) / ROUND;
             if (!tuned && rounds == 2 && pl.nf / (3ull * ROUND) >= 32) rounds = 3;
+            if (!tuned && pl.nf >= PRE_BIG_NF && rounds > PRE_BIG_ROUNDS) rounds = PRE_BIG_ROUNDS;
             // never below 16 references per lane: sizes just above one round (n ~ 1.4e5 at c = 16) would otherwise get 262144 lanes
             // of 9, and chunks that short overload msm_combine* (measured at 2^20: 16 per lane cost 162 ms per proof against 110)
             const uint32_t l_r = (uint32_t)((pl.nf + (uint64_t)rounds * ROUND - 1) / ((uint64_t)rounds * ROUND));
@@ -2173,41 +2182,90 @@ int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long
                 pl.n_lanes = rounds * ROUND;
                 pl.chunk_l = l_r;
             }
-            max_lanes = pl.n_lanes;
+            pl.max_lanes = pl.n_lanes;
             if (long_chunks) {
                 const uint32_t long_rounds = (uint32_t)c->tune.long_rounds;
                 const uint32_t lr = long_rounds < 1 ? 1u : long_rounds > rounds ? rounds : long_rounds;
                 // never more lanes than the plan the buffers were sized for (part_pt holds two partials per lane of max_lanes):
                 // where the whole-round rounding above was refused (chunks below 16), lr rounds of lanes can exceed it
-                if ((uint64_t)lr * ROUND <= max_lanes) {
+                if ((uint64_t)lr * ROUND <= pl.max_lanes) {
                     pl.n_lanes = lr * ROUND;
                     pl.chunk_l = (uint32_t)((pl.nf + pl.n_lanes - 1) / pl.n_lanes);
                 }
             }
         }
     }
-    pl.S = 1;
-    while (pl.S < 128 && (uint64_t)pl.S * 32768 < pl.nf) pl.S <<= 1;   // 256 / 512 slabs measured slower (scans grow)
     pl.win_bytes = pl.wide_red ? (size_t)4 * sizeof(PH) : (size_t)2 * pl.gv.W * sizeof(PH);
-    int rc;
-    if (!pl.wide && (rc = mb.counts.ensure((size_t)pl.S * pl.g.B * 4 + 4096))) return rc;
-    if ((rc = mb.offsets.ensure((size_t)(pl.g.B + 1) * 4))) return rc;
-    if ((rc = mb.tmp.ensure((size_t)pl.nf * (pl.wide ? 4 : 2)))) return rc;
-    if ((rc = mb.entries.ensure((size_t)pl.nf * 4))) return rc;
-    if ((rc = mb.buckets.ensure((size_t)pl.g.B * PT))) return rc;
-    if ((rc = mb.part_pt.ensure((size_t)max_lanes * 2 * PT))) return rc;
-    if ((rc = mb.part_key.ensure((size_t)(PRE_Q_OFF + pl.g.B + 2) * 4))) return rc;   // partition-sort scratch | combine queues
+    return ZK_OK;
+}
+
+// bytes of every work buffer of a job's set (MsmBufs) under a plan; 0 = not used
+struct PreSizes {
+    size_t counts, offsets, entries, buckets, part_pt, part_key, seg, seg2, seg3, win, stage;
+};
+
+template <class Cv>
+void pre_sizes(const PrePlan& pl, PreSizes& z) {
+    typedef typename Cv::FqU F;
+    constexpr size_t PT = (size_t)4 * Store<F>::WORDS * 4;
+    memset(&z, 0, sizeof z);
+    z.counts = (size_t)256 * PS_SLABS * 4;                       // slab counts of the 256 sort partitions -> cursors
+    z.offsets = (size_t)(pl.g.B + 1) * 4;
+    // the sorted references.  The job's digits (int16 / int32 per reference) live here first: the digit kernel writes them, the
+    // partition scatter reads them into the staging area, and only then the placement kernel overwrites them with the references
+    z.entries = (size_t)pl.nf * 4;
+    z.buckets = (size_t)pl.g.B * PT;
+    z.part_pt = (size_t)pl.max_lanes * 2 * PT;
+    z.part_key = (size_t)(PRE_Q_OFF + pl.g.B + 2) * 4;          // partition-sort scratch | combine queues
     if (pl.wide_red) {
         const size_t n1 = pl.g.B >> WIDE_LOGG1, n2 = n1 >> WIDE_LOGK2;
-        if ((rc = mb.seg.ensure(n1 * 2 * PT))) return rc;                   // level 1: (run, acc) of the 4-bucket nodes
-        if ((rc = mb.seg2.ensure(n2 * 2 * PT))) return rc;                  // level 2: 16-bucket nodes
-        if ((rc = mb.win.ensure((size_t)2 * pl.gv.W * PT))) return rc;     // level 3: S_v | T_v of the virtual windows, internal form
-        if ((rc = mb.seg3.ensure((size_t)4 * 256 * PT))) return rc;         // level 4: (run, acc) of <= 256 segments for each of S, T
+        z.seg = n1 * 2 * PT;                                     // level 1: (run, acc) of the 4-bucket nodes
+        z.seg2 = n2 * 2 * PT;                                    // level 2: 16-bucket nodes
+        z.win = (size_t)2 * pl.gv.W * PT;                        // level 3: S_v | T_v of the virtual windows, internal form
+        z.seg3 = (size_t)4 * 256 * PT;                           // level 4: (run, acc) of <= 256 segments for each of S, T
     } else {
-        if ((rc = mb.seg.ensure((size_t)pl.gv.W * pl.gv.ns * 2 * PT))) return rc;
-        if ((rc = mb.win.ensure(pl.win_bytes > (size_t)2 * pl.gv.W * PT ? pl.win_bytes : (size_t)2 * pl.gv.W * PT))) return rc;   // SAT or internal form
+        z.seg = (size_t)pl.gv.W * pl.gv.ns * 2 * PT;
+        z.win = pl.win_bytes > (size_t)2 * pl.gv.W * PT ? pl.win_bytes : (size_t)2 * pl.gv.W * PT;   // SAT or internal form
     }
+    z.stage = (size_t)pl.nf * (pl.wide ? 6 : 5);                 // references in partition order + their low bucket bits
+}
+
+// bytes the device would have to give for this job: what pre_ensure would newly allocate in `mb` (and in the ctx's shared staging area)
+template <class Cv>
+size_t pre_need(zk_ctx* c, const PrePlan& pl, const MsmBufs& mb) {
+    PreSizes z;
+    pre_sizes<Cv>(pl, z);
+    size_t t = mb.counts.need_for(z.counts) + mb.offsets.need_for(z.offsets) + mb.entries.need_for(z.entries) + mb.buckets.need_for(z.buckets) +
+               mb.part_pt.need_for(z.part_pt) + mb.part_key.need_for(z.part_key) + mb.seg.need_for(z.seg) + mb.win.need_for(z.win);
+    if (z.seg2) t += mb.seg2.need_for(z.seg2) + mb.seg3.need_for(z.seg3);
+    t += pl.shared_stage ? c->stage_shared.need_for(z.stage) : mb.stage.need_for(z.stage);
+    return t;
+}
+
+template <class Cv>
+int pre_ensure(zk_ctx* c, const PrePlan& pl, MsmBufs& mb) {
+    PreSizes z;
+    pre_sizes<Cv>(pl, z);
+    int rc;
+    if ((rc = mb.counts.ensure(z.counts))) return rc;
+    if ((rc = mb.offsets.ensure(z.offsets))) return rc;
+    if ((rc = mb.entries.ensure(z.entries))) return rc;
+    if ((rc = mb.buckets.ensure(z.buckets))) return rc;
+    if ((rc = mb.part_pt.ensure(z.part_pt))) return rc;
+    if ((rc = mb.part_key.ensure(z.part_key))) return rc;
+    if ((rc = mb.seg.ensure(z.seg))) return rc;
+    if ((rc = mb.win.ensure(z.win))) return rc;
+    if (z.seg2 && ((rc = mb.seg2.ensure(z.seg2)) || (rc = mb.seg3.ensure(z.seg3)))) return rc;
+    // (growing a buffer frees the old one: hipFree waits for the device, so kernels of earlier jobs still reading it are safe)
+    if ((rc = (pl.shared_stage ? c->stage_shared : mb.stage).ensure(z.stage))) return rc;
     return ZK_OK;
+}
+
+template <class Cv>
+int pre_plan(zk_ctx* c, zk_srs* s, size_t n, MsmBufs& mb, PrePlan& pl, bool long_chunks = false) {
+    int rc = pre_plan_geom<Cv>(c, s, n, pl, long_chunks);
+    if (rc) return rc;
+    return pre_ensure<Cv>(c, pl, mb);
 }
 
 // The sort of a table-path job comes in two pieces.  `pre_queue_digits` is the only kernel that reads the caller's scalars
@@ -2229,10 +2287,8 @@ int pre_queue_digits(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_sc
         uint32_t* part_total = part_start + P + 1;
         uint32_t* scan_counter = part_total + P;
         uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
-        if ((rc = mb.stage.ensure((size_t)pl.nf * 6))) return rc;
-        if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
         uint32_t* hist = (uint32_t*)mb.counts.p;
-        int32_t* dig32 = (int32_t*)mb.tmp.p;
+        int32_t* dig32 = (int32_t*)mb.entries.p;          // the digits wait in the buffer of the sorted references (pre_sizes)
         if (mont) hipLaunchKernelGGL((psortw_digits_hist<FrS, true>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
                                      lob, dig32, hist, scan_counter, combine_q);
         else hipLaunchKernelGGL((psortw_digits_hist<FrS, false>), dim3(PS_SLABS), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n, sp, pl.g,
@@ -2241,15 +2297,13 @@ int pre_queue_digits(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_sc
         return ZK_OK;
     }
     if (!pre_psort16(pl)) return ZK_ERR_UNSUPPORTED;     // the table windows are 16 .. 21 bits: 2^15 buckets = 256 partitions of 128
-    int16_t* dig = (int16_t*)mb.tmp.p;
+    int16_t* dig = (int16_t*)mb.entries.p;
     const bool pairs = (n & 1) == 0 && pl.g.c == 16 && pl.g.W == 16 && pl.g.Wt == 16 && !pl.g.neg;        // two scalars per lane
     const uint32_t P = pl.g1.nb >> PS_LOB;
     uint32_t* part_start = (uint32_t*)mb.part_key.p;    // P + 1 partition starts | P totals | scan counter
     uint32_t* part_total = part_start + P + 1;
     uint32_t* scan_counter = part_total + P;
     uint32_t* combine_q = (uint32_t*)mb.part_key.p + PRE_Q_OFF;
-    if ((rc = mb.stage.ensure((size_t)pl.nf * 5))) return rc;
-    if ((rc = mb.counts.ensure((size_t)256 * PS_SLABS * 4))) return rc;
     uint32_t* hist = (uint32_t*)mb.counts.p;
     if (pairs && P == 256) {
         // digits and the per-slab partition counts in one kernel
@@ -2278,11 +2332,21 @@ int pre_queue_digits(zk_ctx* c, const PrePlan& pl, MsmBufs& mb, const void* d_sc
     return ZK_OK;
 }
 
-// jobs of one SRS (same window geometry); lens[k] scalars in job k
+// jobs of one SRS (same window geometry); lens[k] scalars in job k.  Jobs whose plan shares the ctx's staging area (shared_stage:
+// 2^24 scalars and more at c = 20) are placed one after the other -- three launches per job, each tens of milliseconds long.
 template <class Cv>
 int pre_queue_sort_rest(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, const size_t* lens, uint32_t n_jobs, hipStream_t st) {
     if (n_jobs == 0) return ZK_OK;
     if (n_jobs > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
+    uint32_t n_shared = 0;
+    for (uint32_t k = 0; k < n_jobs; ++k) n_shared += pls[k].shared_stage ? 1u : 0u;
+    if (n_shared && n_jobs > 1) {
+        for (uint32_t k = 0; k < n_jobs; ++k) {
+            int rc = pre_queue_sort_rest<Cv>(c, pls + k, mbs + k, lens + k, 1, st);
+            if (rc) return rc;
+        }
+        return ZK_OK;
+    }
     ProfScope ps(c, "msm_sort", st);
     const PrePlan& p0 = pls[0];
     const uint32_t P = p0.wide ? 256u : p0.g1.nb >> PS_LOB;
@@ -2291,15 +2355,16 @@ int pre_queue_sort_rest(zk_ctx* c, const PrePlan* pls, MsmBufs* const* mbs, cons
     for (uint32_t k = 0; k < n_jobs; ++k) {
         MsmBufs& mb = *mbs[k];
         SJob& J = sj.j[k];
-        J.dig = mb.tmp.p;
+        void* stage = pls[k].shared_stage ? c->stage_shared.p : mb.stage.p;
+        J.dig = mb.entries.p;           // overwritten by the placement kernel once the scatter has read them
         J.n = lens[k];
         J.sp = psort_slab_len(lens[k]);
         J.hist = (uint32_t*)mb.counts.p;
         J.part_start = (uint32_t*)mb.part_key.p;
         J.part_total = J.part_start + P + 1;
         J.counter = J.part_total + P;
-        J.stage_ref = (uint32_t*)mb.stage.p;
-        J.stage_lo = (char*)mb.stage.p + (size_t)pls[k].nf * 4;
+        J.stage_ref = (uint32_t*)stage;
+        J.stage_lo = (char*)stage + (size_t)pls[k].nf * 4;
         J.entries = (uint32_t*)mb.entries.p;
         J.offsets = (uint32_t*)mb.offsets.p;
     }
@@ -2659,6 +2724,10 @@ int msm_run_pre(zk_ctx* c, zk_srs* s, size_t base_offset, const void* d_scalars,
     MsmBufs& mb = c->mb[0];
     PrePlan pl;
     int rc = pre_plan<Cv>(c, s, n, mb, pl);
+    if (rc == ZK_ERR_OOM) {                        // sets of earlier, larger rounds still hold memory: give it back and try once more
+        zk_release_free_work(c, 0);
+        rc = pre_plan<Cv>(c, s, n, mb, pl);
+    }
     if (rc) return rc;
     if ((rc = ensure_pinned(c, pl.win_bytes * MAX_JOBS))) return rc;
     MsmBufs* one = &mb;
@@ -2691,10 +2760,27 @@ int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 // Option "msm_merge" = 0 (A/B hook): every job is sorted and accumulated by its own launches at begin, as before round 4.
 static bool msm_merge_enabled(const zk_ctx* c) { return c->tune.msm_merge != 0; }
 
+// bytes of device memory the table path may still take: free memory minus the reserve of the ctx's options (transforms, the
+// caller's own allocations in flight); SIZE_MAX when the runtime cannot say (hipMalloc then decides)
+static size_t pre_mem_available(const zk_ctx* c) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return SIZE_MAX;
+    const size_t reserve = (size_t)(c->tune.mem_reserve_mb < 0 ? 0 : c->tune.mem_reserve_mb) << 20;
+    return fr > reserve ? fr - reserve : 0;
+}
+
+// Memory budget: before job k takes the buffer set of its slot,
+//   1. a FREE set (no job living in it) that already holds more of what the job needs is adopted -- its work buffers change places
+//      with the slot's -- so that sets released by an early close are reused instead of allocated again;
+//   2. if the device then has no room for what is still missing (hipMemGetInfo; or the test hook's limit on the queued sets) and
+//      jobs are queued whose close would free their sets, the call stops with ZK_ERR_OOM and *n_begun jobs begun: the caller
+//      closes the queued jobs (msm_batch_pre_end), parks their points and calls again.
+// With nothing queued the job is always attempted: a hard ZK_ERR_OOM then comes from hipMalloc itself.
 template <class Cv>
 int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                         const uint8_t* kinds /* per job: 0 Montgomery coefficients, 1 canonical scalars; may be null */,
-                        const std::function<int(uint32_t)>* before_job /* optional: runs before job k is queued */) {
+                        const std::function<int(uint32_t)>* before_job /* optional: runs before job k is queued */, uint32_t* n_begun) {
+    if (n_begun) *n_begun = 0;
     if (n_polys == 0) return ZK_OK;
     if (slot0 + n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
     int rc;
@@ -2703,11 +2789,41 @@ int msm_batch_pre_begin(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, 
     for (uint32_t k = 0; k < n_polys; ++k) {
         MsmBufs& mb = c->mb[slot0 + k];
         PrePlan pl;
-        if ((rc = pre_plan<Cv>(c, s, lens[k], mb, pl))) return rc;
+        if ((rc = pre_plan_geom<Cv>(c, s, lens[k], pl))) return rc;
+        size_t need = pre_need<Cv>(c, pl, mb);
+        if (need) {
+            int best = -1;
+            for (int j = 0; j < MAX_JOBS; ++j) {
+                MsmBufs& o = c->mb[j];
+                if (&o == &mb || o.stage_of_job != 0 || o.entries.cap == 0) continue;
+                const size_t nj = pre_need<Cv>(c, pl, o);
+                if (nj < need) {
+                    need = nj;
+                    best = j;
+                }
+            }
+            if (best >= 0) mb.swap_work(c->mb[best]);
+        }
+        if (need) {
+            size_t queued_bytes = 0;
+            uint32_t queued = 0;
+            for (int j = 0; j < MAX_JOBS; ++j)
+                if (c->mb[j].stage_of_job != 0) {
+                    queued_bytes += c->mb[j].work_bytes();
+                    ++queued;
+                }
+            if (queued) {
+                const size_t limit = (size_t)(c->tune.round_mem_limit_mb > 0 ? c->tune.round_mem_limit_mb : 0) << 20;
+                if (limit && queued_bytes + need > limit) return ZK_ERR_OOM;
+                if (need > pre_mem_available(c)) return ZK_ERR_OOM;
+            }
+        }
+        if ((rc = pre_ensure<Cv>(c, pl, mb))) return rc;
         const bool mont = !kinds || kinds[k] == 0;   // a commit: Montgomery coefficients, into_repr fused into the digit kernel
         if (before_job && (rc = (*before_job)(k))) return rc;
         if ((rc = pre_queue_digits<Cv>(c, pl, mb, d_coeffs[k], lens[k], st, mont))) return rc;
         mb.stage_of_job = 1;
+        if (n_begun) *n_begun = k + 1;
         if (defer) continue;
         MsmBufs* one = &mb;
         if ((rc = pre_queue_sort_rest<Cv>(c, &pl, &one, &lens[k], 1, st))) return rc;
@@ -2743,7 +2859,7 @@ int msm_batch_pre_reduce(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* 
     uint32_t nd = 0;
     for (uint32_t k = 0; k < n_jobs; ++k) {
         const bool deferred = mbs[k]->stage_of_job == 1;
-        if ((rc = pre_plan<Cv>(c, s, lens[k], *mbs[k], pl[k], deferred && k != last_deferred))) return rc;    // buffers already large enough: no allocation
+        if ((rc = pre_plan_geom<Cv>(c, s, lens[k], pl[k], deferred && k != last_deferred))) return rc;    // the buffers were taken at begin
         if (pl[k].g1.nb != pl[0].g1.nb || pl[k].gv.ns != pl[0].gv.ns) return ZK_ERR_UNSUPPORTED;
         // a device form the reduction cannot deliver is refused HERE, before the sort and the accumulation of the deferred jobs
         // are queued: the round is then exactly as it was and the host form may still close it
@@ -2839,7 +2955,7 @@ int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slo
     c->round_reduced = 0;
     PrePlan pl[MAX_JOBS];
     for (uint32_t k = 0; k < n_jobs; ++k)
-        if ((rc = pre_plan<Cv>(c, s, lens[k], c->mb[slots[k]], pl[k]))) return rc;
+        if ((rc = pre_plan_geom<Cv>(c, s, lens[k], pl[k]))) return rc;
     const size_t wb = pl[0].win_bytes;
     static const bool host_timing = getenv("ZK_HOST_TIMING") != nullptr;      // diagnostic: where the host tail of a round goes
     const auto t0 = std::chrono::steady_clock::now();
@@ -2871,16 +2987,46 @@ int msm_batch_pre_end(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slo
     return pre_host_finish_jobs<Cv>(c, h_win, wb, n_jobs, pl[0].gv.W, pl[0].gv.B, out_xyz, out_xy, out_inf);
 }
 
+// The blocking form: begin every job, end them together.  Under the memory budget (msm_batch_pre_begin) the call may come in
+// pieces -- the jobs begun so far are ended, their sets reused by the rest -- with the same points in the same order.
 template <class Cv>
 int msm_batch_pre(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, uint64_t* out_xyz /* n_polys x 3L */,
                   const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job) {
+    constexpr int L64 = Cv::Fq::N / 2;
     if (n_polys == 0) return ZK_OK;
     if (n_polys > (uint32_t)MAX_JOBS) return ZK_ERR_UNSUPPORTED;
-    int rc = msm_batch_pre_begin<Cv>(c, s, 0, n_polys, d_coeffs, lens, kinds, before_job);
-    if (rc) return rc;
-    uint32_t slots[MAX_JOBS];
-    for (uint32_t k = 0; k < n_polys; ++k) slots[k] = k;
-    return msm_batch_pre_end<Cv>(c, s, n_polys, slots, lens, out_xyz, out_xy, out_inf);
+    for (int k = 0; k < MAX_JOBS; ++k) c->mb[k].stage_of_job = 0;     // no round is open (the callers refuse otherwise): every set is free
+    uint32_t done = 0;
+    bool released = false;
+    while (done < n_polys) {
+        uint32_t begun = 0;
+        const std::function<int(uint32_t)> shifted = [&](uint32_t k) { return (*before_job)(done + k); };
+        int rc = msm_batch_pre_begin<Cv>(c, s, 0, n_polys - done, d_coeffs + done, lens + done, kinds ? kinds + done : nullptr,
+                                         before_job ? &shifted : nullptr, &begun);
+        if (rc == ZK_ERR_OOM && begun == 0 && !released) {
+            zk_release_free_work(c, -1);           // whatever earlier, larger calls left in the sets
+            released = true;
+            continue;
+        }
+        if (rc && !(rc == ZK_ERR_OOM && begun > 0)) {
+            if (begun) (void)hipStreamSynchronize(c->stream);     // the queued kernels still read the caller's inputs
+            for (int k = 0; k < MAX_JOBS; ++k) c->mb[k].stage_of_job = 0;
+            return rc;
+        }
+        const uint32_t m = rc ? begun : n_polys - done;
+        if (rc) ++c->round_flushes;
+        uint32_t slots[MAX_JOBS];
+        for (uint32_t k = 0; k < m; ++k) slots[k] = k;
+        rc = msm_batch_pre_end<Cv>(c, s, m, slots, lens + done, out_xyz + (size_t)done * 3 * L64, out_xy ? out_xy + (size_t)done * 2 * L64 : nullptr,
+                                   out_inf ? out_inf + done : nullptr);
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            for (int k = 0; k < MAX_JOBS; ++k) c->mb[k].stage_of_job = 0;
+            return rc;
+        }
+        done += m;
+    }
+    return ZK_OK;
 }
 
 template <class Fq>
@@ -2991,7 +3137,7 @@ int ZK_SYM(msm_batch_pre_dev)(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void
 
 int ZK_SYM(msm_batch_pre_begin_dev)(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                                     const uint8_t* kinds, const std::function<int(uint32_t)>* before_job) {
-    return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
+    return msm_batch_pre_begin<CurveSel>(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job, nullptr);
 }
 int ZK_SYM(msm_batch_pre_reduce_dev)(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials,
                                      int partial_kind) {

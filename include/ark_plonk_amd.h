@@ -94,6 +94,12 @@ int zk_ctx_set_staging(zk_ctx* ctx, int mode);
  *   "pre_max_log_n"  vectors longer than 2^value take the per-window path even over a table: 0 = built-in limit (2^26), 13 .. 25
  *                    (test hook; the ranks of a window-sharded MSM must agree on it, as on "pre_vw" / "pre_logg" for the
  *                    window-sum exchange below)
+ *   "mem_reserve_mb"      device memory (MiB) the table path leaves alone when it decides whether another deferred job's buffer set
+ *                         still fits (hipMemGetInfo): default 1024
+ *   "round_mem_limit_mb"  test hook, 0 = off: the buffer sets of a round's QUEUED jobs may together hold at most this many MiB, so that
+ *                         the early close described at zk_kzg_round_begin_dev can be exercised at small sizes
+ *   "host_workers"        helper threads of the ctx's host pool (window-sum combine, affine normalisation, digests): default
+ *                         min(15, hardware threads - 1); a launcher with several ranks per host passes cores / LOCAL_WORLD_SIZE - 1
  * ZK_ERR_UNSUPPORTED: unknown key; ZK_ERR_BAD_ARG: value out of range; ZK_ERR_PENDING: a deferred round is open (a job's plan must
  * not change between its accumulation and its reduction).  The library reads NO environment variable on a compute path
  * (ZK_VERBOSE and ZK_HOST_TIMING switch diagnostics on stderr only). */
@@ -317,6 +323,15 @@ int zk_kzg_round_end(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xy, uint8_t* ou
 int zk_kzg_round_end_partial(zk_ctx* ctx, uint32_t n_jobs, uint64_t* out_xyz);
 int zk_kzg_round_pending(zk_ctx* ctx, uint32_t* n_jobs);
 int zk_kzg_round_abort(zk_ctx* ctx);
+/* Memory of a deferred round (round 6).  Every queued table-path job lives in a buffer set of its own until the round closes --
+ * 4 B per (scalar, window) for its sorted references plus the chunk-edge partials and bucket arrays: 71 MB per job at n = 2^20, 2.5 GB at
+ * 2^25 -- and sets are kept for the next round.  A begin that finds no room on the device for another set (hipMemGetInfo
+ * minus option "mem_reserve_mb", or hipMalloc failing) CLOSES THE JOBS QUEUED SO FAR -- sort, accumulation, reduction, host combine, the
+ * points parked in call order -- and reuses their sets; the round stays open and zk_kzg_round_end* returns exactly the points it would
+ * have returned.  ZK_ERR_OOM is left for a size whose blocking form does not fit either (the reference itself has no size limit but
+ * the field's two-adicity: plonk-core/src/error.rs:14-21).  zk_round_mem_stats: early closes so far, bytes held by the buffer sets, and
+ * the device's free / total memory as the budget sees it (any pointer may be NULL). */
+int zk_round_mem_stats(zk_ctx* ctx, uint64_t* early_closes, uint64_t* set_bytes, uint64_t* device_free, uint64_t* device_total);
 /* Since round 4 a begin queues only the digit kernel of its jobs -- the one kernel that reads the caller's vectors, so the inputs are
  * consumed in stream order at the call, as before -- and zk_kzg_round_reduce / _end queue the rest for ALL jobs of the round as one
  * launch per kernel: the sort's placement passes, ONE accumulation launch (msm_accumulate_batch), the reductions.

@@ -11,10 +11,29 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 static std::atomic<long> g_launches{0}, g_allocs{0}, g_frees{0};
 extern "C" long fake_hip_launches() { return g_launches.load(); }
 extern "C" long fake_hip_live_allocations() { return g_allocs.load() - g_frees.load(); }
+// A "device" of `budget` bytes (0 = unbounded, reported as 64 GiB free of 256): hipMalloc fails with hipErrorOutOfMemory beyond it and
+// hipMemGetInfo reports what is left -- the memory budget of the deferred rounds and the error paths behind a failed allocation
+// run under the sanitizers through this.
+static std::mutex g_mem_mu;
+static std::map<void*, size_t> g_mem;
+static size_t g_live_bytes = 0, g_budget = 0, g_report_extra = 0;
+// report_extra: hipMemGetInfo over-reports the free memory by this much (fragmentation, another process): the estimate says "fits",
+// hipMalloc says no
+extern "C" void fake_hip_set_memory(size_t budget, size_t report_extra) {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    g_budget = budget;
+    g_report_extra = report_extra;
+}
+extern "C" size_t fake_hip_live_bytes() {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    return g_live_bytes;
+}
 
 extern "C" {
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -24,14 +43,41 @@ hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "fake hip"; }
 hipError_t hipMalloc(void** p, size_t n) {
+    *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        if (g_budget && g_live_bytes + n > g_budget) return hipErrorOutOfMemory;
+    }
     *p = calloc(n ? n : 1, 1);
     if (!*p) return hipErrorOutOfMemory;
     ++g_allocs;
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    g_mem[*p] = n;
+    g_live_bytes += n;
     return hipSuccess;
 }
 hipError_t hipFree(void* p) {
-    if (p) ++g_frees;
+    if (p) {
+        ++g_frees;
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        auto it = g_mem.find(p);
+        if (it != g_mem.end()) {
+            g_live_bytes -= it->second;
+            g_mem.erase(it);
+        }
+    }
     free(p);
+    return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t* fr, size_t* tot) {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    if (g_budget) {
+        *tot = g_budget;
+        *fr = (g_budget > g_live_bytes ? g_budget - g_live_bytes : 0) + g_report_extra;
+    } else {
+        *tot = (size_t)256 << 30;
+        *fr = (size_t)64 << 30;
+    }
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }

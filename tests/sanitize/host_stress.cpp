@@ -21,6 +21,8 @@
 
 extern "C" long fake_hip_launches();
 extern "C" long fake_hip_live_allocations();
+extern "C" void fake_hip_set_memory(size_t budget, size_t report_extra);
+extern "C" size_t fake_hip_live_bytes();
 
 #define REQUIRE(cond)                                                              \
     do {                                                                           \
@@ -264,6 +266,61 @@ int main() {
             });
         for (auto& t : th) t.join();
         REQUIRE(g_fail.load() == 0);
+    }
+
+    // ---- 2b. the memory budget of the deferred rounds (round 6): a begin that finds no room for another job's buffer set closes the
+    // queued jobs early and reuses their sets; the option's soft limit, a "device" that really runs out (hipMalloc failing), and a
+    // device too small for even one set (ZK_ERR_OOM, the ctx usable afterwards)
+    {
+        std::vector<void*> d(4, nullptr);
+        zk_ctx* c = nullptr;
+        REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
+        for (int k = 0; k < 4; ++k) {
+            REQUIRE(zk_dev_alloc(c, n * 32, &d[k]) == ZK_OK);
+            REQUIRE(zk_dev_upload(c, d[k], polys[k].data(), n * 32) == ZK_OK);
+        }
+        const void* in[8] = {d[0], d[1], d[2], d[3], d[0], d[1], d[2], d[3]};
+        size_t lens[8] = {n, n, n - 1, 64, n, n - 2, n, n};
+        uint64_t xy[16 * 12], z[4] = {5, 0, 0, 0}, ch[4] = {7, 0, 0, 0};
+        uint8_t inf[16];
+        uint64_t closes = 0, set_bytes = 0, fr = 0, tot = 0;
+        REQUIRE(zk_ctx_set_option(c, "round_mem_limit_mb", 40) == ZK_OK && zk_ctx_set_option(c, "mem_reserve_mb", 0) == ZK_OK);
+        for (int it = 0; it < 3; ++it) {
+            REQUIRE(zk_kzg_round_begin_dev(c, srs, 8, in, lens, nullptr) == ZK_OK);
+            REQUIRE(zk_kzg_open_begin_dev(c, srs, 3, in, lens, z, ch) == ZK_OK);
+            REQUIRE(zk_kzg_round_begin_dev(c, srs, 4, in, lens, nullptr) == ZK_OK);
+            if (it == 1) REQUIRE(zk_kzg_round_reduce(c) == ZK_OK);
+            REQUIRE(zk_kzg_round_end(c, 13, xy, inf) == ZK_OK && inf[0] && inf[12]);
+        }
+        REQUIRE(zk_round_mem_stats(c, &closes, &set_bytes, &fr, &tot) == ZK_OK && closes >= 3 && set_bytes < ((size_t)110 << 20) && tot > fr);     // two table-path sets of 19 MB (nine without the
+                                                                                          // budget); n - 1, n - 2 and 64 are per-window jobs
+        REQUIRE(zk_kzg_commit_batch_dev(c, srs, 8, in, lens, xy, inf) == ZK_OK && inf[7]);       // the blocking batch in pieces
+        REQUIRE(zk_ctx_set_option(c, "round_mem_limit_mb", 0) == ZK_OK);
+        zk_ctx_destroy(c);
+        // a device with room for about three sets beyond what is live: hipMemGetInfo says so first, hipMalloc itself when the reserve hides it
+        for (int lie = 0; lie < 2; ++lie) {
+            REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
+            REQUIRE(zk_ctx_set_option(c, "mem_reserve_mb", 0) == ZK_OK);
+            fake_hip_set_memory(fake_hip_live_bytes() + ((size_t)56 << 20), lie ? (size_t)1 << 30 : 0);
+            REQUIRE(zk_kzg_round_begin_dev(c, srs, 8, in, lens, nullptr) == ZK_OK);
+            REQUIRE(zk_kzg_open_begin_dev(c, srs, 3, in, lens, z, ch) == ZK_OK);
+            REQUIRE(zk_kzg_round_end(c, 9, xy, inf) == ZK_OK && inf[8]);
+            REQUIRE(zk_round_mem_stats(c, &closes, nullptr, &fr, nullptr) == ZK_OK && closes >= 1 && (lie || fr < ((size_t)56 << 20)));
+            // too small for a single set: ZK_ERR_OOM, nothing queued, the round can be dropped and the ctx works again with memory back
+            fake_hip_set_memory(fake_hip_live_bytes() + ((size_t)1 << 20), 0);
+            zk_ctx* c2 = nullptr;
+            REQUIRE(zk_ctx_create(0, &c2) == ZK_OK);
+            REQUIRE(zk_kzg_round_begin_dev(c2, srs, 2, in, lens, nullptr) == ZK_ERR_OOM);
+            REQUIRE(zk_kzg_round_abort(c2) == ZK_OK);
+            REQUIRE(zk_kzg_commit_batch_dev(c2, srs, 2, in, lens, xy, inf) == ZK_ERR_OOM);
+            fake_hip_set_memory(0, 0);
+            REQUIRE(zk_kzg_commit_batch_dev(c2, srs, 2, in, lens, xy, inf) == ZK_OK && inf[1]);
+            zk_ctx_destroy(c2);
+            zk_ctx_destroy(c);
+        }
+        REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
+        for (int k = 0; k < 4; ++k) REQUIRE(zk_dev_free(c, d[k]) == ZK_OK);
+        zk_ctx_destroy(c);
     }
 
     // ---- 3. eviction: drop every unreferenced entry, then the last references

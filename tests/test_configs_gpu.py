@@ -132,6 +132,36 @@ def test_config5_poseidon_size_point_2_25(ctx, oracle_cpu):
     assert_is_scalar_times_g(got, k, cid)
 
 
+def test_config5_deferred_schedule_2_25(ctx):
+    """Config 5's size point through the DEFAULT form of the per-proof schedule (eleven PC calls collected in five deferred rounds,
+    sixteen jobs in the last one): round 5 returned ZK_ERR_OOM here -- 52.8 GiB of table + 87 GiB of the schedule's own polynomials +
+    194 GiB of job buffer sets.  With the digits parked in the reference buffer, one staging area per round and at most eight rounds
+    of lanes per job the sets hold about 41 GB, and a begin that still found no room would close the queued jobs early
+    instead of failing.  The 29 points equal those of the blocking form (every call waits; at most seven jobs alive), proof for proof."""
+    import torch
+    from ark_plonk_amd.prover_schedule import ProofSchedule
+    from test_deferred_gpu import _ck
+    cv = zk.get_curve(0)
+    log_n = 25
+    ck = _ck(ctx, cv, 1 << log_n, seed=2525).precompute()
+    assert ck.table_window_bits() == 20
+    blocking = ProofSchedule(log_n, ctx, ck, cv, defer_calls=False)
+    want = blocking.run_once(proof_id=0)
+    del blocking
+    torch.cuda.empty_cache()
+    deferred = ProofSchedule(log_n, ctx, ck, cv)
+    assert deferred.defer_calls
+    got = deferred.run_once(proof_id=0)
+    st = ctx.round_mem_stats()
+    assert len(got) == 29 and got == want
+    assert len(set(pt.xy().tobytes() for pt in got)) == 20          # 29 MSMs over 20 distinct polynomials (prover.rs:569-607 commits 9 of them again)
+    assert st["set_bytes"] < 80 << 30, st                                                     # 194 GiB before the diet
+    print("2^25 deferred:", {k: (v >> 20) for k, v in st.items() if k != "early_closes"}, "MiB; early closes", st["early_closes"])
+    del deferred
+    torch.cuda.empty_cache()
+    ck.close()
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_table_window_sizes_agree(cid, ctx, oracle_cpu):
     """zk_srs_precompute_ex: every table window c in 16..21 gives the commitment of the per-window path and of the CPU

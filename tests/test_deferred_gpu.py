@@ -269,9 +269,11 @@ def test_ctx_options_api(ctx):
     from ark_plonk_amd import _lib
     L = _lib.lib()
     import ctypes
+    import os
     for key in ctx.OPTIONS:
         old = ctx.get_option(key)
-        assert old == {"msm_merge": 1, "pre_logg": -1, "long_rounds": 1}.get(key, 0)
+        assert old == {"msm_merge": 1, "pre_logg": -1, "long_rounds": 1, "mem_reserve_mb": 1024,
+                       "host_workers": min(15, max(0, (os.cpu_count() or 1) - 1))}.get(key, 0)
     assert L.zk_ctx_set_option(ctx.handle, b"no_such_key", 1) == _lib.ZK_ERR_UNSUPPORTED
     v = ctypes.c_int64()
     assert L.zk_ctx_get_option(ctx.handle, b"no_such_key", ctypes.byref(v)) == _lib.ZK_ERR_UNSUPPORTED
@@ -296,4 +298,108 @@ def test_ctx_options_api(ctx):
         for k in ("pre_vw", "chunk_l", "combine_sg"):
             ctx.set_option(k, 0)
         ctx.set_option("pre_logg", -1)
+    ck.close()
+
+
+# ---- the memory budget of a deferred round (round 6): no room for another job's buffer set -> the queued jobs are
+# closed early, their points parked, their sets reused; the round returns exactly the points it would have returned
+def _budget_round(ck, ctx, p, z, chi):
+    """sixteen jobs in the shape of the prover's last round, with a short vector (computed at begin) and an odd length in it"""
+    ck.commit_begin(p[:4])
+    ck.commit_begin([p[4][:1000], p[5][: p[5].shape[0] - 3], p[6]])
+    ck.open_begin(p[:7] + p[10:12], z, chi)
+    ck.commit_begin(p[7:14])
+    return ck.open_begin(p[7:14], z, chi)
+
+
+@pytest.mark.parametrize("cid,window", [(0, 0), (1, 0), (0, 20)])
+def test_round_under_a_memory_budget_closes_early_and_returns_the_same_points(ctx, cid, window):
+    cv = zk.get_curve(cid)
+    n = 1 << 14
+    ck = _ck(ctx, cv, n, seed=61).precompute(window)
+    p = _polys(n, 14, 62)
+    if cid == 1:
+        for t in p:
+            t[:, 3] >>= 2
+    z = np.array([5, 6, 7, 8], dtype=np.uint64)
+    chi = np.array([9, 10, 11, 12], dtype=np.uint64)
+    # the reference round on a fresh ctx (the session's shared ctx still holds the sets of earlier, larger tests): sixteen sets
+    ctx1 = zk.Context(ctx.device)
+    ctx1.use_torch_stream()
+    ck1 = ck.with_ctx(ctx1)
+    assert _budget_round(ck1, ctx1, p, z, chi) == 16
+    want = ck1.round_end()
+    st0 = ctx1.round_mem_stats()
+    ctx1.close()
+    assert want[:4] == ck.commit_batch(p[:4]) and want[7] == ck.open(p[:7] + p[10:12], z, chi)
+    per_set = st0["set_bytes"] // 16
+    assert st0["device_total"] > st0["device_free"] > 0 and per_set > 0 and st0["early_closes"] == 0
+    # fresh ctx (no buffer sets yet): the queued sets may hold three jobs' worth -> the round closes early several times
+    ctx2 = zk.Context(ctx.device)
+    ctx2.use_torch_stream()
+    ck2 = ck.with_ctx(ctx2)
+    try:
+        ctx2.set_option("round_mem_limit_mb", max(1, (3 * per_set) >> 20) + 1)
+        assert _budget_round(ck2, ctx2, p, z, chi) == 16 and ck2.round_pending() == 16
+        got = ck2.round_end()
+        st = ctx2.round_mem_stats()
+        assert got == want
+        assert st["early_closes"] >= 2, st
+        assert st["set_bytes"] < st0["set_bytes"] // 2, (st, st0)        # the sets of closed jobs were reused, not allocated again
+        # the same round again: the sets exist now, nothing new is needed, nothing closes early
+        assert _budget_round(ck2, ctx2, p, z, chi) == 16
+        assert ck2.round_end() == want
+        # reduce-then-end and the Jacobian form see parked and queued jobs alike
+        _budget_round(ck2, ctx2, p, z, chi)
+        ck2.round_reduce()
+        assert ck2.round_end() == want
+        _budget_round(ck2, ctx2, p, z, chi)
+        parts = ck2.round_end_partial(16)
+        assert [zk.msm.sum_partials(parts[k:k + 1], cid) for k in range(16)] == want
+        # the blocking batch comes in pieces under the same budget (a third ctx: no sets yet)
+        ctx3 = zk.Context(ctx.device)
+        ctx3.use_torch_stream()
+        ctx3.set_option("round_mem_limit_mb", max(1, (2 * per_set) >> 20) + 1)
+        ck3 = ck.with_ctx(ctx3)
+        assert ck3.commit_batch(p[:7]) == ck.commit_batch(p[:7])
+        assert ck3.commit_batch(p[7:14]) == want[8:15]
+        assert ctx3.round_mem_stats()["early_closes"] >= 1
+        # ... and so does the host-pointer batch (uploads per job in front of its digits)
+        host = [t.cpu().numpy().view(np.uint64) for t in p[7:14]]
+        assert ck3.commit_batch(host) == want[8:15]
+        ctx3.close()
+    finally:
+        ctx2.set_option("round_mem_limit_mb", 0)
+    ctx2.close()
+    ck.close()
+
+
+def test_round_under_a_memory_budget_device_exchange_forms(ctx):
+    """Jobs parked by an early close enter the device forms of the multi-GPU exchange as jobs computed at submission do: their point
+    as virtual-window sum S_0, every other sum the point at infinity."""
+    import torch
+    cv = zk.get_curve(0)
+    n = 1 << 14
+    ck = _ck(ctx, cv, n, seed=63).precompute()
+    p = _polys(n, 6, 64)
+    want = ck.commit_batch(p)
+    ctx2 = zk.Context(ctx.device)
+    ctx2.use_torch_stream()
+    ck2 = ck.with_ctx(ctx2)
+    ck2.commit_begin(p)
+    assert ck2.round_end() == want
+    per_set = ctx2.round_mem_stats()["set_bytes"] // 6
+    ctx2.close()
+    ctx2 = zk.Context(ctx.device)
+    ctx2.use_torch_stream()
+    ck2 = ck.with_ctx(ctx2)
+    ctx2.set_option("round_mem_limit_mb", max(1, (2 * per_set) >> 20) + 1)
+    words = ck2.winsums_dev_words()
+    buf = torch.zeros((6, words), dtype=torch.int64, device="cuda")
+    for t in p:
+        ck2.commit_begin([t])
+    ck2.round_end_winsums_dev(buf, 6)
+    assert ctx2.round_mem_stats()["early_closes"] >= 1
+    assert ck2.sum_winsums_dev(buf.reshape(1, -1), 1, 6) == want
+    ctx2.close()
     ck.close()

@@ -63,6 +63,9 @@ MADD_CYCLES_2WAVES = 3055 * 4.77 + 117 * 4.70 + 492 * 4.45 + 690 * 2.64
 PURE_MAD_RATE_2_WAVES = 2.66e13
 PURE_MAD_RATE_8_WAVES = 3.41e13
 CURVE_TITLE = {"bls12_381": "BLS12-381", "bn254": "BN254"}
+TAU = 0x7A5C0DE             # the synthetic SRS is P_i = TAU^i G: a known tau lets a commitment be checked as (sum p_i tau^i) G
+# BASELINE.json configs 3, 4 and 5 as the default run's `configs` leg times them: curve:log_n:steps
+DEFAULT_CONFIGS = "bls12_381:22:2,bn254:18:5,bls12_381:25:1"
 
 
 def ark_adds(n: int, bits: int = 255) -> int:
@@ -76,20 +79,42 @@ def ark_adds(n: int, bits: int = 255) -> int:
 
 
 def build_srs(ctx, cv, n, lo, hi, torch):
-    """Synthetic KZG SRS slice P_i = tau^i G for i in [lo, hi), generated on the GPU."""
+    """Synthetic KZG SRS slice P_i = tau^i G for i in [lo, hi), generated on the GPU: the Montgomery powers by doubling
+    (pw[k:2k] = pw[0:k] * tau^k, zk_fr_mul_dev), into_repr, then the library's fixed-base utility."""
     from ark_plonk_amd import _lib, curves
-    tau = 0x7A5C0DE
-    t = pow(tau, lo, cv.r)
-    pw = []
-    for _ in range(hi - lo):
-        pw.append(t)
-        t = t * tau % cv.r
-    sc = torch.from_numpy(curves.ints_to_limbs(pw, 4).view(np.int64)).cuda()
-    out = torch.empty((hi - lo, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    L = _lib.lib()
+    m = hi - lo
     ctx.use_torch_stream()
-    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, cv.curve_id, sc.data_ptr(), hi - lo, out.data_ptr()))
+    pw = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+    pw[0] = torch.from_numpy(curves.fr_to_mont(cv, [pow(TAU, lo, cv.r)]).view(np.int64))[0].cuda()
+    k = 1
+    while k < m:
+        j = min(k, m - k)
+        step = torch.from_numpy(curves.fr_to_mont(cv, [pow(TAU, k, cv.r)]).view(np.int64)).cuda().expand(j, 4).contiguous()
+        _lib.check(L.zk_fr_mul_dev(ctx.handle, cv.curve_id, pw.data_ptr(), step.data_ptr(), j, pw[k:].data_ptr()), "zk_fr_mul_dev")
+        k *= 2
+    _lib.check(L.zk_fr_from_mont_dev(ctx.handle, cv.curve_id, pw.data_ptr(), m, pw.data_ptr()), "zk_fr_from_mont_dev")
+    out = torch.empty((m, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
+    _lib.check(L.zk_g1_fixed_base_batch_dev(ctx.handle, cv.curve_id, pw.data_ptr(), m, out.data_ptr()))
     torch.cuda.synchronize()
     return out
+
+
+def kzg_identity_holds(cv, coeffs_mont, point) -> bool:
+    """commit(p) over the SRS P_i = tau^i G is (sum_i p_i tau^i) G: the scalar side by Horner over Python integers (the raw limbs read as
+    integers are R p_i: one multiplication by R^-1 at the end), the group side by affine double-and-add (curves.g1_mul) -- no library
+    call and no oracle in either.  coeffs_mont: (n, 4) uint64 host array of Montgomery coefficients; point: G1Affine."""
+    from ark_plonk_amd import curves
+    acc = 0
+    for v in reversed(curves.limbs_to_ints(coeffs_mont)):
+        acc = (acc * TAU + v) % cv.r
+    k = acc * pow(1 << 256, -1, cv.r) % cv.r
+    exp = curves.g1_mul(cv, k)
+    if exp is None:
+        return bool(point.infinity)
+    if point.infinity:
+        return False
+    return curves.fq_from_mont(cv, point.x.reshape(1, -1))[0] == exp[0] and curves.fq_from_mont(cv, point.y.reshape(1, -1))[0] == exp[1]
 
 
 def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45.0):
@@ -532,8 +557,13 @@ def parse_args():
     ap.add_argument("--no-sharded-leg", action="store_true", help="replica mode: skip the extra sharded-MSM legs")
     ap.add_argument("--sharded-n22-leg", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: also time BASELINE config 3 (n = 2^22, MSMs point-sharded); auto = on for the default workload")
-    ap.add_argument("--extra-legs", default="auto", choices=["auto", "on", "off"],
-                    help="N = 1: drop_in, dedup and no_precompute legs; auto = on when log-n >= 16")
+    ap.add_argument("--configs", default="auto", metavar="SPEC",
+                    help="the `configs` leg (N = 1): BASELINE.json's other configurations timed by this very run, never part of `value` -- "
+                         f"'auto' = {DEFAULT_CONFIGS} (curve:log_n:steps; config 3's size on one card, config 4, config 5's size point in the "
+                         "deferred form) when the headline is the default one; 'off'; or a list of the same form")
+    ap.add_argument("--extra-legs", default="auto", choices=["auto", "on", "off", "all"],
+                    help="N = 1: blocking_calls, power, drop_in, dedup and no_precompute legs; auto = on when log-n >= 16; 'all' adds the legs "
+                         "outside SURVEY.md section 8's hot path (data_benchcircuit, with_device_glue, full_proof)")
     ap.add_argument("--dedup", action="store_true",
                     help="NOT the headline workload: the library's commitment cache on (SURVEY.md 8f N3), 17 MSMs per proof instead of 29")
     ap.add_argument("--grand-products", action="store_true",
@@ -561,6 +591,7 @@ def parse_args():
 
 
 def main():
+    t_start = time.perf_counter()
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -653,10 +684,12 @@ def main():
 
     def timed_region(sharded: bool, n_streams: int = 1, steps: int = steps, log_n: int = args.log_n, precompute: bool = not args.no_precompute,
                      dedup=("abi" if args.dedup else False), warmup: int = args.warmup, glue: bool = False, defer_calls: bool = not args.block_every_call,
-                     data: str = args.data):
+                     data: str = args.data, cv=cv, ctx=ctx, breakdown: bool = True, table_window: int = args.table_window, keep=None):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
         n_streams S > 1 (replicas / single GPU only): the K steps are dealt round-robin to S concurrent proof
-        streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS."""
+        streams (one thread + zk_ctx + HIP stream each) on this rank's GPU, all using ONE device-resident SRS.
+        cv / ctx: another curve or zk_ctx than the headline's (the `configs` leg); breakdown=False: no extra proofs with every scope on;
+        keep(sched, points): called with the schedule and the points of the digest proof before everything is freed."""
         import threading
         n = 1 << log_n
         by_windows = sharded and args.shard_axis == "windows" and world > 1
@@ -666,9 +699,9 @@ def main():
         ck0 = zk.CommitterKey(srs, cv, ctx)
         del srs
         if by_windows:
-            ck0.precompute(args.table_window, rows=(rank, world))   # this rank's windows only: about 1/G of the table over the whole SRS
+            ck0.precompute(table_window, rows=(rank, world))   # this rank's windows only: about 1/G of the table over the whole SRS
         elif precompute:
-            ck0.precompute(args.table_window)   # window-multiples table resident in HBM (one-time, like PC::trim)
+            ck0.precompute(table_window)   # window-multiples table resident in HBM (one-time, like PC::trim)
         lanes = []
         for i in range(S):
             cx = ctx if i == 0 else new_ctx(dev)
@@ -732,7 +765,7 @@ def main():
                 "msm_accumulate_jobs": ctx.profile_get("msm_accumulate_jobs"), "msm_accumulate_points": ctx.profile_get("msm_accumulate_points")}
         msms_run = lanes[0]["sched"].msms_run        # of the last timed proof (the digest run below repeats proof 0)
         kb = 0
-        if not args.no_profile:
+        if not args.no_profile and breakdown:
             kb = 2
             ctx.profile(1)
             ctx.profile_reset()
@@ -750,13 +783,16 @@ def main():
         if args.check:
             for ln in lanes:
                 with torch.cuda.stream(ln["stream"]):
-                    digs.append(digest(ln["sched"].run_once(proof_id=0)))
+                    pts0 = ln["sched"].run_once(proof_id=0)
+                    digs.append(digest(pts0))
+                    if keep is not None and ln is lanes[0]:
+                        keep(ln["sched"], pts0)
             if len(set(digs)) != 1:
                 raise RuntimeError(f"proof streams disagree: {digs}")
         res = {"dt": dt, "prof": prof, "points_per_launch": hi - lo, "digest": digs[0] if digs else None,
                "exchange": getattr(lanes[0]["sched"], "exchange", None) if sharded else None, "collectives": lanes[0]["sched"].collectives,
                "ntt_bytes": lanes[0]["sched"].ntt_bytes(), "streams": S, "steps_profiled": lanes[0]["k"], "msms_run": msms_run, "kb": kb,
-               "windows": ck0.table_windows()}
+               "windows": ck0.table_windows(), "window_bits": ck0.table_window_bits() if precompute else 0, "mem": ctx.round_mem_stats()}
         if dedup == "abi":
             for ln in lanes:
                 ln["ctx"].set_commit_cache(False)
@@ -1031,9 +1067,18 @@ def main():
         a_ms, a_n = rr["prof"]["msm_accumulate"]
         return a_ms / max(rr["prof"]["msm_accumulate_jobs"][1] or a_n, 1)
 
+    line["leg_s"] = {"headline": round(time.perf_counter() - t_start, 2)}      # wall seconds of every leg (the headline's includes start-up)
+
     def leg(name, fn):
         """an extra leg never takes the headline down; every rank agrees on its outcome first"""
         _LINE["leg"] = name
+        t_leg = time.perf_counter()
+        try:
+            _leg(name, fn)
+        finally:
+            line["leg_s"][name] = round(time.perf_counter() - t_leg, 2)
+
+    def _leg(name, fn):
         with LegDeadline(args.leg_timeout, world > 1 and rank == 0):
             try:
                 res = fn()
@@ -1044,7 +1089,8 @@ def main():
                 res = {"error": "another rank failed this leg"}
         line[name] = res
 
-    extra = args.extra_legs == "on" or (args.extra_legs == "auto" and log_n >= 16)
+    extra = args.extra_legs in ("on", "all") or (args.extra_legs == "auto" and log_n >= 16)
+    extra_all = args.extra_legs == "all"       # legs outside SURVEY.md section 8's hot path
     if world == 1 and S == 1 and args.streams_leg > 1:
         # the GPU's throughput with several proofs in flight (a proving service): small kernels of one proof fill the
         # registers/issue slots the 2-waves/SIMD accumulate of another leaves idle
@@ -1062,7 +1108,7 @@ def main():
                     "what": "the same 29 MSMs with every one of the eleven PC calls blocking (zk_kzg_round_batch_dev per call), as an unchanged Prover::prove issues them",
                     "commitments_match": (rb["digest"] == r["digest"]) if args.check else None}
         leg("blocking_calls", blocking_leg)
-    if world == 1 and S == 1 and extra and args.data == "uniform" and not (args.dedup or args.grand_products or args.quotient):
+    if world == 1 and S == 1 and extra_all and args.data == "uniform" and not (args.dedup or args.grand_products or args.quotient):
         def benchcircuit_leg():
             # SURVEY.md 8d config 2's "realistic" vector on this very binary: wire columns as benches/plonk.rs' BenchCircuit builds them
             # (composer.rs:493-548: periodic {6, 7, -20, 1} / {-20, 6, 7, 0} rows + 3 blinding rows, zero-padded) -- data-independence
@@ -1126,6 +1172,7 @@ def main():
                         "how": "zk_ctx_set_commit_cache(1): 256-bit device digest of every coefficient vector; prover.rs:569-607 re-commits 12 polynomials",
                         "commitments_match": (r3["digest"] == r["digest"]) if args.check else None}
             leg("dedup", dedup_leg)
+    if world == 1 and S == 1 and extra_all and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
         def glue_leg():
             k2 = max(2, min(steps, 3))
             r5 = timed_region(False, 1, k2, warmup=1, glue=True)
@@ -1220,6 +1267,7 @@ def main():
                             "products, the pointwise quotient, 23 evaluations, the linearisation polynomial, merlin transcript, proof bytes); "
                             "tests/test_prover_gpu.py checks such proofs against the reference verifier's equations" % log_n}
         leg("full_proof", full_proof_leg)
+    if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
         if not args.no_precompute:
             def nopre_leg():
                 k2 = max(2, min(steps, 3))
@@ -1228,6 +1276,64 @@ def main():
                         "path": "per-window buckets, host Horner; bases read once per window, no 128-B row gathers of a table",
                         "commitments_match": (r4["digest"] == r["digest"]) if args.check else None}
             leg("no_precompute", nopre_leg)
+    # ---- BASELINE.json's other configurations, timed by this very run (never part of `value`): config 3's size on one card (2^22),
+    # config 4 (BN254, 2^18) and config 5's size point (2^25) -- the reference's own harness sweeps its sizes in one invocation
+    # (benches/plonk.rs:95-162).  Default options throughout: the deferred form of the schedule, the library's default table window.
+    spec = args.configs
+    if spec == "auto":
+        spec = DEFAULT_CONFIGS if (world == 1 and S == 1 and log_n == 20 and cv.curve_id == 0 and args.extra_legs != "off"
+                                   and not (args.no_precompute or args.dedup or args.block_every_call)) else "off"
+    if world == 1 and S == 1 and spec != "off":
+        def accumulate_roofline(rr, cvx):
+            a_ms, a_n = rr["prof"]["msm_accumulate"]
+            pts = rr["prof"]["msm_accumulate_points"][1] or a_n * rr["points_per_launch"]
+            if not a_n or not a_ms:
+                return None
+            ach = (32.0 + 16.0 * cvx.fq_limbs) * pts / (a_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "avg_launch_ms": a_ms / a_n, "launches": int(a_n), "traffic": None}
+
+        def configs_leg():
+            out, t_leg0 = [], time.perf_counter()
+            for item in spec.split(","):
+                cname, lg, k2 = item.split(":")
+                lg, k2 = int(lg), int(k2)
+                cvx = zk.get_curve(cname)
+                t_c = time.perf_counter()
+                row = {"config": f"{CURVE_TITLE[cvx.name]} n=2^{lg}", "log_n": lg, "curve": cvx.name, "steps": k2}
+                cx = new_ctx(dev)                     # a ctx of its own: closing it returns the job buffer sets, plans and staging of this size
+                cx.use_torch_stream()
+                kept = {}
+
+                def keep(sched, pts, kept=kept, lg=lg):
+                    # one MSM of the digest proof for the identity check below: the first wire polynomial and its commitment
+                    if lg <= 22:
+                        kept["coef"] = sched.coef[0].cpu().numpy().view(np.uint64)
+                        kept["point"] = pts[0]
+                try:
+                    torch.cuda.empty_cache()
+                    rr = timed_region(False, 1, k2, log_n=lg, warmup=1, cv=cvx, ctx=cx, breakdown=False, table_window=0, keep=keep,
+                                      defer_calls=True, dedup=False, data="uniform", precompute=True)
+                    row.update({"proofs_per_s": k2 / rr["dt"], "ms_per_proof": rr["dt"] / k2 * 1e3,
+                                "msm_path": f"window table, c = {rr['window_bits']}, {rr['windows']} shared-bucket windows; deferred rounds (5 host waits per proof)",
+                                "roofline": accumulate_roofline(rr, cvx), "commitments_sha256": rr["digest"],
+                                "job_sets_gib": round(rr["mem"]["set_bytes"] / 2**30, 2), "early_closes": rr["mem"]["early_closes"]})
+                    if "coef" in kept:
+                        row["kzg_identity_holds"] = kzg_identity_holds(cvx, kept["coef"], kept["point"])
+                        row["kzg_identity_what"] = ("commit(w_l) of the digest proof == (sum_i p_i tau^i) G: Horner over Python integers and an "
+                                                    "affine double-and-add, no library call in the check")
+                except Exception as e:     # noqa: BLE001 -- a size that fails is reported, the others still run
+                    row["error"] = repr(e)
+                finally:
+                    kept.clear()
+                    cx.close()
+                    torch.cuda.empty_cache()
+                row["seconds"] = round(time.perf_counter() - t_c, 2)
+                out.append(row)
+            return {"what": "BASELINE.json configs 3 (its size, on one card), 4 and 5 (its size point: DESIGN.md 5) through the headline's code "
+                            "path with default options; per config: warm-up 1, then `steps` timed proofs; commitments digest of proof 0",
+                    "rows": out, "seconds": round(time.perf_counter() - t_leg0, 2)}
+        leg("configs", configs_leg)
     if world > 1 and mode == "replica" and not args.no_sharded_leg:
         # the same proofs with every MSM point-sharded over the ranks (one RCCL all-gather of Jacobian partials per
         # prover round) -- single-proof latency
@@ -1272,10 +1378,13 @@ def main():
     _LINE["leg"] = None
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            t_cb = time.perf_counter()
             try:
                 line["cpu_baseline"] = cpu_baseline(log_n, cv.curve_id, sbits)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            line["leg_s"]["cpu_baseline"] = round(time.perf_counter() - t_cb, 2)
+        line["leg_s"]["total"] = round(time.perf_counter() - t_start, 2)
         if not _LINE["printed"]:
             _LINE["printed"] = True
             print(json.dumps(line), flush=True)

@@ -174,3 +174,15 @@ def test_committed_counter_files_name_the_current_kernel_build():
     r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "ark_plonk_amd/csrc"], capture_output=True, text=True)
     if r.returncode == 0 and r.stdout.strip():
         assert r.stdout.strip().startswith(a["commit"]) or a["commit"].startswith(r.stdout.strip()), (a["commit"], r.stdout.strip())
+
+
+def test_curve_constants_and_host_scalar_mul():
+    """ark_plonk_amd/curves.py (product code, independent of oracle/): the G1 generators lie on their curves and the pure-Python
+    double-and-add bench.py uses for its KZG identity checks agrees with the oracle's group law."""
+    from ark_plonk_amd import curves
+    from oracle import bigint_oracle as bo
+    for cid in (0, 1):
+        cv, o = curves.get_curve(cid), bo.CURVES[cid]
+        assert (cv.gy * cv.gy - cv.gx ** 3 - cv.b) % cv.q == 0 and (cv.gx, cv.gy, cv.r, cv.q) == (o.gx, o.gy, o.r, o.q)
+        for k in (0, 1, 2, 3, 0xDEADBEEF12345678, cv.r - 1, cv.r, cv.r + 5):
+            assert curves.g1_mul(cv, k) == bo.ec_mul(o, k % o.r, (o.gx, o.gy)), (cid, k)

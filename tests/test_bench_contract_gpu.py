@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "13", "--steps", "2", "--warmup", "1", "--streams-leg", "2",
-                        "--check", "--extra-legs", "on"], capture_output=True, text=True, timeout=900)
+                        "--check", "--extra-legs", "all", "--configs", "bls12_381:14:2,bn254:13:2,bls12_381:15:1"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -54,6 +55,21 @@ def test_bench_json_contract():
     bc = d["data_benchcircuit"]
     assert bc["proofs_per_s"] > 0 and len(bc["commitments_sha256"]) == 64 and bc["commitments_sha256"] != d["commitments_sha256"]
     assert "power" in d and ("socket_power_w" in d["power"] or "error" in d["power"])
+    # BASELINE.json's other configurations inside the same line (the default run times 2^22, BN254 2^18 and 2^25; small stand-ins here)
+    rows = d["configs"]["rows"]
+    assert [(x["curve"], x["log_n"], x["steps"]) for x in rows] == [("bls12_381", 14, 2), ("bn254", 13, 2), ("bls12_381", 15, 1)]
+    for x in rows:
+        assert "error" not in x, x
+        assert x["proofs_per_s"] > 0 and abs(x["ms_per_proof"] * x["proofs_per_s"] - 1000.0) < 1.0 and len(x["commitments_sha256"]) == 64
+        assert x["msm_path"].startswith("window table") and x["seconds"] > 0 and x["early_closes"] == 0 and x["job_sets_gib"] >= 0
+        rfx = x["roofline"]
+        assert rfx["bound"] == "hbm" and rfx["peak"] == 8000.0 and abs(rfx["frac"] - rfx["achieved"] / rfx["peak"]) < 1e-12 and rfx["launches"] >= 5 * x["steps"]
+        assert x["kzg_identity_holds"] is True
+    # wall seconds of every leg, and of the whole run
+    ls = d["leg_s"]
+    for name in ("headline", "concurrent_streams", "blocking_calls", "power", "drop_in", "dedup", "no_precompute", "configs", "cpu_baseline", "total"):
+        assert ls[name] >= 0, name
+    assert ls["total"] >= ls["headline"] + ls["configs"]
 
 
 def test_bench_default_metric_is_baselines():

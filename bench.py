@@ -655,6 +655,10 @@ def main():
     dev = torch.cuda.current_device()
     ctx = new_ctx(dev)
     ctx.use_torch_stream()
+    if ranks_info is not None:
+        # the ranks of a host share its cores: each ctx's host pool is sized min(15, cores / LOCAL_WORLD_SIZE - 1) (ark_plonk_amd/context.py)
+        ranks_info["host_pool"] = {"workers_per_ctx": ctx.get_option("host_workers"), "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
+                                   "host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
     cv = zk.get_curve(args.curve)
     sbits = cv.r.bit_length()
     steps = args.steps

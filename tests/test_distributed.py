@@ -783,6 +783,13 @@ def test_bench_gpus_4_one_card():
     assert ms.get("commitments_match_replicas") is True and ms["exchange"] == "host" and ms["collectives_per_proof"] == 5, ms
     mw = d4["msm_sharded_winsums"]          # the same leg with the other form of the exchange: an N > 1 run times both
     assert mw.get("commitments_match_replicas") is True and mw["exchange"] == "winsums" and mw["collectives_per_proof"] == 5, mw
+    # wall seconds per leg (DESIGN.md 6 extrapolates the driver's 8-GPU run from the same fields of a 2^20 rehearsal): the budget of
+    # this rehearsal -- four ranks time-slicing ONE card at 2^13 -- is a minute per leg and the sum is what the run took
+    ls = d4["leg_s"]
+    assert set(ls) >= {"headline", "msm_sharded", "msm_sharded_winsums", "total"} and all(v < 60 for k, v in ls.items() if k != "total"), ls
+    assert abs(ls["total"] - sum(v for k, v in ls.items() if k != "total")) < 5 and ls["total"] < wall
+    hp = d4["ranks"]["host_pool"]
+    assert hp["local_world"] == 4 and hp["workers_per_ctx"] == max(0, min(15, hp["host_cores"] // 4 - 1)), hp
     for axis, form in (("points", "winsums"), ("windows", "host")):
         r, l, _ = _run_bench(common + ["--gpus", "4", "--backend", "gloo", "--mode", "shard", "--shard-axis", axis, "--exchange", form], 900)
         assert r.returncode == 0, r.stderr[-3000:]

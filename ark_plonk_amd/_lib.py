@@ -71,6 +71,7 @@ SYMBOLS = {
                                          ctypes.POINTER(ctypes.c_uint64)]),
     "zk_ctx_set_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "zk_ctx_get_option": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "zk_cache_verify_stats": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
     "zk_profile_enable": (c_int, [c_void_p, c_int]),
     "zk_profile_reset": (c_int, [c_void_p]),
     "zk_profile_get": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),

@@ -88,7 +88,7 @@ class Context:
 
     # -- tuning options of the MSM planner (zk_ctx_set_option; the ZK_* environment hooks of rounds 2-4 are gone)
     OPTIONS = ("msm_merge", "pre_vw", "pre_logg", "chunk_l", "long_rounds", "combine_sg", "pre_max_log_n", "mem_reserve_mb",
-               "round_mem_limit_mb", "host_workers")
+               "round_mem_limit_mb", "host_workers", "cache_verify")
 
     def set_option(self, key: str, value: int):
         check(lib().zk_ctx_set_option(self.handle, key.encode(), int(value)), f"zk_ctx_set_option({key})")
@@ -122,6 +122,12 @@ class Context:
         v = [ctypes.c_uint64() for _ in range(4)]
         check(lib().zk_residency_cache_stats(self.handle, *[ctypes.byref(x) for x in v]), "zk_residency_cache_stats")
         return {"hits": v[0].value, "misses": v[1].value, "entries": v[2].value, "bytes": v[3].value}
+
+    def cache_verify_stats(self) -> dict:
+        """option "cache_verify": hits of the commitment / residency cache that were checked, and how many did not hold."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().zk_cache_verify_stats(self.handle, ctypes.byref(a), ctypes.byref(b)), "zk_cache_verify_stats")
+        return {"checked": a.value, "mismatches": b.value}
 
     # -- host-pointer entry points: PCIe volume and staging mode
     def io_stats(self, reset: bool = False) -> dict:

@@ -146,6 +146,16 @@ inline bool res_wants(const zk_ctx* c, size_t bytes) { return c->res_on && bytes
 // every host-pointer call that consults the cache starts a new epoch: what it touches stays until it returns
 inline void res_begin_call(zk_ctx* c) { ++c->res_epoch; }
 
+// the buffer of an evicted / dropped entry: kept for reuse (no hipMalloc in the steady state) while the free list stays within an
+// eighth of the cache's capacity and eight buffers -- device memory beyond res_cap that no statistic showed
+void res_recycle(zk_ctx* c, DevBuf& buf) {
+    size_t held = 0;
+    for (const DevBuf& b : c->res_free) held += b.cap;
+    if (c->res_free.size() < 8 && held + buf.cap <= c->res_cap / 8) c->res_free.push_back(buf);
+    else buf.release();
+    buf = DevBuf();
+}
+
 zk_ctx::ResEntry* res_find(zk_ctx* c, size_t bytes, const uint64_t dig[4]) {
     for (auto it = c->res.begin(); it != c->res.end(); ++it)
         if (it->valid && it->bytes == bytes && memcmp(it->dig, dig, 32) == 0) {
@@ -156,6 +166,27 @@ zk_ctx::ResEntry* res_find(zk_ctx* c, size_t bytes, const uint64_t dig[4]) {
         }
     ++c->res_misses;
     return nullptr;
+}
+
+void res_drop(zk_ctx* c, zk_ctx::ResEntry* e);
+
+// option "cache_verify": a hit is believed only after the resident bytes were compared with the caller's (both streams drained, one
+// blocking download); a mismatch -- two vectors under one keyed digest, or a bug -- is counted, the entry dropped, the call uploads
+bool res_verify_hit(zk_ctx* c, zk_ctx::ResEntry* e, const void* host_bytes) {
+    if (!c->cache_verify) return true;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->verify_host.resize(e->bytes);
+    ++c->verify_checked;
+    bool same = hipMemcpy(c->verify_host.data(), e->buf.p, e->bytes, hipMemcpyDeviceToHost) == hipSuccess &&
+                memcmp(c->verify_host.data(), host_bytes, e->bytes) == 0;
+    if (!same) {
+        ++c->verify_mismatch;
+        --c->res_hits;
+        ++c->res_misses;
+        res_drop(c, e);
+    }
+    return same;
 }
 
 // a fresh entry of `bytes` at the front of the list (not yet valid), or nullptr when nothing may be evicted / allocated: the
@@ -173,8 +204,7 @@ zk_ctx::ResEntry* res_new(zk_ctx* c, size_t bytes) {
         }
         if (!found) return nullptr;
         c->res_bytes -= it->bytes;
-        if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
-        else it->buf.release();
+        res_recycle(c, it->buf);
         c->res.erase(it);
     }
     DevBuf buf;
@@ -203,8 +233,7 @@ void res_drop(zk_ctx* c, zk_ctx::ResEntry* e) {        // an entry whose product
     for (auto it = c->res.begin(); it != c->res.end(); ++it)
         if (&*it == e) {
             c->res_bytes -= it->bytes;
-            if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
-            else it->buf.release();
+            res_recycle(c, it->buf);
             c->res.erase(it);
             return;
         }
@@ -215,14 +244,35 @@ void res_fail_call(zk_ctx* c) {
     for (auto it = c->res.begin(); it != c->res.end();) {
         if (it->epoch == c->res_epoch) {
             c->res_bytes -= it->bytes;
-            if (c->res_free.size() < 8) c->res_free.push_back(it->buf);
-            else it->buf.release();
+            res_recycle(c, it->buf);
             it = c->res.erase(it);
         } else {
             ++it;
         }
     }
 }
+
+// Every host-pointer call that consults the cache runs inside one of these.  An exit that was not marked ok() -- a failed allocation,
+// a failed copy, a failed kernel launch, at ANY point of the call -- waits for both streams (uploads may still be in flight on the copy
+// stream) and drops every entry the call touched or created: their digests may name bytes that never arrived (an early
+// `return rc` used to leave such entries valid, and a retry with the same polynomials then committed over garbage).
+struct ResCall {
+    zk_ctx* c;
+    bool active, good = false;
+    explicit ResCall(zk_ctx* ctx) : c(ctx), active(ctx->res_on) {
+        if (active) res_begin_call(c);
+    }
+    int done(int rc) {
+        good = rc == ZK_OK;
+        return rc;
+    }
+    ~ResCall() {
+        if (!active || good) return;
+        (void)hipStreamSynchronize(c->stream);
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        res_fail_call(c);
+    }
+};
 
 void res_clear(zk_ctx* c) {
     for (auto& e : c->res) e.buf.release();
@@ -256,7 +306,9 @@ void res_resolve(zk_ctx* c, uint32_t n, const void* const* h_ptrs, const size_t*
     host_digest256_multi(c->pool.get(), hp, hb, m, RES_SEED, dig);
     for (uint32_t j = 0; j < m; ++j) {
         const uint32_t k = idx[j];
-        if (zk_ctx::ResEntry* e = res_find(c, hb[j], dig[j])) {
+        zk_ctx::ResEntry* e = res_find(c, hb[j], dig[j]);
+        if (e && !res_verify_hit(c, e, hp[j])) e = nullptr;
+        if (e) {
             out[k].d_ptr = e->buf.p;
             out[k].upload = false;
         } else if (zk_ctx::ResEntry* f = res_new(c, hb[j])) {
@@ -312,7 +364,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
         c->tune.host_workers = hc > 16 ? 15 : hc > 1 ? (int)hc - 1 : 0;     // + the calling thread; option "host_workers" resizes it
         c->pool.reset(new HostPool((unsigned)c->tune.host_workers));
     }
-    zk_process_key(c->digest_key);
+    c->key_from_os = zk_process_key(c->digest_key);
     c->digest_key[0] ^= (uint64_t)(uintptr_t)c * 0x9E3779B97F4A7C15ull;      // caches are per ctx: so are their keys
     for (int i = 0; i < 16 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_job[i], hipEventDisableTiming);
     (void)hipSetDevice(prev);
@@ -407,6 +459,11 @@ int zk_ctx_set_option(zk_ctx* c, const char* key, int64_t value) {
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
     int64_t lo = 0, hi = 0;
+    if (strcmp(key, "cache_verify") == 0) {
+        if (value < 0 || value > 1) return ZK_ERR_BAD_ARG;
+        c->cache_verify = value != 0;
+        return ZK_OK;
+    }
     if (strcmp(key, "host_workers") == 0) {
         if (value < 0 || value > 63) return ZK_ERR_BAD_ARG;
         c->pool.reset(new HostPool((unsigned)value));      // joins the old workers first (no batch is running: the ctx lock is held)
@@ -432,6 +489,10 @@ int zk_ctx_get_option(zk_ctx* c, const char* key, int64_t* value) {
         *value = c->tune.host_workers;
         return ZK_OK;
     }
+    if (strcmp(key, "cache_verify") == 0) {
+        *value = c->cache_verify ? 1 : 0;
+        return ZK_OK;
+    }
     int* f = tune_field(c, key, &lo, &hi);
     if (!f) return ZK_ERR_UNSUPPORTED;
     *value = *f;
@@ -442,6 +503,7 @@ int zk_ctx_set_residency_cache(zk_ctx* c, int enable, size_t capacity_bytes, siz
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
+    if (enable && !c->key_from_os) return ZK_ERR_UNSUPPORTED;     // as zk_ctx_set_commit_cache
     ZK_HIP_TRY(hipStreamSynchronize(c->stream));
     if (capacity_bytes) c->res_cap = capacity_bytes;
     if (max_vector_bytes) c->res_max_vec = max_vector_bytes;
@@ -457,6 +519,14 @@ int zk_residency_cache_stats(zk_ctx* c, uint64_t* hits, uint64_t* misses, uint64
     if (misses) *misses = c->res_misses;
     if (entries) *entries = c->res.size();
     if (bytes) *bytes = c->res_bytes;
+    return ZK_OK;
+}
+
+int zk_cache_verify_stats(zk_ctx* c, uint64_t* checked, uint64_t* mismatches) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    Guard g(c);
+    if (checked) *checked = c->verify_checked;
+    if (mismatches) *mismatches = c->verify_mismatch;
     return ZK_OK;
 }
 
@@ -547,16 +617,18 @@ int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in
     const void* d_in = nullptr;
     bool need_upload = in_len != 0;
     zk_ctx::ResEntry* out_entry = nullptr;
+    ResCall rcall(c);
     if (c->res_on) {
-        res_begin_call(c);
         if (!inverse && res_wants(c, in_len * 32)) {
             const void* hp = in;
             const size_t hb = in_len * 32;
             uint64_t dig[1][4];
             host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
             if (zk_ctx::ResEntry* e = res_find(c, hb, dig[0])) {
-                d_in = e->buf.p;
-                need_upload = false;
+                if (res_verify_hit(c, e, in)) {
+                    d_in = e->buf.p;
+                    need_upload = false;
+                }
             }
         }
         if (inverse && res_wants(c, n * 32)) out_entry = res_new(c, n * 32);
@@ -570,31 +642,20 @@ int zk_ntt(zk_ctx* c, int curve_id, int kind, uint32_t log_n, const uint64_t* in
         if ((rc = c->io_b.ensure(n * 32))) return rc;
         d_out = c->io_b.p;
     }
-    if (need_upload && (rc = zk_h2d(c, const_cast<void*>(d_in), in, in_len * 32, c->stream))) {
-        if (c->res_on) res_fail_call(c);
-        return rc;
-    }
+    if (need_upload && (rc = zk_h2d(c, const_cast<void*>(d_in), in, in_len * 32, c->stream))) return rc;
     rc = ntt_run_dev(c, curve_id, kind, log_n, d_in, in_len, d_out);
     if (!rc) rc = zk_d2h(c, out, d_out, n * 32, c->stream);
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    if (rc && c->res_on) {
-        (void)hipStreamSynchronize(c->stream);
-        res_fail_call(c);
-        out_entry = nullptr;
-    }
+    if (rc) return rc;                 // ~ResCall drops out_entry with everything else this call touched
     if (out_entry) {
-        if (rc) {
-            res_drop(c, out_entry);
-        } else {
-            const void* hp = out;
-            const size_t hb = n * 32;
-            uint64_t dig[1][4];
-            host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
-            memcpy(out_entry->dig, dig[0], 32);
-            out_entry->valid = true;
-        }
+        const void* hp = out;
+        const size_t hb = n * 32;
+        uint64_t dig[1][4];
+        host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
+        memcpy(out_entry->dig, dig[0], 32);
+        out_entry->valid = true;
     }
-    return rc;
+    return rcall.done(ZK_OK);
 }
 
 int zk_ntt_batch(zk_ctx* c, int curve_id, int kind, uint32_t log_n, uint32_t n_polys, const uint64_t* const* ins, const size_t* in_lens,
@@ -704,6 +765,7 @@ static int srs_register_host(zk_ctx* c, int curve_id, const uint64_t* bases_xy, 
     const size_t bytes = n * 2 * L * 8;
     uint64_t dig[4] = {0, 0, 0, 0};
     std::unique_lock<std::mutex> reg(g_srs_mu, std::defer_lock);
+    if (!c->key_from_os) use_cache = false;      // no OS entropy behind the digest key: every registration builds its own copy
     if (use_cache) {
         host_digest256(bases_xy, bytes, 0x5125ull ^ ((uint64_t)curve_id << 32) ^ (uint64_t)n, dig);
         if (inf_flags) {
@@ -986,6 +1048,9 @@ static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
     uint8_t miss_kind[16];
     uint32_t miss_job[16], n_miss = 0;
     int alias[16];     // job k repeats miss alias[k] of this very call
+    bool was_hit[16] = {false};      // option "cache_verify": a hit is computed all the same and compared below
+    uint64_t hit_xy[16 * 12];
+    uint8_t hit_inf[16];
     for (uint32_t k = 0; k < n_jobs; ++k) {
         const uint32_t kind = kinds && kinds[k] ? 1u : 0u;
         alias[k] = -1;
@@ -1001,6 +1066,15 @@ static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
         }
         if (hit) {
             ++c->cache_hits;
+            if (!c->cache_verify) continue;
+            was_hit[k] = true;
+            memcpy(hit_xy + (size_t)k * 12, out_xy + (size_t)k * 2 * L, sizeof(uint64_t) * 2 * L);
+            hit_inf[k] = c->commit_cache.front().inf;
+            miss_in[n_miss] = d_inputs[k];
+            miss_len[n_miss] = lens[k];
+            miss_kind[n_miss] = (uint8_t)kind;
+            miss_job[n_miss] = k;
+            ++n_miss;
             continue;
         }
         for (uint32_t m = 0; m < n_miss && alias[k] < 0; ++m) {
@@ -1026,6 +1100,18 @@ static int batch_cached_locked(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const void
             const uint32_t k = miss_job[m];
             memcpy(out_xy + (size_t)k * 2 * L, m_xy + (size_t)m * 2 * L, sizeof(uint64_t) * 2 * L);
             if (out_inf) out_inf[k] = m_inf[m];
+            if (was_hit[k]) {          // cache_verify: the entry exists; what it held against what was just computed
+                ++c->verify_checked;
+                if (hit_inf[k] != m_inf[m] || (!m_inf[m] && memcmp(hit_xy + (size_t)k * 12, m_xy + (size_t)m * 2 * L, sizeof(uint64_t) * 2 * L))) {
+                    ++c->verify_mismatch;
+                    for (auto& ce : c->commit_cache)
+                        if (ce.srs_id == s->id && ce.n == lens[k] && ce.kind == miss_kind[m] && !memcmp(ce.dig, dig + 4 * k, 32)) {
+                            memcpy(ce.xy, m_xy + (size_t)m * 2 * L, sizeof(uint64_t) * 2 * L);
+                            ce.inf = m_inf[m];
+                        }
+                }
+                continue;
+            }
             zk_ctx::CommitEntry e;
             memset(&e, 0, sizeof e);
             e.srs_id = s->id;
@@ -1050,6 +1136,7 @@ int zk_ctx_set_commit_cache(zk_ctx* c, int enable, uint32_t capacity) {
     if (!c) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (round_open(c)) return ZK_ERR_PENDING;
+    if (enable && !c->key_from_os) return ZK_ERR_UNSUPPORTED;     // the digests that would address it have no OS entropy behind their key
     c->commit_cache_on = enable != 0;
     if (capacity) c->commit_cache_cap = capacity;
     if (!enable) c->commit_cache.clear();
@@ -1528,7 +1615,7 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
     // job at the resident copy instead -- d_in[k] is read when job k is queued, after up(k) has run.
     const void* d_in[16];
     bool cached[16] = {false};
-    if (c->res_on) res_begin_call(c);
+    ResCall rcall(c);
     for (uint32_t k = 0; k < n_polys; ++k) {
         if (lens[k] > s->n) return ZK_ERR_BAD_ARG;
         cached[k] = res_wants(c, lens[k] * 32);
@@ -1543,8 +1630,10 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
             uint64_t dig[1][4];
             host_digest256_multi(c->pool.get(), &hp, &hb, 1, RES_SEED, dig);
             if (zk_ctx::ResEntry* e = res_find(c, hb, dig[0])) {
-                d_in[k] = e->buf.p;                    // resident: nothing crosses PCIe, nothing to wait for
-                return ZK_OK;
+                if (res_verify_hit(c, e, coeffs_mont[k])) {
+                    d_in[k] = e->buf.p;                // resident: nothing crosses PCIe, nothing to wait for
+                    return ZK_OK;
+                }
             }
             if (zk_ctx::ResEntry* f = res_new(c, hb)) {
                 memcpy(f->dig, dig[0], 32);
@@ -1561,14 +1650,9 @@ int zk_kzg_commit_batch(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* 
     if (c->commit_cache_on) {   // the digests need every input on the device first
         for (uint32_t k = 0; k < n_polys; ++k)
             if ((rc = up(k))) return rc;
-        return batch_cached_locked(c, s, n_polys, d_in, lens, nullptr, out_xy, out_inf);
+        return rcall.done(batch_cached_locked(c, s, n_polys, d_in, lens, nullptr, out_xy, out_inf));
     }
-    rc = batch_locked(c, s, n_polys, d_in, lens, nullptr, nullptr, out_xy, out_inf, &up);
-    if (rc && c->res_on) {
-        (void)hipStreamSynchronize(c->stream);
-        res_fail_call(c);
-    }
-    return rc;
+    return rcall.done(batch_locked(c, s, n_polys, d_in, lens, nullptr, nullptr, out_xy, out_inf, &up));
 }
 
 int zk_kzg_commit(zk_ctx* c, zk_srs* s, const uint64_t* coeffs_mont, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
@@ -1605,8 +1689,8 @@ int zk_kzg_open(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* p
     ResInput ri[16];
     for (uint32_t k = 0; k < n_polys; ++k)
         if (lens[k] && !polys_mont[k]) return ZK_ERR_BAD_ARG;
+    ResCall rcall(c);
     if (c->res_on) {      // the eleven / seven polynomials of an opening were all transformed or committed before (prover.rs:582-618)
-        res_begin_call(c);
         const void* hp[16];
         size_t hb[16];
         for (uint32_t k = 0; k < n_polys; ++k) {
@@ -1623,17 +1707,9 @@ int zk_kzg_open(zk_ctx* c, zk_srs* s, uint32_t n_polys, const uint64_t* const* p
             if ((rc = c->mb[k].upload.ensure((lens[k] ? lens[k] : 1) * 32))) return rc;
             d_in[k] = c->mb[k].upload.p;
         }
-        if (ri[k].upload && (rc = zk_h2d(c, const_cast<void*>(d_in[k]), polys_mont[k], lens[k] * 32, c->stream))) {
-            if (c->res_on) res_fail_call(c);
-            return rc;
-        }
+        if (ri[k].upload && (rc = zk_h2d(c, const_cast<void*>(d_in[k]), polys_mont[k], lens[k] * 32, c->stream))) return rc;
     }
-    const int rc2 = zk_kzg_open_dev(c, s, n_polys, d_in, lens, z_mont, challenge_mont, out_xy, out_inf);
-    if (rc2 && c->res_on) {
-        (void)hipStreamSynchronize(c->stream);
-        res_fail_call(c);
-    }
-    return rc2;
+    return rcall.done(zk_kzg_open_dev(c, s, n_polys, d_in, lens, z_mont, challenge_mont, out_xy, out_inf));
 }
 
 int zk_kzg_witness_dev(zk_ctx* c, int curve_id, uint32_t n_polys, const void* const* d_polys, const size_t* lens, const uint64_t* z_mont,

@@ -336,6 +336,12 @@ struct zk_ctx {
     std::list<ResEntry> res;         // most recently used first
     std::vector<DevBuf> res_free;    // buffers of evicted entries, reused before anything is allocated
     uint64_t res_epoch = 0, res_hits = 0, res_misses = 0;
+    // option "cache_verify": every hit of the commitment / residency cache is checked against the real thing (the MSM recomputed, the
+    // resident bytes compared with the caller's); a mismatch is counted and the computed / uploaded value used (zk_cache_verify_stats)
+    bool cache_verify = false;
+    bool key_from_os = false;          // zk_process_key delivered OS entropy when the ctx was created: the caches may be switched on
+    uint64_t verify_checked = 0, verify_mismatch = 0;
+    std::vector<unsigned char> verify_host;
 
     // open round (zk_kzg_round_begin_dev / zk_kzg_open_begin_dev ... zk_kzg_round_end): jobs whose sort + accumulate are queued
     // on the stream and whose reduction waits for the round to close, in submission order.  Job k lives in buffer set mb[k].
@@ -498,5 +504,6 @@ void host_digest256_multi(HostPool* pool, const void* const* ptrs, const size_t*
 // 256-bit multiset digests of n_jobs device vectors of 32-byte elements -> d_out[job][4] (async on st)
 // keyed with `key` (the ctx's digest_key): see hostio.hip
 int dev_digest256(const void* const* d_ptrs, const size_t* lens, uint32_t n_jobs, uint64_t* d_out, hipStream_t st, const uint64_t key[4]);
-// 256 random bits per process (operating-system entropy), the key of every cache digest
-void zk_process_key(uint64_t out[4]);
+// 256 random bits per process (operating-system entropy), the key of every cache digest; false: the OS gave none (hostio.hip)
+bool zk_process_key(uint64_t out[4]);
+void zk_process_key_reset_for_tests(const char* path);

@@ -10,6 +10,7 @@
 //                and sent by DMA while the next slot is being filled: 49 GB/s there, kept for hosts where mode 0 is slow.
 // Pinned or hipHostRegister-ed caller buffers are detected and always sent directly.
 #include "ctx.h"
+#include <sys/random.h>
 
 #include <chrono>
 #include <cstdio>
@@ -77,12 +78,30 @@ ZK_HD uint64_t fmix64(uint64_t x) {
     return x;
 }
 
-// one block: four xxhash-style lanes over 32-byte stripes, cross-mixed at the end so that every output word depends
-// on every input byte.  The lanes start from the 256-bit process key (zk_process_key): the digests address caches, and a
-// fixed, public mixing function would let a client who picks the cached bytes search for two inputs with one digest offline.
+// one block: four xxhash-style lanes over 32-byte stripes.  Lane k reads word k of every stripe, so the lanes are folded into each
+// other every eighth stripe (and twice more at the end): a difference confined to one 64-bit column of the vector -- small field
+// elements in canonical form differ in their low limb only -- reaches all 256 bits of state within 256 bytes instead of being carried
+// by one lane's 64 bits to the final mix.  The lanes start from the 256-bit process key (zk_process_key): the digests
+// address caches, and a fixed, public mixing function would let a client who picks the cached bytes search for two inputs with one
+// digest offline.
 void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, const uint64_t key[4], uint64_t out[4]) {
     uint64_t a[4] = {key[0] ^ (seed + P1 + P2), key[1] ^ (seed + P2), key[2] ^ seed, key[3] ^ (seed - P1)};
+    auto fold = [&a]() {
+        const uint64_t t0 = a[0], t1 = a[1], t2 = a[2], t3 = a[3];
+        a[0] = t0 + (rotl64(t1, 13) ^ rotl64(t2, 29) ^ rotl64(t3, 47));
+        a[1] = t1 + (rotl64(t2, 13) ^ rotl64(t3, 29) ^ rotl64(t0, 47));
+        a[2] = t2 + (rotl64(t3, 13) ^ rotl64(t0, 29) ^ rotl64(t1, 47));
+        a[3] = t3 + (rotl64(t0, 13) ^ rotl64(t1, 29) ^ rotl64(t2, 47));
+    };
     size_t i = 0;
+    for (; i + 256 <= bytes; i += 256) {
+        for (size_t j = 0; j < 256; j += 32) {
+            uint64_t w[4];
+            memcpy(w, p + i + j, 32);
+            for (int k = 0; k < 4; ++k) a[k] = rotl64(a[k] + w[k] * P2, 31) * P1;
+        }
+        fold();
+    }
     for (; i + 32 <= bytes; i += 32) {
         uint64_t w[4];
         memcpy(w, p + i, 32);
@@ -93,6 +112,7 @@ void block_digest(const uint8_t* p, size_t bytes, uint64_t seed, const uint64_t 
         memcpy(w, p + i, bytes - i);
         for (int k = 0; k < 4; ++k) a[k] = rotl64(a[k] + w[k] * P2, 31) * P1;
     }
+    fold();
     const uint64_t len = (uint64_t)bytes;
     for (int r = 0; r < 2; ++r)
         for (int k = 0; k < 4; ++k) a[k] = fmix64(a[k] ^ rotl64(a[(k + 1) & 3], 17) ^ (a[(k + 2) & 3] * P3) ^ (len + P5 * (uint64_t)(k + 1)));
@@ -133,23 +153,44 @@ __global__ void __launch_bounds__(256) digest_kernel(DigJobs jobs, uint64_t* out
 
 }  // namespace
 
-// 256 bits drawn once per process from the operating system (getrandom / /dev/urandom).  Digests are only ever compared inside
-// the process that computed them, so the key never leaves it.
-void zk_process_key(uint64_t out[4]) {
-    static uint64_t key[4];
-    static std::once_flag once;
-    std::call_once(once, [] {
+// 256 bits drawn once per process from the operating system (getrandom, else /dev/urandom).  Digests are only ever compared inside
+// the process that computed them, so the key never leaves it.  Returns whether the operating system delivered: without it the key
+// falls back to address-space layout + clock -- digests still work as checksums of this process, but the caches whose hits REPLACE a
+// computation (commitment cache, residency cache, SRS registry) refuse to switch on (ZK_ERR_UNSUPPORTED / no sharing).
+static std::mutex g_key_mu;
+static bool g_key_done = false, g_key_ok = false;
+static uint64_t g_key[4];
+static std::string g_entropy_path = "/dev/urandom";
+static bool g_use_getrandom = true;
+
+bool zk_process_key(uint64_t out[4]) {
+    std::lock_guard<std::mutex> lk(g_key_mu);
+    if (!g_key_done) {
         bool ok = false;
-        if (FILE* f = fopen("/dev/urandom", "rb")) {
-            ok = fread(key, 1, sizeof key, f) == sizeof key;
-            fclose(f);
+        if (g_use_getrandom) ok = getrandom(g_key, sizeof g_key, 0) == (ssize_t)sizeof g_key;
+        if (!ok) {
+            if (FILE* f = fopen(g_entropy_path.c_str(), "rb")) {
+                ok = fread(g_key, 1, sizeof g_key, f) == sizeof g_key;
+                fclose(f);
+            }
         }
-        if (!ok) {      // no entropy source: address-space layout + clock (still unknown to a remote client, but weaker)
-            uint64_t x = (uint64_t)(uintptr_t)&key ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
-            for (int k = 0; k < 4; ++k) key[k] = x = fmix64(x + P1 * (uint64_t)(k + 1));
+        if (!ok) {
+            uint64_t x = (uint64_t)(uintptr_t)&g_key ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+            for (int k = 0; k < 4; ++k) g_key[k] = x = fmix64(x + P1 * (uint64_t)(k + 1));
         }
-    });
-    memcpy(out, key, sizeof key);
+        g_key_ok = ok;
+        g_key_done = true;
+    }
+    memcpy(out, g_key, sizeof g_key);
+    return g_key_ok;
+}
+
+// test hook (tests/sanitize/host_stress.cpp; not part of the C ABI): draw the key again, from `path` only
+void zk_process_key_reset_for_tests(const char* path) {
+    std::lock_guard<std::mutex> lk(g_key_mu);
+    g_key_done = false;
+    g_use_getrandom = path == nullptr;
+    g_entropy_path = path ? path : "/dev/urandom";
 }
 
 void host_digest256(const void* p, size_t bytes, uint64_t seed, uint64_t out[4]) {

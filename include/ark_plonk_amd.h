@@ -100,6 +100,9 @@ int zk_ctx_set_staging(zk_ctx* ctx, int mode);
  *                         the early close described at zk_kzg_round_begin_dev can be exercised at small sizes
  *   "host_workers"        helper threads of the ctx's host pool (window-sum combine, affine normalisation, digests): default
  *                         min(15, hardware threads - 1); a launcher with several ranks per host passes cores / LOCAL_WORLD_SIZE - 1
+ *   "cache_verify"        0 (default) | 1: every hit of the commitment cache is recomputed and every hit of the residency cache compared
+ *                         byte for byte with the caller's vector before it is believed; mismatches are counted (zk_cache_verify_stats)
+ *                         and the computed / uploaded value is used.  A diagnostic mode: it costs what the caches save
  * ZK_ERR_UNSUPPORTED: unknown key; ZK_ERR_BAD_ARG: value out of range; ZK_ERR_PENDING: a deferred round is open (a job's plan must
  * not change between its accumulation and its reduction).  The library reads NO environment variable on a compute path
  * (ZK_VERBOSE and ZK_HOST_TIMING switch diagnostics on stderr only). */
@@ -110,15 +113,20 @@ int zk_ctx_set_staging(zk_ctx* ctx, int mode);
  * most max_vector_bytes (named by a keyed 256-bit digest of the bytes the caller receives) and zk_ntt / zk_kzg_commit_batch / zk_kzg_open
  * digest every input of at most that size on the ctx's host pool and use the resident copy on a match; a miss uploads into a fresh
  * entry, so a second use of any vector hits too (the prover key's sigma polynomials, proof after proof).  A digest runs at ~190 GB/s
- * against PCIe's 56, so a hit costs a third of an upload and a miss a third more (profiles/r05_notes.md).  Results are identical by
- * construction: a hit is taken on equality of (length, digest) of the caller's CURRENT bytes -- the trust model of zk_srs_register's
- * registry.  capacity_bytes = device memory the entries may hold (0 = leave unchanged; default 2 GiB, least recently used evicted;
+ * against PCIe's 56, so a hit costs a third of an upload and a miss a third more (profiles/r05_notes.md).  WHAT IS GUARANTEED: results
+ * are identical to the uncached calls UNLESS two different vectors of one length collide under the keyed 256-bit non-cryptographic
+ * digest (per-process key from the operating system) -- a hit is taken on equality of (length, digest) of the caller's CURRENT bytes,
+ * the contents are not compared: the trust model of zk_srs_register's registry below.  Option "cache_verify" = 1 compares them (and
+ * recomputes every commitment-cache hit) and counts mismatches: zk_cache_verify_stats.  Without operating-system entropy behind the
+ * key (getrandom and /dev/urandom both unavailable) enabling either cache returns ZK_ERR_UNSUPPORTED.  capacity_bytes = device memory the entries may hold (0 = leave unchanged; default 2 GiB, least recently used evicted;
  * entries of the running call are never evicted); max_vector_bytes: 0 = leave unchanged (default 64 MiB: at n = 2^20 the n-sized
  * vectors are cached, the 4n-sized coset evaluations -- consumed by host code, never sent back -- are not).  enable = 0 drops every entry. */
 int zk_ctx_set_residency_cache(zk_ctx* ctx, int enable, size_t capacity_bytes, size_t max_vector_bytes);
 int zk_residency_cache_stats(zk_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* entries, uint64_t* bytes);
 int zk_ctx_set_option(zk_ctx* ctx, const char* key, int64_t value);
 int zk_ctx_get_option(zk_ctx* ctx, const char* key, int64_t* value);
+/* hits checked under option "cache_verify" and how many of them did not hold (either pointer may be NULL) */
+int zk_cache_verify_stats(zk_ctx* ctx, uint64_t* checked, uint64_t* mismatches);
 
 /* Per-kernel HIP-event timing (bench.py roofline leg). on = 1: every launch of the hot kernels is bracketed by
  * hipEventRecord on the ctx stream (≈ 200 scopes, ≈ 2 ms per 2^20 proof); on = 2: only the dominant kernel, msm_accumulate
@@ -183,11 +191,13 @@ int zk_msm_g1(zk_ctx* ctx, int curve_id, const uint64_t* bases_xy, const uint8_t
  * 32 GiB) is exceeded, least recently used first.  zk_srs_register_dev (bases already on the device; d_inf_flags may
  * be NULL) is never cached.
  *
- * Trust model of the content-addressed caches (this one and zk_ctx_set_commit_cache): a hit is accepted on equality of a
- * 256-bit digest, without comparing contents.  The digests are KEYED with 256 bits drawn from the operating system once per
- * process (the commitment cache mixes in a per-ctx value); they are never exported, so a client that chooses the cached bytes
- * cannot search for two inputs with one digest offline.  The mixing functions are fast non-cryptographic ones (xxhash-style
- * lanes; a sum of per-element keyed mixes on the device): a collision would return another SRS handle / another polynomial's
+ * Trust model of the content-addressed caches (this one, zk_ctx_set_commit_cache, zk_ctx_set_residency_cache): a hit is accepted
+ * on equality of a 256-bit digest, without comparing contents -- results are identical to the uncached call unless two inputs collide
+ * under that digest.  The digests are KEYED with 256 bits drawn from the operating system once per process (the commitment cache
+ * mixes in a per-ctx value); they are never exported, so a client that chooses the cached bytes cannot search for two inputs with
+ * one digest offline; without operating-system entropy the registry shares nothing and the two ctx caches refuse to switch on.  The
+ * mixing functions are fast NON-CRYPTOGRAPHIC ones (four xxhash-style lanes folded into each other every 256 bytes; a sum of
+ * per-element keyed mixes on the device): a collision would return another SRS handle / another polynomial's
  * commitment -- an invalid proof that the verifier rejects, never an unsound one.  A service that must not even produce an
  * invalid proof for adversarial witnesses leaves the commitment cache off (the default) and registers its SRS from one
  * trusted source. */
@@ -265,8 +275,9 @@ int zk_kzg_commit_batch(zk_ctx* ctx, zk_srs* srs, uint32_t n_polys, const uint64
  * w_r, w_4, h_1, z_2).  With the cache on, every zk_kzg_commit* / zk_kzg_*_batch* call that returns affine points
  * first computes a 256-bit digest of each coefficient vector on the device and serves (srs, input kind, length,
  * digest) hits from the cache: an unchanged Prover::prove runs 17 MSMs per proof instead of 29 (20 on the first: the
- * prover key's sigma commitments then stay cached across proofs), outputs identical.  capacity = entries kept
- * (0 = leave unchanged; default 64, least recently used dropped). */
+ * prover key's sigma commitments then stay cached across proofs); outputs identical unless two coefficient vectors collide under the
+ * keyed digest (trust model: at zk_srs_register above; option "cache_verify").  capacity = entries kept (0 = leave unchanged; default
+ * 64, least recently used dropped).  ZK_ERR_UNSUPPORTED: no operating-system entropy behind the digest key. */
 int zk_ctx_set_commit_cache(zk_ctx* ctx, int enable, uint32_t capacity);
 int zk_commit_cache_stats(zk_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* entries);
 

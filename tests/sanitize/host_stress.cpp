@@ -23,6 +23,7 @@ extern "C" long fake_hip_launches();
 extern "C" long fake_hip_live_allocations();
 extern "C" void fake_hip_set_memory(size_t budget, size_t report_extra);
 extern "C" size_t fake_hip_live_bytes();
+void zk_process_key_reset_for_tests(const char* path);      // csrc/hostio.hip: test hook, not part of the C ABI
 
 #define REQUIRE(cond)                                                              \
     do {                                                                           \
@@ -321,6 +322,58 @@ int main() {
         REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
         for (int k = 0; k < 4; ++k) REQUIRE(zk_dev_free(c, d[k]) == ZK_OK);
         zk_ctx_destroy(c);
+    }
+
+    // ---- 2c. the caches' error paths and guarantees (round 6)
+    {
+        zk_ctx* c = nullptr;
+        REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
+        const uint64_t* hp[4] = {polys[0].data(), polys[1].data(), polys[2].data(), polys[3].data()};
+        size_t hl[4] = {n, n, n - 1, 64};
+        uint64_t xy[16 * 12], z[4] = {5, 0, 0, 0}, ch[4] = {7, 0, 0, 0};
+        uint8_t inf[16];
+        uint64_t h0 = 0, m0 = 0, e0 = 0, b0 = 0, h1 = 0, m1 = 0, e1 = 0, b1 = 0;
+        REQUIRE(zk_ctx_set_residency_cache(c, 1, 0, 0) == ZK_OK);
+        REQUIRE(zk_kzg_commit_batch(c, srs, 2, hp, hl, xy, inf) == ZK_OK);                 // two vectors resident
+        REQUIRE(zk_residency_cache_stats(c, &h0, &m0, &e0, &b0) == ZK_OK && e0 == 2);
+        // a call that fails AFTER it has created entries (a staging buffer of a later polynomial finds no memory): the entries it made or
+        // touched are gone -- their digests would name bytes that never arrived -- and the same call succeeds once memory is back
+        fake_hip_set_memory(fake_hip_live_bytes() + 4096, 0);
+        REQUIRE(zk_kzg_open(c, srs, 4, hp, hl, z, ch, xy, inf) == ZK_ERR_OOM);
+        REQUIRE(zk_residency_cache_stats(c, &h1, &m1, &e1, &b1) == ZK_OK && e1 <= e0 && b1 <= b0);
+        REQUIRE(zk_ctx_set_commit_cache(c, 1, 8) == ZK_OK);
+        zk_ctx* cfresh = nullptr;                                                       // no staging buffers yet: its first upload fails
+        REQUIRE(zk_ctx_create(0, &cfresh) == ZK_OK);
+        REQUIRE(zk_ctx_set_residency_cache(cfresh, 1, 0, 0) == ZK_OK && zk_ctx_set_commit_cache(cfresh, 1, 8) == ZK_OK);
+        REQUIRE(zk_kzg_commit_batch(cfresh, srs, 4, hp, hl, xy, inf) == ZK_ERR_OOM);
+        REQUIRE(zk_residency_cache_stats(cfresh, nullptr, nullptr, &e1, &b1) == ZK_OK && e1 == 0 && b1 == 0);
+        fake_hip_set_memory(0, 0);
+        REQUIRE(zk_kzg_commit_batch(cfresh, srs, 4, hp, hl, xy, inf) == ZK_OK && inf[0] && inf[3]);
+        REQUIRE(zk_kzg_open(c, srs, 4, hp, hl, z, ch, xy, inf) == ZK_OK);
+        zk_ctx_destroy(cfresh);
+        // cache_verify: every hit is checked against the real thing; nothing may be found wrong
+        uint64_t checked = 0, wrong = 9;
+        REQUIRE(zk_ctx_set_option(c, "cache_verify", 1) == ZK_OK);
+        REQUIRE(zk_kzg_commit_batch(c, srs, 4, hp, hl, xy, inf) == ZK_OK);
+        REQUIRE(zk_kzg_commit_batch(c, srs, 4, hp, hl, xy, inf) == ZK_OK);
+        REQUIRE(zk_kzg_open(c, srs, 3, hp, hl, z, ch, xy, inf) == ZK_OK);
+        REQUIRE(zk_cache_verify_stats(c, &checked, &wrong) == ZK_OK && checked >= 6 && wrong == 0);
+        REQUIRE(zk_ctx_set_option(c, "cache_verify", 0) == ZK_OK && zk_ctx_set_option(c, "cache_verify", 2) == ZK_ERR_BAD_ARG);
+        zk_ctx_destroy(c);
+        // no operating-system entropy behind the digest key: the caches whose hits replace a computation refuse to switch on, and the
+        // SRS registry shares nothing
+        zk_process_key_reset_for_tests("/nonexistent/entropy");
+        REQUIRE(zk_ctx_create(0, &c) == ZK_OK);
+        REQUIRE(zk_ctx_set_commit_cache(c, 1, 8) == ZK_ERR_UNSUPPORTED && zk_ctx_set_residency_cache(c, 1, 0, 0) == ZK_ERR_UNSUPPORTED);
+        REQUIRE(zk_ctx_set_commit_cache(c, 0, 0) == ZK_OK && zk_ctx_set_residency_cache(c, 0, 0, 0) == ZK_OK);
+        zk_srs *s1 = nullptr, *s2 = nullptr;
+        REQUIRE(zk_srs_register(c, CURVE, srs_a.data(), nullptr, n, &s1) == ZK_OK && zk_srs_register(c, CURVE, srs_a.data(), nullptr, n, &s2) == ZK_OK);
+        REQUIRE(s1 != s2 && s1 != srs);
+        REQUIRE(zk_kzg_commit_batch(c, s1, 2, hp, hl, xy, inf) == ZK_OK);
+        zk_srs_free(s1);
+        zk_srs_free(s2);
+        zk_ctx_destroy(c);
+        zk_process_key_reset_for_tests(nullptr);
     }
 
     // ---- 3. eviction: drop every unreferenced entry, then the last references

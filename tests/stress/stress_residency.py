@@ -19,12 +19,18 @@ from ark_plonk_amd import _lib  # noqa: E402
 from oracle import cpu  # noqa: E402
 
 
-def run(budget: float = 60.0, seed: int = 5, ctx=None, max_log_n: int = 15):
+def run(budget: float = 60.0, seed: int = 5, ctx=None, max_log_n: int = 15, verify: bool = False):
+    """verify=True: the same session with option "cache_verify" on (and the commitment cache too): every hit is compared with the
+    caller's bytes / recomputed before it is believed; not one may be found wrong."""
     cpu.build()
     own = ctx is None
     if own:
         ctx = zk.Context(0)
     plain = zk.Context(ctx.device)                       # the same calls without the cache
+    v0 = ctx.cache_verify_stats()
+    if verify:
+        ctx.set_option("cache_verify", 1)
+        ctx.set_commit_cache(True)
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     calls = hits0 = 0
@@ -125,13 +131,20 @@ def run(budget: float = 60.0, seed: int = 5, ctx=None, max_log_n: int = 15):
             rounds += 1
     finally:
         ctx.set_residency_cache(False)
+        v1 = ctx.cache_verify_stats()
+        if verify:
+            ctx.set_commit_cache(False)
+            ctx.set_option("cache_verify", 0)
         plain.close()
         if own:
             ctx.close()
+    if verify:
+        assert v1["checked"] - v0["checked"] > 0 and v1["mismatches"] == v0["mismatches"], (v0, v1)
+        print(f"cache_verify: {v1['checked'] - v0['checked']} hits checked against the caller's bytes / a recomputation, 0 mismatches", flush=True)
     print(f"stress ok: {rounds} rounds, {calls} host-pointer calls / caller rewrites with the residency cache on ({hits0} hits) equal to the same "
           f"calls without it and to the CPU restatement (seed {seed}, {budget:.0f} s)", flush=True)
     return calls
 
 
 if __name__ == "__main__":
-    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(os.environ.get("SEED", "5")))
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(os.environ.get("SEED", "5")), verify=os.environ.get("VERIFY", "0") == "1")

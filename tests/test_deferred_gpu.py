@@ -273,7 +273,7 @@ def test_ctx_options_api(ctx):
     for key in ctx.OPTIONS:
         old = ctx.get_option(key)
         assert old == {"msm_merge": 1, "pre_logg": -1, "long_rounds": 1, "mem_reserve_mb": 1024,
-                       "host_workers": min(15, max(0, (os.cpu_count() or 1) - 1))}.get(key, 0)
+                       "host_workers": min(15, max(0, (os.cpu_count() or 1) - 1))}.get(key, 0), key
     assert L.zk_ctx_set_option(ctx.handle, b"no_such_key", 1) == _lib.ZK_ERR_UNSUPPORTED
     v = ctypes.c_int64()
     assert L.zk_ctx_get_option(ctx.handle, b"no_such_key", ctypes.byref(v)) == _lib.ZK_ERR_UNSUPPORTED

@@ -43,3 +43,9 @@ def test_stress_shards_short(ctx, oracle_cpu):
 
 def test_stress_residency_short(ctx, oracle_cpu):
     assert _load("stress_residency").run(budget=15.0, seed=70, ctx=ctx, max_log_n=13) >= 20
+
+
+def test_stress_residency_with_cache_verify(ctx, oracle_cpu):
+    """the same randomised session with option "cache_verify": every hit of the residency and commitment caches is checked against the
+    caller's bytes / a recomputation (include/ark_plonk_amd.h: what the caches guarantee) -- no mismatch"""
+    assert _load("stress_residency").run(budget=10.0, seed=71, ctx=ctx, max_log_n=13, verify=True) >= 10

@@ -125,10 +125,6 @@ SYMBOLS = {
     "zk_kzg_round_end": (c_int, [c_void_p, c_u32, c_void_p, c_void_p]),
     "zk_kzg_round_end_partial": (c_int, [c_void_p, c_u32, c_void_p]),
     "zk_kzg_round_pending": (c_int, [c_void_p, ctypes.POINTER(c_u32)]),
-    "zk_partial_dev_bytes": (c_size_t, [c_int]),
-    "zk_kzg_round_reduce_partial_dev": (c_int, [c_void_p, c_void_p]),
-    "zk_kzg_round_end_partial_dev": (c_int, [c_void_p, c_u32, c_void_p]),
-    "zk_g1_sum_partials_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_u32, c_void_p, c_void_p]),
     "zk_winsums_dev_bytes": (c_size_t, [c_void_p, c_void_p]),
     "zk_winsums_geometry": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_u32)]),
     "zk_kzg_round_reduce_winsums_dev": (c_int, [c_void_p, c_void_p]),

@@ -1,8 +1,8 @@
 """Build the gfx950 shared library (hipcc, in-tree).  `python -m ark_plonk_amd.build [--force]`.
 
-The heavy kernels are compiled as separate objects -- one per (curve, NTT radix exponent) and one MSM
-object per curve -- so a full build parallelises over the host cores and an edit rebuilds only what
-it touches.
+The heavy kernels are compiled as separate objects -- one per (curve, NTT radix exponent) and four MSM
+units per curve (sort / accumulate / reduce / host plan: csrc/msm_common.cuh) -- so a full build
+parallelises over the host cores and an edit rebuilds only what it touches.
 """
 from __future__ import annotations
 
@@ -23,6 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 FIELD_HDRS = ["field.cuh", "fieldu.cuh", "fields.cuh", "curve_params.h", "zk_common.h"]
 HOST_HDRS = FIELD_HDRS + ["ec.cuh", "ecu.cuh", "ctx.h", "../../include/ark_plonk_amd.h"]
+MSM_UNITS = ("msm_accumulate", "msm_reduce", "msm_sort", "msm_plan")      # heaviest first
 
 
 def jobs():
@@ -42,8 +43,9 @@ def jobs():
     ]
     for c in (0, 1):
         # ARK_PLONK_AMD_MSM_FLAGS: extra compiler flags for the MSM objects only (scheduler experiments: tools/ab_bench.sh)
-        out.append((f"msm_c{c}.o", "msm.hip", [f"-DZK_CURVE_SEL={c}"] + os.environ.get("ARK_PLONK_AMD_MSM_FLAGS", "").split(),
-                    HOST_HDRS + ["ecq.cuh"]))
+        for unit in MSM_UNITS:
+            out.append((f"{unit}_c{c}.o", f"{unit}.hip", [f"-DZK_CURVE_SEL={c}"] + os.environ.get("ARK_PLONK_AMD_MSM_FLAGS", "").split(),
+                        HOST_HDRS + ["msm_common.cuh"] + (["ecq.cuh"] if unit == "msm_reduce" else [])))
         for s in range(3, 10):
             out.append((f"ntt_pass_c{c}_s{s}.o", "ntt_pass_inst.hip", [f"-DZK_CURVE_SEL={c}", f"-DZK_NTT_S={s}"],
                         FIELD_HDRS + ["ntt_pass.cuh"]))
@@ -68,7 +70,7 @@ def build(force: bool = False, verbose: bool = False, workers: int | None = None
         if force or _stale(o, deps):
             todo.append([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", o])
     # heaviest first (large S, MSM) so the tail of the build is short
-    todo.sort(key=lambda c: (0 if "msm.hip" in " ".join(c) else 1, -int(next((d.split("=")[1] for d in c if d.startswith("-DZK_NTT_S=")), 0))))
+    todo.sort(key=lambda c: (0 if "/msm_" in " ".join(c[-3:]) else 1, -int(next((d.split("=")[1] for d in c if d.startswith("-DZK_NTT_S=")), 0))))
 
     def run(cmd):
         if verbose:

@@ -174,6 +174,7 @@ void res_drop(zk_ctx* c, zk_ctx::ResEntry* e);
 // blocking download); a mismatch -- two vectors under one keyed digest, or a bug -- is counted, the entry dropped, the call uploads
 bool res_verify_hit(zk_ctx* c, zk_ctx::ResEntry* e, const void* host_bytes) {
     if (!c->cache_verify) return true;
+    if (e->born == c->res_epoch) return true;       // created by this very call (the same vector twice in one batch): its upload has not been queued yet
     (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     c->verify_host.resize(e->bytes);
@@ -224,6 +225,7 @@ zk_ctx::ResEntry* res_new(zk_ctx* c, size_t bytes) {
     e.bytes = bytes;
     e.buf = buf;
     e.epoch = c->res_epoch;
+    e.born = c->res_epoch;
     e.valid = false;
     c->res_bytes += bytes;
     return &e;
@@ -1205,7 +1207,6 @@ static void round_clear(zk_ctx* c) {
     c->pend_srs = nullptr;
     c->pend_reduced = false;
     c->pend_partials = nullptr;
-    c->pend_partial_kind = 0;
     c->round_reduced = 0;
 }
 
@@ -1349,7 +1350,7 @@ static int round_end_locked(zk_ctx* c, uint32_t n_expected, uint64_t* out_xyz, u
     const uint32_t n = c->pend_n;
     zk_srs* s = c->pend_srs;
     if (n != n_expected) return ZK_ERR_BAD_ARG;          // the round stays open
-    if (c->pend_partials) return ZK_ERR_PENDING;         // reduced towards the device (zk_kzg_round_reduce_partial_dev): close it with _end_partial_dev
+    if (c->pend_partials) return ZK_ERR_PENDING;         // reduced towards the device (zk_kzg_round_reduce_winsums_dev): close it with _end_winsums_dev
     if (n == 0) return ZK_OK;
     const int L = fq_limbs64(s->curve);
     uint32_t slots[16], nq = 0;
@@ -1417,13 +1418,12 @@ int zk_kzg_round_reduce(zk_ctx* c) {
     return ZK_OK;
 }
 
-// ---- the same round closed with its partials left ON THE DEVICE (multi-GPU exchange without a host hop)
-// Two forms.  kind 1: ONE point per job (zk_partial_dev_bytes) -- a further dependent quad launch forms sum_v S_v + B_v sum_v v T_v.
-// kind 2: the job's 2 VW virtual-window sums S_v | T_v as the last reduction kernel writes them (zk_winsums_dev_bytes: 32 KiB per job
-// at the default geometry) -- that combination is linear in them, so the ranks add them element-wise after the all-gather
+// ---- the same round closed with its result left ON THE DEVICE (multi-GPU exchange without a host hop): every job's 2 VW
+// virtual-window sums S_v | T_v as the last reduction kernel writes them (zk_winsums_dev_bytes: 32 KiB per job at the default geometry).
+// The combination sum_v S_v + B_v sum_v v T_v is linear in them, so the ranks add them element-wise after the all-gather
 // (zk_g1_sum_winsums_dev: one throughput-shaped kernel) and the one combine per job stays on the host pool, as on a single GPU.
-size_t zk_partial_dev_bytes(int curve_id) { return msm_partial_dev_bytes(curve_id); }
-
+// (Round 4's other device form -- ONE point per job, formed by a further dependent quad launch -- measured last of the three
+// exchanges on one card and was retired in round 6: profiles/design_history_msm.md.)
 size_t zk_winsums_dev_bytes(zk_ctx* c, zk_srs* s) {
     if (!c || !s) return 0;
     Guard g(c);
@@ -1446,10 +1446,10 @@ int zk_winsums_geometry(zk_ctx* c, zk_srs* s, uint32_t out[4]) {
     return ZK_OK;
 }
 
-// ctx lock held: queues everything up to every job's partial at d_out + k * (bytes of the form), k = submission order.
-// Whatever makes the device forms impossible is found BEFORE anything is queued, so that ZK_ERR_UNSUPPORTED really leaves the
+// ctx lock held: queues everything up to every job's window sums at d_out + k * zk_winsums_dev_bytes, k = submission order.
+// Whatever makes the device form impossible is found BEFORE anything is queued, so that ZK_ERR_UNSUPPORTED really leaves the
 // round as it was (the accumulation used to have run, with the long-chunk plan, when a c >= 18 table was refused).
-static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out, int kind) {
+static int round_reduce_winsums_dev_locked(zk_ctx* c, void* d_out) {
     zk_srs* s = c->pend_srs;
     const size_t pb = msm_partial_dev_bytes(s->curve);
     if (pb > PINNED_JOB_SLOT) return ZK_ERR_UNSUPPORTED;
@@ -1464,13 +1464,11 @@ static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out, int kind) {
     }
     SrsRead rl(s->mu);
     uint32_t vw = 0, vb = 0;
-    const bool geom = msm_partial_dev_supported(c, s, &vw, &vb);
-    const size_t jb = kind == 2 ? (size_t)2 * vw * pb : pb;                 // bytes per job in d_out
-    if (kind == 2 && !geom) return ZK_ERR_UNSUPPORTED;                      // without a table there are no virtual windows to speak of
+    if (!msm_partial_dev_supported(c, s, &vw, &vb)) return ZK_ERR_UNSUPPORTED;   // no table, or one whose reduction finishes on the host (c >= 18)
+    const size_t jb = (size_t)2 * vw * pb;                                  // bytes per job in d_out
     for (uint32_t k = 0; k < c->pend_n; ++k) {
         const zk_ctx::PendingJob& pj = c->pend[k];
         if (!pj.queued) continue;
-        if (!geom) return ZK_ERR_UNSUPPORTED;                               // tables with window_bits >= 18 finish on the host
         slots[nq] = k;
         qlens[nq] = pj.n;
         outs[nq] = (char*)d_out + (size_t)k * jb;
@@ -1478,59 +1476,44 @@ static int round_reduce_partial_dev_locked(zk_ctx* c, void* d_out, int kind) {
     }
     int rc;
     if (n_host && (rc = ensure_pinned_jobs(c))) return rc;
-    if (nq && (rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens, outs, kind))) return rc;
-    // jobs computed at submission (vectors too short for the table path): their host Jacobian, converted, goes up in one small copy
-    // each from a pinned slot of its own (truly asynchronous; the slot is reused by the next round of this ctx only, which begins
-    // after this one was waited for).  As window sums such a job is S_0 = the point, every other sum the point at infinity.
+    if (nq && (rc = msm_batch_pre_reduce_dev(c, s, nq, slots, qlens, outs))) return rc;
+    // jobs computed at submission (vectors too short for the table path) or parked by the memory budget: their host Jacobian, converted,
+    // goes up in one small copy each from a pinned slot of its own (truly asynchronous; the slot is reused by the next round of this ctx
+    // only, which begins after this one was waited for).  As window sums such a job is S_0 = the point, every other sum the point at infinity.
     for (uint32_t k = 0; k < c->pend_n; ++k) {
         const zk_ctx::PendingJob& pj = c->pend[k];
         if (pj.queued) continue;
         unsigned char* slot = (unsigned char*)c->pinned_jobs + (size_t)k * PINNED_JOB_SLOT;
         if ((rc = g1_jacobian_to_partial_host(s->curve, pj.xyz, slot))) return rc;
         char* dst = (char*)d_out + (size_t)k * jb;
-        if (kind == 2) ZK_HIP_TRY(hipMemsetAsync(dst, 0, jb, c->stream));
+        ZK_HIP_TRY(hipMemsetAsync(dst, 0, jb, c->stream));
         ZK_HIP_TRY(hipMemcpyAsync(dst, slot, pb, hipMemcpyHostToDevice, c->stream));
     }
     c->pend_reduced = true;
     c->pend_partials = d_out;
-    c->pend_partial_kind = kind;
     return ZK_OK;
 }
 
-static int round_reduce_dev_form(zk_ctx* c, void* d_out, int kind) {
+int zk_kzg_round_reduce_winsums_dev(zk_ctx* c, void* d_out) {
     if (!c || !d_out) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (c->pend_n == 0) return ZK_OK;
-    if (c->pend_reduced) return (c->pend_partials == d_out && c->pend_partial_kind == kind) ? ZK_OK : ZK_ERR_PENDING;
-    return round_reduce_partial_dev_locked(c, d_out, kind);
+    if (c->pend_reduced) return c->pend_partials == d_out ? ZK_OK : ZK_ERR_PENDING;
+    return round_reduce_winsums_dev_locked(c, d_out);
 }
 
-static int round_end_dev_form(zk_ctx* c, uint32_t n_jobs, void* d_out, int kind) {
+int zk_kzg_round_end_winsums_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) {
     if (!c || (n_jobs && !d_out)) return ZK_ERR_BAD_ARG;
     Guard g(c);
     if (c->pend_n != n_jobs) return ZK_ERR_BAD_ARG;           // the round stays open
     if (n_jobs == 0) return ZK_OK;
     int rc = ZK_OK;
-    if (!c->pend_reduced) rc = round_reduce_partial_dev_locked(c, d_out, kind);
-    else if (c->pend_partials != d_out || c->pend_partial_kind != kind) rc = ZK_ERR_PENDING;    // reduced towards the host or another buffer / form
+    if (!c->pend_reduced) rc = round_reduce_winsums_dev_locked(c, d_out);
+    else if (c->pend_partials != d_out) rc = ZK_ERR_PENDING;    // reduced towards the host or another buffer
     if (rc == ZK_ERR_PENDING || rc == ZK_ERR_UNSUPPORTED) return rc;   // nothing was queued by this call: the round stays open for the host form
     if (rc) (void)hipStreamSynchronize(c->stream);          // as round_end_locked: kernels of the round may still read the inputs
     round_clear(c);
     return rc;
-}
-
-int zk_kzg_round_reduce_partial_dev(zk_ctx* c, void* d_out) { return round_reduce_dev_form(c, d_out, 1); }
-int zk_kzg_round_end_partial_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) { return round_end_dev_form(c, n_jobs, d_out, 1); }
-int zk_kzg_round_reduce_winsums_dev(zk_ctx* c, void* d_out) { return round_reduce_dev_form(c, d_out, 2); }
-int zk_kzg_round_end_winsums_dev(zk_ctx* c, uint32_t n_jobs, void* d_out) { return round_end_dev_form(c, n_jobs, d_out, 2); }
-
-int zk_g1_sum_partials_dev(zk_ctx* c, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
-    if (n_jobs == 0) return ZK_OK;
-    if (!c || !d_partials || !out_xy || ranks == 0) return ZK_ERR_BAD_ARG;
-    if (curve_id != ZK_CURVE_BLS12_381 && curve_id != ZK_CURVE_BN254) return ZK_ERR_BAD_ARG;
-    Guard g(c);
-    if (round_open(c)) return ZK_ERR_PENDING;               // the pinned buffer belongs to the open round
-    return g1_sum_partials_dev(c, curve_id, d_partials, ranks, n_jobs, out_xy, out_inf);
 }
 
 int zk_g1_sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {

@@ -329,6 +329,7 @@ struct zk_ctx {
         uint64_t dig[4] = {0, 0, 0, 0};
         bool valid = false;          // dig names the buffer's contents (false while an output is still being produced)
         uint64_t epoch = 0;          // the call that last used it: entries of the running call are never evicted
+        uint64_t born = 0;           // the call that created it: until that call returns its bytes may still be on their way up
         DevBuf buf;
     };
     bool res_on = false;
@@ -355,8 +356,7 @@ struct zk_ctx {
     };
     uint32_t pend_n = 0;
     bool pend_reduced = false;      // zk_kzg_round_reduce ran: the round takes no further jobs, zk_kzg_round_end only waits
-    void* pend_partials = nullptr;  // ... as zk_kzg_round_reduce_partial_dev: the jobs' partials are (being) written there, on the device
-    int pend_partial_kind = 0;      // 1: one point per job (zk_partial_dev_bytes); 2: the job's virtual-window sums (zk_winsums_dev_bytes)
+    void* pend_partials = nullptr;  // ... as zk_kzg_round_reduce_winsums_dev: the jobs' virtual-window sums are (being) written there, on the device
     void* pinned_jobs = nullptr;    // 16 x 512 B pinned: partials of jobs computed at submission, on their way to the device (async copies)
     hipEvent_t round_ev = nullptr;  // recorded behind the reduction kernels of a round (msm_batch_pre_reduce)
     uint32_t round_reduced = 0;     // jobs whose reductions are queued behind round_ev (0: none)
@@ -443,17 +443,14 @@ int msm_batch_pre_dev(zk_ctx* c, zk_srs* s, uint32_t n_polys, const void* const*
 // jobs in slots[0 .. n_jobs) with one launch per reduction kernel, wait once, combine on the host
 int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens,
                             const uint8_t* kinds = nullptr, const std::function<int(uint32_t)>* before_job = nullptr);
-// d_partials + partial_kind 1: every job's sum as ONE point at d_partials[k]; 2: the job's 2 VW virtual-window sums there (msm_winsums_dev_bytes)
-int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials = nullptr,
-                             int partial_kind = 1);
+// d_winsums (optional, n_jobs pointers): the job's 2 VW virtual-window sums are left there, on the device (zk_winsums_dev_bytes each)
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_winsums = nullptr);
 // whether (and in which geometry) the device-resident forms of the exchange exist for this SRS's table: vw = virtual windows, vb = buckets
 // of each; false for tables the reduction finishes on the host side only (window_bits >= 18) or without a table
 bool msm_partial_dev_supported(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb);
-// multi-GPU exchange on the device: a partial = one point in the internal XYZZ form
+// multi-GPU exchange on the device: bytes of one point in the internal XYZZ form; the 2 VW virtual-window sums of a job (S_v | T_v) are
+// added element-wise over the ranks and combined on the host pool as the single-GPU path combines them
 size_t msm_partial_dev_bytes(int curve);
-int g1_sum_partials_dev(zk_ctx* c, int curve, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
-// ... or the 2 VW virtual-window sums of a job (S_v | T_v), added element-wise over the ranks, combined on the host pool as the
-// single-GPU path combines them
 int g1_sum_winsums_dev(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
 int g1_jacobian_to_partial_host(int curve, const uint64_t* xyz, void* out);
 int msm_batch_pre_end_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz,

@@ -1,4 +1,4 @@
-// Curve dispatch for the per-curve MSM objects (msm.hip built with -DZK_CURVE_SEL=0/1).
+// Curve dispatch for the per-curve MSM objects (the msm_* units built with -DZK_CURVE_SEL=0/1: msm_common.cuh).
 #include "ctx.h"
 
 #define DECLS(sfx)                                                                                                    \
@@ -14,12 +14,10 @@
                                const uint8_t* kinds, uint64_t* out_xy, uint8_t* out_inf, const std::function<int(uint32_t)>* before_job); \
     int msm_batch_pre_begin_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_polys, const void* const* d_coeffs, const size_t* lens, \
                                      const uint8_t* kinds, const std::function<int(uint32_t)>* before_job);                \
-    int msm_batch_pre_reduce_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials, \
-                                      int partial_kind);                                                               \
+    int msm_batch_pre_reduce_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_winsums); \
     bool msm_partial_dev_supported##sfx(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb);                             \
     int g1_sum_winsums_dev##sfx(zk_ctx* c, zk_srs* s, const void* d_all, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf); \
     size_t msm_partial_dev_bytes##sfx();                                                                               \
-    int g1_sum_partials_dev##sfx(zk_ctx* c, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf); \
     void g1_jacobian_to_partial_host##sfx(const uint64_t* xyz, void* out);                                             \
     int msm_batch_pre_end_dev##sfx(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, uint64_t* out_xyz, \
                                    uint64_t* out_xy, uint8_t* out_inf);
@@ -78,10 +76,9 @@ int msm_batch_pre_begin_dev(zk_ctx* c, zk_srs* s, uint32_t slot0, uint32_t n_pol
     if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_begin_dev_c1(c, s, slot0, n_polys, d_coeffs, lens, kinds, before_job);
     return ZK_ERR_BAD_ARG;
 }
-int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_partials,
-                             int partial_kind) {
-    if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_reduce_dev_c0(c, s, n_jobs, slots, lens, d_partials, partial_kind);
-    if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_reduce_dev_c1(c, s, n_jobs, slots, lens, d_partials, partial_kind);
+int msm_batch_pre_reduce_dev(zk_ctx* c, zk_srs* s, uint32_t n_jobs, const uint32_t* slots, const size_t* lens, void* const* d_winsums) {
+    if (s->curve == ZK_CURVE_BLS12_381) return msm_batch_pre_reduce_dev_c0(c, s, n_jobs, slots, lens, d_winsums);
+    if (s->curve == ZK_CURVE_BN254) return msm_batch_pre_reduce_dev_c1(c, s, n_jobs, slots, lens, d_winsums);
     return ZK_ERR_BAD_ARG;
 }
 bool msm_partial_dev_supported(zk_ctx* c, zk_srs* s, uint32_t* vw, uint32_t* vb) {
@@ -98,11 +95,6 @@ size_t msm_partial_dev_bytes(int curve) {
     if (curve == ZK_CURVE_BLS12_381) return msm_partial_dev_bytes_c0();
     if (curve == ZK_CURVE_BN254) return msm_partial_dev_bytes_c1();
     return 0;
-}
-int g1_sum_partials_dev(zk_ctx* c, int curve, const void* d_parts, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf) {
-    if (curve == ZK_CURVE_BLS12_381) return g1_sum_partials_dev_c0(c, d_parts, ranks, n_jobs, out_xy, out_inf);
-    if (curve == ZK_CURVE_BN254) return g1_sum_partials_dev_c1(c, d_parts, ranks, n_jobs, out_xy, out_inf);
-    return ZK_ERR_BAD_ARG;
 }
 int g1_jacobian_to_partial_host(int curve, const uint64_t* xyz, void* out) {
     if (curve == ZK_CURVE_BLS12_381) g1_jacobian_to_partial_host_c0(xyz, out);

@@ -293,35 +293,6 @@ class CommitterKey:
         check(lib().zk_kzg_round_end_partial(self.ctx.handle, k, ptr_of(out)), "zk_kzg_round_end_partial")
         return out[:k]
 
-    def partial_dev_words(self) -> int:
-        """int64 words of one device-side partial (zk_partial_dev_bytes / 8)."""
-        return lib().zk_partial_dev_bytes(self.curve.curve_id) // 8
-
-    def round_reduce_partial_dev(self, d_out):
-        """`round_reduce` for the device form of the exchange: the jobs' partials are written (by the last reduction kernel) into the
-        device tensor `d_out` (jobs x partial_dev_words int64), typically the collective's send buffer."""
-        self.ctx.use_torch_stream()
-        check(lib().zk_kzg_round_reduce_partial_dev(self.ctx.handle, d_out.data_ptr()), "zk_kzg_round_reduce_partial_dev")
-
-    def round_end_partial_dev(self, d_out, n_jobs: int | None = None):
-        """Close the round leaving every job's partial ON THE DEVICE in `d_out` (no host wait): see the header."""
-        k = self.round_pending() if n_jobs is None else n_jobs
-        if d_out.numel() < k * self.partial_dev_words():
-            raise ValueError("partial buffer too small")
-        self.ctx.use_torch_stream()
-        check(lib().zk_kzg_round_end_partial_dev(self.ctx.handle, k, d_out.data_ptr()), "zk_kzg_round_end_partial_dev")
-
-    def sum_partials_dev(self, d_all, ranks: int, n_jobs: int) -> list:
-        """All-gathered device partials (ranks x jobs x partial_dev_words, rank-major) -> one G1Affine per job: one kernel, one wait."""
-        L = self.curve.fq_limbs
-        out = np.zeros((max(n_jobs, 1), 2 * L), dtype=np.uint64)
-        inf = np.zeros(max(n_jobs, 1), dtype=np.uint8)
-        self.ctx.use_torch_stream()
-        check(lib().zk_g1_sum_partials_dev(self.ctx.handle, self.curve.curve_id, d_all.data_ptr(), ranks, n_jobs, ptr_of(out), ptr_of(inf)),
-              "zk_g1_sum_partials_dev")
-        return [_point(out[i], inf[i:i + 1], self.curve) for i in range(n_jobs)]
-
-    # -- the exchange one step earlier: a job's 2 VW virtual-window sums instead of their combination (see the header)
     def winsums_dev_words(self) -> int:
         """int64 words of one job's window sums (zk_winsums_dev_bytes / 8); 0 where the form does not exist (no table, c >= 18)."""
         return lib().zk_winsums_dev_bytes(self.ctx.handle, self._h) // 8

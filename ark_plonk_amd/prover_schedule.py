@@ -73,8 +73,7 @@ class ProofSchedule:
                  dist=None, seed: int = 0x5EED0000, dedup=False,
                  grand_products: bool = False, quotient: bool = False, fuse_round5: bool = False, data: str = "uniform",
                  ntt_batch: bool = True, linearisation: bool = False, lookup_round2: bool = False, defer_calls: bool = True,
-                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool | None = None, split_rounds: int = 0,
-                 exchange: str | None = None):
+                 hoist: bool = True, shard_axis: str = "points", partials_on_device: bool | None = None, exchange: str | None = None):
         import torch
         self.torch = torch
         self.cv = get_curve(curve)
@@ -103,18 +102,10 @@ class ProofSchedule:
         # host waits for them (zk_kzg_round_reduce): the sigma ffts (prover-key data, permutation/mod.rs:671-674) behind round 1, the
         # public-input and L_1 iffts (pi.rs:115, quotient_poly.rs:325) behind round 2, the twelve coset ffts of the quotient round
         # (quotient_poly.rs:72-120: wires, z, z_2, f, table, h_1, h_2 are all committed before alpha is drawn) behind round 3.  Same
-        # transforms, same sizes, same batches; they run while the host combines the window sums, normalises and hashes.
-        self.hoist = hoist
-        # hoist == "stream": the hoisted transforms go to a SECOND HIP stream (a second zk_ctx of the same GPU: a ctx drives one stream),
-        # so that they run WHILE the round's memory-bound sort passes and latency-bound reductions occupy the first one instead of
-        # behind them; joined before their results are used (`_join_side`).  Same transforms, same results.
-        self.side_stream = hoist == "stream" and world == 1
-        # split_rounds = m > 1 (an experiment, off by default; profiles/r04_notes.md): every m-th job of a round (jobs 0, m, 2m, ...) is
-        # queued on this ctx, the others on a second ctx of the same GPU driving a second stream, so that the short group's
-        # accumulation runs while the long group is still being sorted and its reductions while the long group accumulates.  Same
-        # calls, same SRS handle (CommitterKey.with_ctx), same points.
-        self.split_rounds = int(split_rounds) if (int(split_rounds) > 1 and world == 1 and defer_calls and not (self.dedup or self.dedup_abi)) else 0
-        self._order = []            # split_rounds: "a" | "b" per queued job of the open round, in call order
+        # transforms, same sizes, same batches; they run while the host combines the window sums, normalises and hashes.  (Putting them
+        # on a second stream, and dealing a round's jobs to two streams, were measured even or slower in round 4 and retired in round 6:
+        # profiles/design_history_msm.md.)
+        self.hoist = bool(hoist)
         self._pending = []          # per open call: ("q", n_jobs) queued in the ABI's round | ("r", [points]) already computed
         # z and z2 evaluation vectors built on the device from the wire / sigma /
         # lookup columns (permutation/mod.rs:652-822) instead of taken as synthetic inputs
@@ -142,16 +133,6 @@ class ProofSchedule:
         self.dom_n = Radix2EvaluationDomain.new(self.n, curve, ctx)
         self.dom_4n = Radix2EvaluationDomain.new(4 * self.n, curve, ctx)
         dev = torch.device("cuda", ctx.device)
-        self._side_done = []
-        if self.side_stream or self.split_rounds:
-            from .context import Context
-            self.ctx2 = Context(ctx.device)
-            self.side = torch.cuda.Stream(device=dev)
-        if self.split_rounds:
-            self.ck2 = ck.with_ctx(self.ctx2)
-        if self.side_stream:
-            self.dom_n2 = Radix2EvaluationDomain.new(self.n, curve, self.ctx2)
-            self.dom_4n2 = Radix2EvaluationDomain.new(4 * self.n, curve, self.ctx2)
         g = torch.Generator(device=dev).manual_seed(seed)
         n = self.n
 
@@ -229,21 +210,20 @@ class ProofSchedule:
         else:
             self.lo = rank * n // world
             self.hi = (rank + 1) * n // world
-        # The exchange of a sharded round (world > 1), three forms, same points:
+        # The exchange of a sharded round (world > 1), two forms, same points:
         #   "winsums"            every job's 2 VW virtual-window sums, written by the reduction kernel the single-GPU path ends with, straight
         #                        into the collective's send buffer; all-gathered (32 KiB per job); added element-wise by one kernel; ONE
         #                        host wait, the combine per job on the host pool (zk_kzg_round_end_winsums_dev / zk_g1_sum_winsums_dev)
-        #   "point"              round 4's device form: one more dependent quad launch forms every job's sum, 256 B per job gathered
-        #                        (zk_kzg_round_end_partial_dev / zk_g1_sum_partials_dev)
-        #   "host" (default)     round 3's: window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
-        # Default = the fastest on ONE card (profiles/r05_sim_rank.txt: "host" by 1-2 % over "winsums", "point" last); on a node the
-        # device forms save a host round trip before and after every collective -- bench.py times both there.  `partials_on_device=True`
-        # without `exchange` selects "winsums".
+        #   "host" (default)     window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
+        # Default = the faster on ONE card (profiles/r05_sim_rank.txt: "host" by 1-2 % over "winsums"); on a node the device form saves
+        # a host round trip before and after every collective -- bench.py times both there.  `partials_on_device=True` without
+        # `exchange` selects "winsums".  (A third form -- one point per job formed by a further dependent launch -- measured last on one
+        # card in round 5 and was retired in round 6: profiles/design_history_msm.md.)
         # The device forms need the deferred rounds, a table with c <= 17 and no commitment cache; otherwise "host" is used.
         if exchange is None:
             exchange = "winsums" if partials_on_device is True else "host"
-        if exchange not in ("winsums", "point", "host"):
-            raise ValueError("exchange: 'winsums', 'point' or 'host'")
+        if exchange not in ("winsums", "host"):
+            raise ValueError("exchange: 'winsums' or 'host'")
         geom = ck.winsums_geometry() if world > 1 else None
         device_form_ok = world > 1 and defer_calls and not (self.dedup or self.dedup_abi) and geom is not None
         if world > 1 and dist is not None and hasattr(dist, "all_gather_object"):
@@ -261,7 +241,7 @@ class ProofSchedule:
         self.exchange = exchange
         self.partials_on_device = exchange != "host"
         if self.partials_on_device:
-            self._pw = ck.winsums_dev_words() if exchange == "winsums" else ck.partial_dev_words()
+            self._pw = ck.winsums_dev_words()
             self._pbuf = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)       # partials of the library's pending jobs
             self._pfull = torch.zeros((16, self._pw), dtype=torch.int64, device=dev)      # ... with all-zero rows (infinity) for empty shards
         self.collectives = 0
@@ -287,11 +267,6 @@ class ProofSchedule:
             self._pending.append(("r", self._commit_now(polys, canonical, labels)))
             return
         self.msms_run += len(polys)
-        if self.split_rounds:
-            for p, kd in zip(polys, canonical or [False] * len(polys)):
-                self._on_group(lambda k, p=p, kd=kd: k.commit_begin([p], canonical=[kd]), tensors=[p])
-                self._pending.append(("q", 1))
-            return
         if self.world == 1:
             self.ck.commit_begin(polys, canonical=canonical)
         else:
@@ -314,81 +289,17 @@ class ProofSchedule:
             self._round_begin([w], canonical=[True], labels=[label])
             return
         self.msms_run += 1
-        if self.split_rounds:
-            self._on_group(lambda k: k.open_begin(polys, self.z_mont, self.chi_mont), tensors=list(polys))
-        else:
-            self.ck.open_begin(polys, self.z_mont, self.chi_mont)
+        self.ck.open_begin(polys, self.z_mont, self.chi_mont)
         self._pending.append(("q", 1))
-
-    def _on_group(self, fn, tensors=()):
-        """split_rounds: queue one job of the open round on this ctx (every m-th job) or on the second ctx / stream (the others; the
-        second stream first waits for what the main stream has queued so far -- the job's input).  `tensors`: the main-stream
-        tensors the job reads -- told to the caching allocator (record_stream) so that a block freed on the main stream is not handed
-        out again while the side stream still reads it."""
-        which = "a" if len(self._order) % self.split_rounds == 0 else "b"
-        self._order.append(which)
-        if which == "a":
-            fn(self.ck)
-            return
-        torch = self.torch
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
-        for t in tensors:
-            t.record_stream(self.side)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            fn(self.ck2)
 
     def _hoisting(self):
         return self.hoist and not self._immediate()
 
-    def _side(self, fn):
-        """Run `fn(dom_n, dom_4n)` (transforms) on the side stream, ordered after everything queued on the main stream so far."""
-        if not self.side_stream:
-            return fn(self.dom_n, self.dom_4n)
-        torch = self.torch
-        main = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            out = fn(self.dom_n2, self.dom_4n2)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        self._side_done.append(done)
-        # results allocated under the side stream are consumed on the main one: tell the caching allocator, or a block freed there
-        # could be handed back to side-stream work while main-stream kernels still read it (ADVICE r4)
-        stack = [out]
-        while stack:
-            o = stack.pop()
-            if isinstance(o, (list, tuple)):
-                stack.extend(o)
-            elif hasattr(o, "record_stream"):
-                o.record_stream(main)
-        return out
-
-    def _join_side(self):
-        """The main stream waits for everything the side stream was given."""
-        if self._side_done:
-            main = self.torch.cuda.current_stream()
-            for ev in self._side_done:
-                main.wait_event(ev)
-            self._side_done = []
-
     def _round_reduce(self):
         """Queue the open round's reductions now; what is launched until `_round_end` runs behind them, under the host's part."""
-        if self.split_rounds and self._order:
-            if "a" in self._order:
-                self.ck.round_reduce()
-            if "b" in self._order:
-                with self.torch.cuda.stream(self.side):
-                    self.ck2.round_reduce()
-            return
         if not self._immediate() and any(kind == "q" for kind, _ in self._pending):
             if self.world > 1 and self.exchange == "winsums":
                 self.ck.round_reduce_winsums_dev(self._pbuf)
-            elif self.world > 1 and self.exchange == "point":
-                self.ck.round_reduce_partial_dev(self._pbuf)
             else:
                 self.ck.round_reduce()
 
@@ -397,16 +308,7 @@ class ProofSchedule:
         pend, self._pending = self._pending, []
         nq = sum(n for kind, n in pend if kind == "q")
         got = []
-        if self.split_rounds and self._order:
-            order, self._order = self._order, []
-            ga = self.ck.round_end(order.count("a")) if "a" in order else []
-            gb = []
-            if "b" in order:
-                with self.torch.cuda.stream(self.side):
-                    gb = self.ck2.round_end(order.count("b"))
-            ia, ib = iter(ga), iter(gb)
-            got = [next(ia) if w == "a" else next(ib) for w in order]
-        elif self.world == 1:
+        if self.world == 1:
             if nq:
                 got = self.ck.round_end(nq)
         elif any(kind != "r" for kind, _ in pend) and self.partials_on_device:
@@ -439,13 +341,12 @@ class ProofSchedule:
         return self._all_gather_sum(full)
 
     def _gather_dev(self, nq, pend):
-        """Sharded round, device forms: the library leaves the queued jobs' partials (one point, or the 2 VW window sums) in `_pbuf`
-        (no host wait), ONE all-gather of the device tensor, one summing kernel.  Jobs whose shard is empty ("z") are all-zero rows
-        = the point at infinity (every window sum infinite)."""
+        """Sharded round, device form: the library leaves the queued jobs' 2 VW window sums in `_pbuf` (no host wait), ONE all-gather of
+        the device tensor, one summing kernel.  Jobs whose shard is empty ("z") are all-zero rows = the point at infinity (every window
+        sum infinite)."""
         jobs = [kind for kind, _ in pend if kind != "r"]
-        ws = self.exchange == "winsums"
         if nq:
-            (self.ck.round_end_winsums_dev if ws else self.ck.round_end_partial_dev)(self._pbuf, nq)
+            self.ck.round_end_winsums_dev(self._pbuf, nq)
         if nq == len(jobs):
             mine = self._pbuf[:nq]
         else:
@@ -456,7 +357,7 @@ class ProofSchedule:
             mine = self._pfull[:len(jobs)]
         allp = all_gather_partials_dev(self.dist, mine, self.world)
         self.collectives += 1
-        return (self.ck.sum_winsums_dev if ws else self.ck.sum_partials_dev)(allp, self.world, len(jobs))
+        return self.ck.sum_winsums_dev(allp, self.world, len(jobs))
 
     def _all_gather_sum(self, parts):
         self.collectives += 1
@@ -513,13 +414,11 @@ class ProofSchedule:
             return self._run_once(proof_id)
         except BaseException:
             self._pending = []
-            self._order = []
-            for k in [self.ck] + ([self.ck2] if self.split_rounds else []):
-                try:
-                    if k.round_pending():
-                        k.round_abort()
-                except Exception:
-                    pass
+            try:
+                if self.ck.round_pending():
+                    self.ck.round_abort()
+            except Exception:
+                pass
             raise
 
     def _run_once(self, proof_id=None):
@@ -541,7 +440,7 @@ class ProofSchedule:
         self._round_begin(c[:4], labels=["w_l", "w_r", "w_o", "w_4"])
         if hoist:
             self._round_reduce()
-            sig = self._side(lambda dn, d4n: dn.batch(0, self.sigma) if self.ntt_batch else [dn.fft(self.sigma[i]) for i in range(4)])     # of round 3
+            sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]     # of round 3
         out += self._round_end()
         # Round 2: table ifft, f ifft + commit, h1/h2 ifft + commits (prover.rs:240-242,281-291,302-317)
         t_ev, f_ev, h1_ev, h2_ev = self.aux_evals[0:4]
@@ -563,14 +462,13 @@ class ProofSchedule:
         self._round_begin([c[7]], labels=["h2"])
         if hoist:
             self._round_reduce()
-            c[10], c[11] = self._side(lambda dn, d4n: (dn.ifft(self.aux_evals[6]), dn.ifft(self.aux_evals[7])))     # pi (of round 3), l1 (of round 4)
+            c[10], c[11] = d.ifft(self.aux_evals[6]), d.ifft(self.aux_evals[7])     # pi (of round 3), l1 (of round 4)
         out += self._round_end()                              # f, h_1, h_2 enter the transcript before beta is drawn (prover.rs:320)
         # Round 3: sigma ffts, z ifft + commit, z2 ifft + commit, pi ifft (permutation/mod.rs:671-674,751,800; pi.rs:115)
         if sig is None:
             sig = d.batch(0, self.sigma) if self.ntt_batch else [d.fft(self.sigma[i]) for i in range(4)]
         z_evals, z2_evals = self.aux_evals[4], self.aux_evals[5]
         if self.grand_products:
-            self._join_side()                                 # the sigma evaluations feed the permutation product
             from . import permutation
             z_evals = permutation.permutation_evals(d, self.evals, sig, self.chi_mont, self.z_mont)       # beta, gamma
         c[8] = d.ifft(z_evals)                    # z
@@ -591,9 +489,8 @@ class ProofSchedule:
 
         if hoist:
             self._round_reduce()
-            self._side(quotient_coset_ffts)                   # of round 4: none of the twelve inputs depends on alpha
+            quotient_coset_ffts(d, d4)                        # of round 4: none of the twelve inputs depends on alpha
         out += self._round_end()                              # z, z_2 enter the transcript before alpha is drawn (prover.rs:398)
-        self._join_side()
         # Round 4: quotient (quotient_poly.rs:71-120,205,292-294,175-177)
         if not hoist:
             c[10] = d.ifft(self.aux_evals[6])         # pi

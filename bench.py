@@ -13,8 +13,7 @@ proofs are independent, so every rank runs the schedule K times with no data-pat
 "whole proofs: replicas only", scaling "weak").  The same run then times extra legs, never part of `value`:
 `msm_sharded` (this size) and `msm_sharded_n22` (BASELINE config 3, n = 2^22): one proof stream with every MSM
 sharded by points over the ranks and combined by ONE RCCL all-gather per group of PC calls (`--exchange`: the jobs' virtual-window
-sums, 32 KiB each, straight out of the last reduction kernel -- the default -- or one point per job, or host Jacobians; NTTs
-replicated).  `--mode shard` makes the sharded form the headline instead (scaling "strong").  Every N > 1 line carries `ranks`: the
+sums, 32 KiB each, straight out of the last reduction kernel, or host Jacobians -- the default; NTTs replicated).  `--mode shard` makes the sharded form the headline instead (scaling "strong").  Every N > 1 line carries `ranks`: the
 world, the backend, the (host, PCI address) of the card each rank drove, how many of those are distinct and an all-reduced sum of
 ones; with backend nccl the run refuses to start when ranks share a card.  `--rehearse` walks the N > 1 control flow without a GPU.
 
@@ -517,16 +516,14 @@ def parse_args():
                          "preferred axis); 'windows' = rank g holds the whole SRS and the table rows of the windows g, g + G, ... "
                          "(BASELINE.json north_star's wording; zk_srs_precompute_rows)")
     ap.add_argument("--drop-in-callers", type=int, default=4, help="drop_in leg: host threads calling the host-pointer entry points at once")
-    ap.add_argument("--exchange", default="host", choices=["winsums", "point", "host"],
-                    help="sharded MSMs, what the ranks all-gather per group of PC calls (default 'host': the fastest of the three on ONE card with a "
+    ap.add_argument("--exchange", default="host", choices=["winsums", "host"],
+                    help="sharded MSMs, what the ranks all-gather per group of PC calls (default 'host': the faster of the two on ONE card with a "
                          "stand-in collective, profiles/r05_sim_rank.txt -- by 1-2 %% over 'winsums', which removes a host round trip before and "
                          "after every collective that a one-card run cannot see; an N > 1 run times BOTH, legs msm_sharded and "
                          "msm_sharded_winsums): 'winsums' = every job's 2 VW virtual-window sums as "
                          "the last reduction kernel of the single-GPU path leaves them on the device (32 KiB per job), added element-wise by one "
                          "kernel, one host combine per job (zk_kzg_round_end_winsums_dev -> all_gather_into_tensor -> zk_g1_sum_winsums_dev); "
-                         "'point' = round 4's device form, one more dependent launch per group forms each job's sum (256 B per job; "
-                         "zk_kzg_round_end_partial_dev -> zk_g1_sum_partials_dev); 'host' = round 3's host Jacobian partials (D2H, host "
-                         "combine, H2D, all_gather, D2H)")
+                         "'host' = round 3's host Jacobian partials (D2H, host combine, H2D, all_gather, D2H)")
     ap.add_argument("--host-partials", action="store_true", help="= --exchange host")
     ap.add_argument("--dist-timeout", type=float, default=300.0,
                     help="N > 1: timeout (s) of the process group: a rank lost inside a collective takes the job down after this long instead of "
@@ -1355,7 +1352,6 @@ def main():
                 d = {"log_n": lg, "ms_per_proof": rs["dt"] / steps * 1e3, "proofs_per_s": steps / rs["dt"],
                      "collective": "all_gather of the jobs' partials, one per group of PC calls (5 per proof; 11 with --block-every-call): "
                                    + {"host": "3L-limb host Jacobian partials (--exchange host)",
-                                      "point": "one device-resident XYZZ point per job formed by a further reduction launch, summed by zk_g1_sum_partials_dev",
                                       "winsums": "the 2 VW virtual-window sums of every job (32 KiB) as the single-GPU path's last reduction kernel writes "
                                                  "them, added element-wise by zk_g1_sum_winsums_dev, combined per job on the host pool"}[rs["exchange"]],
                      "exchange": rs["exchange"], "collectives_per_proof": rs["collectives"] // max(steps + args.warmup + (1 if args.check else 0) + rs["kb"], 1),

@@ -253,16 +253,8 @@ class CommitterKey {
     void precompute_rows(uint32_t rank, uint32_t ranks, uint32_t window_bits = 0) {
         check(zk_srs_precompute_rows(ctx_->handle(), h_, window_bits, rank, ranks), "zk_srs_precompute_rows");
     }
-    size_t partial_bytes() const { return zk_partial_dev_bytes(curve_); }
-    // close the open round with every job's partial left on the device at d_out + k * partial_bytes() (no host wait): the send
-    // buffer of the all-gather
-    void round_end_partial_dev(void* d_out) const {
-        uint32_t k = 0;
-        check(zk_kzg_round_pending(ctx_->handle(), &k), "zk_kzg_round_pending");
-        check(zk_kzg_round_end_partial_dev(ctx_->handle(), k, d_out), "zk_kzg_round_end_partial_dev");
-    }
-    // the same exchange one step earlier (the default of the sharded schedule): every job's 2 VW virtual-window sums, winsums_bytes()
-    // per job, left where the single-GPU path's last reduction kernel writes them; all-gathered; added element-wise
+    // the exchange without a host hop: every job's 2 VW virtual-window sums, winsums_bytes() per job, left on the device where the
+    // single-GPU path's last reduction kernel writes them (the send buffer of the all-gather); all-gathered; added element-wise
     size_t winsums_bytes() const { return zk_winsums_dev_bytes(ctx_->handle(), h_); }
     void round_end_winsums_dev(void* d_out) const {
         uint32_t k = 0;
@@ -274,19 +266,6 @@ class CommitterKey {
         std::vector<uint64_t> xy((size_t)(jobs ? jobs : 1) * 2 * L);
         std::vector<uint8_t> inf(jobs ? jobs : 1);
         check(zk_g1_sum_winsums_dev(ctx_->handle(), h_, d_all, ranks, jobs, xy.data(), inf.data()), "zk_g1_sum_winsums_dev");
-        std::vector<G1Affine> out(jobs);
-        for (uint32_t i = 0; i < jobs; ++i) {
-            out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);
-            out[i].infinity = inf[i] != 0;
-        }
-        return out;
-    }
-    // ranks x jobs partials as the all-gather leaves them -> one affine point per job
-    std::vector<G1Affine> sum_partials_dev(const void* d_all, size_t ranks, uint32_t jobs) const {
-        const int L = fq_limbs(curve_);
-        std::vector<uint64_t> xy((size_t)(jobs ? jobs : 1) * 2 * L);
-        std::vector<uint8_t> inf(jobs ? jobs : 1);
-        check(zk_g1_sum_partials_dev(ctx_->handle(), curve_, d_all, ranks, jobs, xy.data(), inf.data()), "zk_g1_sum_partials_dev");
         std::vector<G1Affine> out(jobs);
         for (uint32_t i = 0; i < jobs; ++i) {
             out[i].xy.assign(xy.begin() + (size_t)i * 2 * L, xy.begin() + (size_t)(i + 1) * 2 * L);

@@ -61,19 +61,8 @@ int main(int argc, char** argv) {
         zk::DeviceVec d_under = dom.transform(ZK_NTT_FFT, d_coeffs);
         auto deferred = ck.round_end();
         std::printf("deferred_round %s\n", (deferred.size() == 2 && deferred[0].xy == single.xy && deferred[1].xy == single.xy) ? "ok" : "MISMATCH");
-        // the multi-GPU exchange's device form with one "rank": the round's partials stay on the device, one kernel sums them
-        {
-            void* d_parts = nullptr;
-            zk::check(zk_dev_alloc(ctx.handle(), 2 * ck.partial_bytes(), &d_parts), "zk_dev_alloc");
-            ck.commit_begin({&d_coeffs});
-            ck.commit_begin({&d_again});
-            ck.round_end_partial_dev(d_parts);
-            auto summed = ck.sum_partials_dev(d_parts, 1, 2);
-            zk::check(zk_dev_free(ctx.handle(), d_parts), "zk_dev_free");
-            std::printf("device_partials %s\n", (summed.size() == 2 && summed[0].xy == single.xy && summed[1].xy == single.xy) ? "ok" : "MISMATCH");
-        }
-        // ... and its default form: the jobs' virtual-window sums (2 VW points each) stay on the device, one kernel adds the ranks' element-wise,
-        // the host pool combines -- here with a planner option flipped in between (options never change a result)
+        // the multi-GPU exchange's device form with one "rank": the jobs' virtual-window sums (2 VW points each) stay on the device, one kernel
+        // adds the ranks' element-wise, the host pool combines -- here with a planner option flipped in between (options never change a result)
         {
             void* d_ws = nullptr;
             zk::check(zk_dev_alloc(ctx.handle(), 2 * ck.winsums_bytes(), &d_ws), "zk_dev_alloc");

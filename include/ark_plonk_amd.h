@@ -347,33 +347,28 @@ int zk_round_mem_stats(zk_ctx* ctx, uint64_t* early_closes, uint64_t* set_bytes,
  * consumed in stream order at the call, as before -- and zk_kzg_round_reduce / _end queue the rest for ALL jobs of the round as one
  * launch per kernel: the sort's placement passes, ONE accumulation launch (msm_accumulate_batch), the reductions.
  *
- * The multi-GPU exchange without a host hop (the reference is a single process): the round is closed with every job's
- * partial left ON THE DEVICE -- one point in the library's internal XYZZ limb form, zk_partial_dev_bytes(curve) bytes (256 for
- * BLS12-381), opaque; every rank runs this library -- at d_out + k * zk_partial_dev_bytes, k = submission order, written by the
- * last reduction kernel.  d_out is typically the send buffer of the collective (ncclAllGather / torch all_gather_into_tensor on
- * the same stream).  Neither call waits: d_out, the inputs and the SRS stay valid until the stream has passed this point
- * (zk_g1_sum_partials_dev waits for it).  zk_kzg_round_reduce_partial_dev is zk_kzg_round_reduce for this form (work queued
- * after it runs behind the reductions); zk_kzg_round_end_partial_dev closes the round (queues the reductions itself unless reduce
- * ran; d_out must then be the same buffer).  An all-zero partial is the point at infinity (a rank with an empty shard).
- * ZK_ERR_UNSUPPORTED (returned before anything is queued: the round stays open, close it with zk_kzg_round_end_partial): tables with
- * window_bits >= 18, the commitment cache.  zk_g1_sum_partials_dev: ranks x n_jobs partials as the all-gather leaves them (rank-major) -> n_jobs affine sums;
- * one kernel, one wait, the n_jobs inversions on the host. */
-size_t zk_partial_dev_bytes(int curve_id);
-int zk_kzg_round_reduce_partial_dev(zk_ctx* ctx, void* d_out);
-int zk_kzg_round_end_partial_dev(zk_ctx* ctx, uint32_t n_jobs, void* d_out);
-int zk_g1_sum_partials_dev(zk_ctx* ctx, int curve_id, const void* d_partials, size_t ranks, uint32_t n_jobs, uint64_t* out_xy, uint8_t* out_inf);
-/* The same exchange one step earlier (round 5; the default of the sharded schedule): a job's result is
+ * The multi-GPU exchange without a host hop (the reference is a single process).  A job's result is
  *   sum_v S_v + B_v * sum_v v * T_v
- * over the 2 VW virtual-window sums S_v | T_v its last reduction kernel writes (VW = 64 by default: 128 points, 32 KiB for BLS12-381),
- * and that expression is LINEAR in them.  zk_kzg_round_reduce_winsums_dev / zk_kzg_round_end_winsums_dev close the round with those
- * sums -- not their combination -- left on the device at d_out + k * zk_winsums_dev_bytes(ctx, srs), written by the reduction kernel
- * the single-GPU path ends with: no further dependent launch.  The ranks all-gather them and zk_g1_sum_winsums_dev adds the ranks'
- * sums element-wise (one kernel of n_jobs * 2 VW independent quads, ranks - 1 additions each), waits once, and leaves the one
- * combine + inversion per job to the ctx's host pool exactly as zk_kzg_round_end does.  Same results, same rules as the form above
- * (ZK_ERR_UNSUPPORTED before anything is queued: no table, window_bits >= 18, the commitment cache; the round then stays open).  Every
- * rank must run the same table window and the same "pre_vw" / "pre_logg" options: zk_winsums_geometry returns {window_bits, windows of
- * a full-width scalar, VW, buckets per virtual window} for the caller to compare across ranks once (the Python schedule all-gathers it
- * at construction and refuses a mismatch); zk_winsums_dev_bytes is 0 where the form does not exist. */
+ * over the 2 VW virtual-window sums S_v | T_v its last reduction kernel writes (VW = 64 by default: 128 points in the library's internal
+ * XYZZ limb form, opaque, 32 KiB for BLS12-381; every rank runs this library), and that expression is LINEAR in them.
+ * zk_kzg_round_reduce_winsums_dev / zk_kzg_round_end_winsums_dev close the round with those sums -- not their combination -- left ON THE
+ * DEVICE at d_out + k * zk_winsums_dev_bytes(ctx, srs), k = submission order, written by the reduction kernel the single-GPU path ends
+ * with: no further dependent launch.  d_out is typically the send buffer of the collective (ncclAllGather / torch
+ * all_gather_into_tensor on the same stream).  Neither call waits: d_out, the inputs and the SRS stay valid until the stream has passed
+ * this point (zk_g1_sum_winsums_dev waits for it).  zk_kzg_round_reduce_winsums_dev is zk_kzg_round_reduce for this form (work queued
+ * after it runs behind the reductions); zk_kzg_round_end_winsums_dev closes the round (queues the reductions itself unless reduce ran;
+ * d_out must then be the same buffer).  All-zero sums are the point at infinity (a rank with an empty shard); a job computed at
+ * submission or parked by the memory budget enters as S_0 = its point.  The ranks all-gather the buffers and zk_g1_sum_winsums_dev adds
+ * the ranks' sums element-wise (one kernel of n_jobs * 2 VW independent quads, ranks - 1 additions each), waits once, and leaves the
+ * one combine + inversion per job to the ctx's host pool exactly as zk_kzg_round_end does.  Same results.
+ * ZK_ERR_UNSUPPORTED (returned before anything is queued: the round stays open, close it with zk_kzg_round_end_partial): no table, a
+ * table with window_bits >= 18 -- the DEFAULT of zk_srs_precompute for whole tables of 2^22 points and more: pass window_bits = 17 to
+ * zk_srs_precompute_ex / _rows for an SRS meant for this exchange -- and the commitment cache.  Every rank must run the same
+ * table window and the same "pre_vw" / "pre_logg" options: zk_winsums_geometry returns {window_bits, windows of a full-width scalar, VW,
+ * buckets per virtual window} for the caller to compare across ranks once (the Python schedule all-gathers it at construction and
+ * refuses a mismatch); zk_winsums_dev_bytes is 0 where the form does not exist.
+ * (Round 4's other device form -- ONE point per job, formed by a further dependent launch: zk_kzg_round_end_partial_dev /
+ * zk_g1_sum_partials_dev -- measured last of the three exchanges and was retired in round 6: profiles/design_history_msm.md.) */
 size_t zk_winsums_dev_bytes(zk_ctx* ctx, zk_srs* srs);
 int zk_winsums_geometry(zk_ctx* ctx, zk_srs* srs, uint32_t out[4]);
 int zk_kzg_round_reduce_winsums_dev(zk_ctx* ctx, void* d_out);

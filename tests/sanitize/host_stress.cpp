@@ -192,26 +192,17 @@ int main() {
                         TCHECK(zk_kzg_round_end(c, 5, xy, inf) == ZK_OK);
                     }
                     TCHECK(zk_kzg_round_pending(c, &pend) == ZK_OK && pend == 0);
-                    // the device form of a round's partials
-                    void* parts = nullptr;
-                    const size_t pb = zk_partial_dev_bytes(CURVE);
-                    TCHECK(pb == 256 && zk_dev_alloc(c, 4 * pb, &parts) == ZK_OK);
-                    TCHECK(zk_kzg_round_begin_dev(c, srs, 4, in, lens, nullptr) == ZK_OK);
-                    TCHECK(zk_kzg_round_reduce_partial_dev(c, parts) == ZK_OK);
-                    TCHECK(zk_kzg_round_end(c, 4, xy, inf) == ZK_ERR_PENDING);
-                    TCHECK(zk_kzg_round_end_partial_dev(c, 4, parts) == ZK_OK);
-                    TCHECK(zk_g1_sum_partials_dev(c, CURVE, parts, 1, 4, xy, inf) == ZK_OK && inf[0] && inf[3]);
-                    TCHECK(zk_dev_free(c, parts) == ZK_OK);
-                    // ... and the window-sum form (round 5): 2 VW sums per job on the device, summed over the ranks, combined by the host pool
+                    // the device form of a round's result: 2 VW sums per job on the device, summed over the ranks, combined by the host pool
                     {
-                        const size_t wb = zk_winsums_dev_bytes(c, srs);
+                        const size_t wb = zk_winsums_dev_bytes(c, srs), pb = 256;
                         uint32_t geom[4] = {0, 0, 0, 0};
                         TCHECK(wb == 2 * 64 * pb && zk_winsums_geometry(c, srs, geom) == ZK_OK && geom[0] == 16 && geom[2] == 64);
                         void* ws = nullptr;
                         TCHECK(zk_dev_alloc(c, 2 * 4 * wb, &ws) == ZK_OK);
                         TCHECK(zk_kzg_round_begin_dev(c, srs, 4, in, lens, nullptr) == ZK_OK);
                         TCHECK(zk_kzg_round_reduce_winsums_dev(c, ws) == ZK_OK);
-                        TCHECK(zk_kzg_round_end_partial_dev(c, 4, ws) == ZK_ERR_PENDING);          // reduced towards the other form
+                        TCHECK(zk_kzg_round_end(c, 4, xy, inf) == ZK_ERR_PENDING);                // reduced towards the device: the host form refuses
+                        TCHECK(zk_kzg_round_end_winsums_dev(c, 4, (char*)ws + 64) == ZK_ERR_PENDING);   // ... and so does another buffer
                         TCHECK(zk_kzg_round_end_winsums_dev(c, 4, ws) == ZK_OK);
                         TCHECK(zk_g1_sum_winsums_dev(c, srs, ws, 2, 4, xy, inf) == ZK_OK && inf[0] && inf[3]);
                         TCHECK(zk_dev_free(c, ws) == ZK_OK);

@@ -1,11 +1,11 @@
-"""Randomised cross-check of the sharded forms of a round of commitments (round 4: `zk_srs_precompute_rows`, `zk_kzg_round_end_partial(_dev)`,
-`zk_g1_sum_partials(_dev)`) against the CPU restatement: G "ranks" played one after the other on one card, G in 2..8,
+"""Randomised cross-check of the sharded forms of a round of commitments (`zk_srs_precompute_rows`, `zk_kzg_round_end_partial`,
+`zk_g1_sum_partials_batch`, `zk_kzg_round_end_winsums_dev`, `zk_g1_sum_winsums_dev`) against the CPU restatement: G "ranks" played one after the other on one card, G in 2..8,
   * by points  -- rank g owns SRS[g n/G, (g+1) n/G) and that slice of every coefficient vector (ragged vectors leave late ranks short or
                   empty), its own whole window table;
   * by windows -- rank g owns rows g, g+G, ... of the window table over the whole SRS (c = 16 or 17) and sees whole vectors;
-and the exchange in its three forms: Jacobian partials through the host (`round_end_partial` + `sum_partials_batch`), one internal point per
-job left on the device (`round_end_partial_dev`, a (G, jobs x words) tensor as the all-gather would leave it, `sum_partials_dev`), or --
-round 5 -- every job's virtual-window sums left on the device and added element-wise (`round_end_winsums_dev`, `sum_winsums_dev`).
+and the exchange in its two forms: Jacobian partials through the host (`round_end_partial` + `sum_partials_batch`), or every job's
+virtual-window sums left on the device -- a (G, jobs x words) tensor as the all-gather would leave it -- and added element-wise
+(`round_end_winsums_dev`, `sum_winsums_dev`).
 The sum over the ranks must be the commitment of the CPU restatement, limb for limb.
 usage: [SEED=..] [MAX_LOG_N=17] python tests/stress/stress_shards.py [seconds]   (a short budget runs under tests/test_stress_gpu.py)"""
 import os
@@ -39,7 +39,7 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
         n = 1 << log_n
         G = int(rng.choice([2, 3, 4, 5, 8]))
         axis = "windows" if rng.random() < 0.5 else "points"
-        form = str(rng.choice(["host", "point", "winsums", "winsums"]))
+        form = str(rng.choice(["host", "winsums"]))
         on_device = form != "host"
         ks = np.zeros((n, 4), dtype=np.uint64)
         ks[:, 0] = rng.integers(1, 1 << 40, size=n, dtype=np.uint64)
@@ -78,8 +78,7 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
                 mine = d_polys
             live = [q for q in mine if q.shape[0] > 0]
             if on_device:
-                ws = form == "winsums"
-                words = ck.winsums_dev_words() if ws else ck.partial_dev_words()
+                words = ck.winsums_dev_words()
                 assert words > 0, (form, axis, c_bits)
                 buf = torch.zeros((k, words), dtype=torch.int64, device="cuda")       # all-zero row = the point at infinity (empty shard)
                 if live:
@@ -87,8 +86,8 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
                     for q in live:
                         ck.commit_begin([q])
                     if rng.random() < 0.5:
-                        (ck.round_reduce_winsums_dev if ws else ck.round_reduce_partial_dev)(sub)
-                    (ck.round_end_winsums_dev if ws else ck.round_end_partial_dev)(sub, len(live))
+                        ck.round_reduce_winsums_dev(sub)
+                    ck.round_end_winsums_dev(sub, len(live))
                     idx = torch.tensor([j for j, q in enumerate(mine) if q.shape[0] > 0], dtype=torch.int64, device="cuda")
                     buf.index_copy_(0, idx, sub)
                 dev_parts.append(buf.reshape(-1))
@@ -101,10 +100,8 @@ def run(budget: float = 120.0, seed: int = 3, ctx=None, max_log_n: int = 17):
             keep = ck          # the summing call needs any key of the curve on this ctx
             if g < G - 1:
                 ck.close()
-        if form == "winsums":
+        if on_device:
             got = keep.sum_winsums_dev(torch.stack(dev_parts), G, k)
-        elif on_device:
-            got = keep.sum_partials_dev(torch.stack(dev_parts), G, k)
         else:
             got = zk.sum_partials_batch(np.stack(host_parts), cid)
         keep.close()

@@ -155,7 +155,7 @@ def test_null_handles_are_refused_by_every_entry_point():
     assert r.returncode == 0, f"crashed in {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else '?'} (exit {r.returncode})"
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert len(res) >= 70
-    empty_is_ok = {"zk_g1_sum_partials_dev", "zk_g1_sum_winsums_dev"}              # n_jobs = 0: nothing to do, documented as ZK_OK
+    empty_is_ok = {"zk_g1_sum_winsums_dev"}              # n_jobs = 0: nothing to do, documented as ZK_OK
     for name, rc in res.items():
         assert rc < 0 or name in empty_is_ok, (name, rc)
         if name not in empty_is_ok:

@@ -53,20 +53,20 @@ def test_config3_msm_2_22_table_plain_and_8_shards(ctx, oracle_cpu):
     # 8 WINDOW shards (BASELINE.json north_star: "shards its windows/buckets across GPUs"): every rank registers the whole SRS, builds
     # the table rows of the windows g, g + 8 (2 of the 15 rows; rank 7: one) and sums all n scalars' digits of those windows.  The
     # partials go through both forms of the exchange: host Jacobian partials, and the device form (the last reduction kernel writes
-    # the partial into the tensor the all-gather would send; zk_g1_sum_partials_dev adds the ranks' partials)
+    # the job's virtual-window sums into the tensor the all-gather would send; zk_g1_sum_winsums_dev adds the ranks' element-wise)
     parts, dev_parts = [], []
     pw = None
     for g in range(G):
         ckw = zk.CommitterKey(bases, cid, ctx).precompute(rows=(g, G))
         assert ckw.table_rows() == (g, G, (15 - g + G - 1) // G) and ckw.table_windows() == 15
         parts.append(ckw.commit_batch_partial([d_s], canonical=[True]))
-        pw = ckw.partial_dev_words()
+        pw = ckw.winsums_dev_words()
         buf = torch.zeros((1, pw), dtype=torch.int64, device="cuda")
         ckw.commit_begin([d_s], canonical=[True])
-        ckw.round_end_partial_dev(buf, 1)
+        ckw.round_end_winsums_dev(buf, 1)
         dev_parts.append(buf)
         if g == G - 1:
-            got_dev = ckw.sum_partials_dev(torch.stack(dev_parts).reshape(G, pw).contiguous(), G, 1)[0]
+            got_dev = ckw.sum_winsums_dev(torch.stack(dev_parts).reshape(G, pw).contiguous(), G, 1)[0]
         ckw.close()
     assert zk.sum_partials_batch(np.stack(parts), cid)[0] == plain
     assert got_dev == plain
@@ -359,15 +359,15 @@ def test_window_shards_small_both_curves(cid, log_n, G, ctx, oracle_cpu):
         ckw = zk.CommitterKey(bases, cid, ctx).precompute(rows=(g, G))
         assert ckw.table_rows() == (g, G, (windows - g + G - 1) // G)
         parts.append(ckw.commit_batch_partial([d_poly, d_short]))
-        pw = ckw.partial_dev_words()
-        assert pw == (32 if cid == 0 else 24)
+        pw = ckw.winsums_dev_words()
+        assert pw == 2 * ckw.winsums_geometry()[2] * (32 if cid == 0 else 24)
         buf = torch.zeros((2, pw), dtype=torch.int64, device="cuda")
         ckw.commit_begin([d_poly])
         ckw.commit_begin([d_short])
-        ckw.round_end_partial_dev(buf, 2)
+        ckw.round_end_winsums_dev(buf, 2)
         dev.append(buf)
         if g == G - 1:
-            got_dev = ckw.sum_partials_dev(torch.stack(dev).reshape(G, 2 * pw).contiguous(), G, 2)
+            got_dev = ckw.sum_winsums_dev(torch.stack(dev).reshape(G, 2 * pw).contiguous(), G, 2)
         ckw.close()
     assert zk.sum_partials_batch(np.stack(parts), cid) == want
     assert got_dev == want

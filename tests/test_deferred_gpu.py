@@ -223,12 +223,6 @@ def test_schedule_with_hoisted_transforms_gives_the_same_commitments(ctx):
     b = ProofSchedule(log_n, ctx, ck, cv, hoist=False).run_once(0)
     c = ProofSchedule(log_n, ctx, ck, cv, defer_calls=False).run_once(0)
     assert a == b == c and len(a) == 29
-    # the two-stream experiments (off by default: both measured slower or even, profiles/r04_notes.md): hoisted transforms on a second
-    # stream; a round's jobs dealt to two contexts of the GPU (every 2nd / 3rd job here, the others there)
-    d = ProofSchedule(log_n, ctx, ck, cv, hoist="stream").run_once(0)
-    e = ProofSchedule(log_n, ctx, ck, cv, split_rounds=2).run_once(0)
-    f = ProofSchedule(log_n, ctx, ck, cv, split_rounds=3).run_once(0)
-    assert a == d == e == f
 
 
 @pytest.mark.parametrize("merge,long_rounds", [(0, None), (1, 1), (1, 3)])

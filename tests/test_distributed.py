@@ -215,10 +215,10 @@ def test_bench_two_ranks_matches_one_rank():
     assert d1["commitments_sha256"] == d4["commitments_sha256"]
     d5 = two_ranks(["--mode", "shard", "--shard-axis", "windows", "--host-partials"])
     assert d1["commitments_sha256"] == d5["commitments_sha256"]
-    # the three forms of the exchange: host Jacobians (round 3; the default: fastest on one card), one point per job (round 4), window sums (round 5)
+    # the two forms of the exchange: host Jacobians (round 3; the default: faster on one card) and window sums on the device (round 5)
     assert "'host'" in d3["config"]["parallelism"] and "'host'" in d4["config"]["parallelism"] and "'host'" in d5["config"]["parallelism"]
-    d6 = two_ranks(["--mode", "shard", "--exchange", "point"])
-    assert "'point'" in d6["config"]["parallelism"] and d1["commitments_sha256"] == d6["commitments_sha256"]
+    d6 = two_ranks(["--mode", "shard", "--exchange", "winsums"])
+    assert "'winsums'" in d6["config"]["parallelism"] and d1["commitments_sha256"] == d6["commitments_sha256"]
     d7 = two_ranks(["--mode", "shard", "--exchange", "winsums", "--shard-axis", "windows"])
     assert "'winsums'" in d7["config"]["parallelism"] and d1["commitments_sha256"] == d7["commitments_sha256"]
     # every N > 1 line says what the backend saw: two processes, ONE card here (a gloo rehearsal), the all-reduced sum of ones
@@ -369,14 +369,14 @@ def test_all_gather_partials_dev_world2_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["winsums", "point", "host"])
+@pytest.mark.parametrize("exchange", ["winsums", "host"])
 def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, exchange, monkeypatch):
     """ProofSchedule with world = 2 and a `dist` that reports backend "nccl": the partials of every group of PC calls must enter
     the collective as int64 tensors on the rank's GPU (RCCL cannot take host tensors), one all_gather per group; with both "ranks"
     contributing this rank's shard the result is twice the shard's commitment.
     on_device (the default since round 4): NO host copy between the last reduction kernel and the collective -- the tensor the
-    collective sends is the very buffer the library wrote the partials into (zk_kzg_round_end_partial_dev), the host-partial entry
-    point is never called, and the ranks' partials are added on the device (zk_g1_sum_partials_dev)."""
+    collective sends is the very buffer the library wrote the window sums into (zk_kzg_round_end_winsums_dev), the host-partial entry
+    point is never called, and the ranks' sums are added on the device (zk_g1_sum_winsums_dev)."""
     import torch
     import ark_plonk_amd as zk
     from ark_plonk_amd import _lib
@@ -401,8 +401,8 @@ def test_schedule_nccl_branch_places_partials_on_the_rank_gpu(ctx, exchange, mon
     monkeypatch.setattr(ck_shard, "round_end_partial", lambda *a, **k: (host_calls.append(1), real_end_partial(*a, **k))[1])
     out = sched.run_once(proof_id=0)
     assert len(out) == 29 and len(d.calls) == 5 and sched.collectives == 5       # five groups of PC calls, one collective each
-    words = {"winsums": ck_shard.winsums_dev_words(), "point": ck_shard.partial_dev_words(), "host": 3 * cv.fq_limbs}[exchange]
-    assert ck_shard.winsums_dev_words() == 2 * ck_shard.winsums_geometry()[2] * ck_shard.partial_dev_words() == 4096      # 128 points x 256 B
+    words = {"winsums": ck_shard.winsums_dev_words(), "host": 3 * cv.fq_limbs}[exchange]
+    assert ck_shard.winsums_dev_words() == 2 * ck_shard.winsums_geometry()[2] * 32 == 4096      # 128 points x 256 B
     for kind, odev, idev, odt, idt, oshape, ishape in d.calls:
         assert odev.type == idev.type == "cuda" and odev.index == idev.index == ctx.device and odt == idt == torch.int64
         assert ishape[0] % words == 0 and oshape == (2 * ishape[0],)
@@ -469,7 +469,7 @@ def _worker_rccl_world1(port, q):
         _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
         ck = zk.CommitterKey(bases[: n // 2].contiguous(), cv, ctx).precompute()
         res = {}
-        for exchange in ("winsums", "point", "host"):
+        for exchange in ("winsums", "host"):
             on_device = exchange != "host"
             TwoRowsOverRccl.calls = []
             sched = ProofSchedule(log_n, ctx, ck, cv, rank=0, world=2, dist=TwoRowsOverRccl, exchange=exchange)
@@ -482,7 +482,7 @@ def _worker_rccl_world1(port, q):
         ck.close()
         ctx.close()
         dist.destroy_process_group()
-        q.put(("ok", res["point"], res["host"], res["winsums"]))
+        q.put(("ok", res["host"], res["winsums"]))
     except BaseException as e:      # the parent reports it
         import traceback
         q.put(("error", repr(e), traceback.format_exc()[-3000:]))
@@ -512,47 +512,11 @@ def test_schedule_exchange_over_real_rccl_world1():
     if got[0] == "no_rccl":
         pytest.skip(f"RCCL did not come up on this box: {got[1]}")
     assert got[0] == "ok", got[1:]
-    dev, host, ws = got[1], got[2], got[3]
-    for r in (dev, host, ws):
+    host, ws = got[1], got[2]
+    for r in (host, ws):
         assert r["n"] == 29 and r["collectives"] == 5 and r["calls"] == 5 and r["devices"] == ["cuda:0"] and r["first_ok"]
-    assert dev["from_pbuf"] is True and ws["from_pbuf"] is True
-    assert dev["points"] == host["points"] == ws["points"]
-
-
-@pytest.mark.gpu
-def test_device_partials_with_short_and_empty_jobs(ctx):
-    """The device form of a round's partials with every kind of job: table path, a vector too short for it (computed at begin,
-    uploaded converted) and the point at infinity (all-zero scalars); against the host form and the oracle."""
-    import torch
-    import ark_plonk_amd as zk
-    from ark_plonk_amd import _lib
-    cv = zk.get_curve(0)
-    n = 1 << 14
-    rng = np.random.default_rng(77)
-    ks = torch.from_numpy(rng.integers(1, 1 << 62, size=(n, 4), dtype=np.uint64).view(np.int64)).cuda()
-    ks[:, 1:] = 0
-    bases = torch.empty((n, 2 * cv.fq_limbs), dtype=torch.int64, device="cuda")
-    ctx.use_torch_stream()
-    _lib.check(_lib.lib().zk_g1_fixed_base_batch_dev(ctx.handle, 0, ks.data_ptr(), n, bases.data_ptr()))
-    ck = zk.CommitterKey(bases, cv, ctx).precompute()
-    polys = [torch.from_numpy(rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64).view(np.int64)).cuda() for m in (n, 100, n - 1)]
-    polys.append(torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
-    want = ck.commit_batch(polys)
-    pw = ck.partial_dev_words()
-    buf = torch.full((len(polys), pw), -1, dtype=torch.int64, device="cuda")
-    for p in polys:
-        ck.commit_begin([p])
-    ck.round_reduce_partial_dev(buf)
-    with pytest.raises(RuntimeError):
-        ck.round_end(len(polys))                      # reduced towards the device: the host form refuses, the round stays open
-    ck.round_end_partial_dev(buf, len(polys))
-    got = ck.sum_partials_dev(buf.reshape(1, -1), 1, len(polys))
-    assert got == want and got[3].infinity
-    # two "ranks" with the same partials: 2 * commitment, as the host form computes it
-    two = ck.sum_partials_dev(torch.cat([buf.reshape(1, -1)] * 2), 2, len(polys))
-    host2 = zk.sum_partials_batch(np.stack([ck.commit_batch_partial(polys)] * 2), 0)
-    assert two == host2
-    ck.close()
+    assert ws["from_pbuf"] is True
+    assert host["points"] == ws["points"]
 
 
 @pytest.mark.gpu
@@ -601,15 +565,16 @@ def test_winsums_form_with_short_and_empty_jobs(ctx):
     polys.append(torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
     want = ck.commit_batch(polys)
     ww = ck.winsums_dev_words()
-    assert ww == 2 * VW * ck.partial_dev_words()
+    assert ww == 2 * VW * 32                              # 2 VW points of 256 bytes
     buf = torch.full((len(polys), ww), -1, dtype=torch.int64, device="cuda")
     for p in polys:
         ck.commit_begin([p])
     ck.round_reduce_winsums_dev(buf)
     with pytest.raises(RuntimeError):
         ck.round_end(len(polys))                          # reduced towards the device: the host form refuses, the round stays open
+    other = torch.zeros_like(buf)
     with pytest.raises(RuntimeError):
-        ck.round_end_partial_dev(buf, len(polys))         # ... and so does the other device form
+        ck.round_end_winsums_dev(other, len(polys))       # ... and so does the device form towards another buffer
     ck.round_end_winsums_dev(buf, len(polys))
     got = ck.sum_winsums_dev(buf.reshape(1, -1), 1, len(polys))
     assert got == want and got[3].infinity
@@ -633,9 +598,8 @@ def test_winsums_form_with_short_and_empty_jobs(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["point", "winsums"])
-def test_device_forms_refused_before_anything_is_queued_c18(ctx, form):
-    """a table with window_bits >= 18 finishes its reduction towards the host only.  The device forms must say
+def test_device_form_refused_before_anything_is_queued_c18(ctx):
+    """a table with window_bits >= 18 finishes its reduction towards the host only.  The device form must say
     ZK_ERR_UNSUPPORTED BEFORE the sort and the merged accumulation of the round's deferred jobs are queued -- otherwise the fall-back
     the header names (zk_kzg_round_end_partial) re-plans jobs that already ran with the long-chunk plan and combines their
     chunk-edge partials wrongly.  Two and three jobs at 2^18 (several rounds of lanes: long chunks differ from short ones)."""
@@ -656,8 +620,7 @@ def test_device_forms_refused_before_anything_is_queued_c18(ctx, form):
     want = ck.commit_batch(polys)
     buf = torch.zeros((3, 4096), dtype=torch.int64, device="cuda")
     L = _lib.lib()
-    end_dev = L.zk_kzg_round_end_partial_dev if form == "point" else L.zk_kzg_round_end_winsums_dev
-    red_dev = L.zk_kzg_round_reduce_partial_dev if form == "point" else L.zk_kzg_round_reduce_winsums_dev
+    end_dev, red_dev = L.zk_kzg_round_end_winsums_dev, L.zk_kzg_round_reduce_winsums_dev
     for k in (2, 3):
         ck.commit_begin(polys[:k])
         assert red_dev(ctx.handle, buf.data_ptr()) == _lib.ZK_ERR_UNSUPPORTED

@@ -469,7 +469,7 @@ def test_repeated_and_opposite_points_take_the_general_law(cid, table, ctx, orac
 
 @pytest.mark.parametrize("cid", [0, 1])
 def test_table_path_irregular_sizes_across_the_lane_rounding_rules(cid, ctx, oracle_cpu):
-    """Lengths that are not powers of two, on both sides of every threshold of the accumulation's lane plan (msm.hip: pre_plan) --
+    """Lengths that are not powers of two, on both sides of every threshold of the accumulation's lane plan (msm_plan.hip: pre_plan_geom) --
     one round of resident lanes (131072) exceeded or not, whole-round rounding taken or refused (chunks below 16), two rounds
     becoming three, the 16-bit -> 17-bit table window at 2^19 points -- as single MSMs and as round batches (in which every job but
     the last takes the long-chunk plan), odd and even, against the C++ restatement's KZG commitment limb for limb."""

@@ -1,5 +1,5 @@
 """Per-kernel register / scratch / LDS / occupancy table of one HIP source, from hipcc's own remarks
-(`-Rpass-analysis=kernel-resource-usage`, device code only).  `python tools/kernel_resources.py msm.hip [-DZK_CURVE_SEL=0] [filter]`"""
+(`-Rpass-analysis=kernel-resource-usage`, device code only).  `python tools/kernel_resources.py msm_accumulate.hip [-DZK_CURVE_SEL=0] [filter]`"""
 import os
 import re
 import subprocess

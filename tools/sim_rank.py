@@ -1,9 +1,9 @@
 """Per-rank compute time of the sharded schedule, measured on ONE GPU: runs rank 0 of a world
 of W with a stand-in for torch.distributed whose all_gather returns W copies of the local tensor.
 No communication is timed -- this shows where a rank's time goes (NTT replica, MSM shard, reductions) for both shard axes
-(points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and the three forms of the
-exchange (winsums: the jobs' virtual-window sums, zk_kzg_round_end_winsums_dev + zk_g1_sum_winsums_dev; point: one device-resident point
-per job, zk_kzg_round_end_partial_dev + zk_g1_sum_partials_dev; host: round 3's Jacobian partials through the host).
+(points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and the two forms of the
+exchange (winsums: the jobs' virtual-window sums, zk_kzg_round_end_winsums_dev + zk_g1_sum_winsums_dev; host: Jacobian partials through
+the host).  Round 5 also timed a third form, one device-resident point per job: last of the three (profiles/r05_sim_rank.txt), retired.
 AN ESTIMATE, NOT A MEASUREMENT of N GPUs.
 
 usage: python tools/sim_rank.py [W ...]
@@ -59,7 +59,7 @@ def main():
                 srs = build_srs(ctx, cv, n, 0, n, torch)
                 ck = zk.CommitterKey(srs, cv, ctx).precompute(rows=(0, w))
             del srs
-            forms = ("-",) if w == 1 else ("winsums", "point", "host")
+            forms = ("-",) if w == 1 else ("winsums", "host")
             # the forms ALTERNATE visit by visit over one key and one set of inputs (a box drifts by several per cent with its power
             # state: configurations measured one after the other cannot resolve the ~2 % between the forms)
             scheds = {f: ProofSchedule(log_n, ctx, ck, cv, rank=0, world=w, dist=FakeDist(w) if w > 1 else None, shard_axis=axis,

@@ -1,7 +1,7 @@
 // Unsaturated (29-bit limb) Montgomery arithmetic for the scalar field on gfx950: the NTT butterflies, the KZG witness /
 // evaluation kernels, the quotient and grand-product kernels.  (The MSM's base field uses signed 30-bit limbs: fields.cuh.)
 //
-// Why: measured on MI355X (profiles/r01_ubench_valu.txt) v_mad_u64_u32 issues in 4 cycles per
+// Why: measured on MI355X (profiles/r01/r01_ubench_valu.txt) v_mad_u64_u32 issues in 4 cycles per
 // wave-instruction -- the same as one v_add_co/v_addc -- so in a saturated 32-bit-limb CIOS the carry
 // handling costs more than the multiplies.  With 29-bit limbs a 64-bit accumulator absorbs a whole
 // product-scanning column (2*NL products < 2^58 each) with no carries: one v_mad_u64_u32 per limb

@@ -4,7 +4,7 @@
 // The reference hands over ordinary heap slices (`domain.ifft(&w_l_scalar)` prover.rs:196-203, `PC::commit(ck, polys)`
 // prover.rs:213), i.e. pageable memory.  Two ways to move it (zk_ctx_set_staging):
 //   0 (default)  hipMemcpyAsync straight from / to the caller's buffer.  Measured on the MI355X hosts (tools/pcie_probe.py,
-//                profiles/r02_notes.md): 56 GB/s in both directions, the same as pinned memory -- the runtime's own staging
+//                profiles/r02/r02_notes.md): 56 GB/s in both directions, the same as pinned memory -- the runtime's own staging
 //                keeps the link busy.
 //   1            an explicit ring of pinned 8 MiB slots per ctx, the caller's bytes copied into a slot by the ctx's host pool
 //                and sent by DMA while the next slot is being filled: 49 GB/s there, kept for hosts where mode 0 is slow.

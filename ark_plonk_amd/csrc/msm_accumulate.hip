@@ -213,9 +213,9 @@ int msm_precompute_run(zk_ctx* c, zk_srs* s, uint32_t window_bits, uint32_t w0, 
     typedef typename Cv::FqU F;
     // default window: 16 bits (16 rows, 2^15 buckets) below 2^19 points; from there on 17 bits, which scalars folded to
     // k <= (r - 1) / 2 (MsmGeom::neg) cover in 15 windows -- one mixed addition per scalar fewer for twice the buckets to reduce
-    // (measured, profiles/r03_notes.md: 2^18 27.1 / 29.2 ms per proof at c = 16 / 17, 2^19 48.1 / 47.3, 2^20 87.4 / 85.6, 2^22 364.6 / 353.2)
+    // (measured, profiles/r03/r03_notes.md: 2^18 27.1 / 29.2 ms per proof at c = 16 / 17, 2^19 48.1 / 47.3, 2^20 87.4 / 85.6, 2^22 364.6 / 353.2)
     // From 2^22 points on a whole table takes 20 bits (13 rows, 2^19 buckets): the 2 x 2^19 additions of the wide bucket reduction are
-    // then fewer than the two additions per scalar they save (measured, profiles/r05_sweep_window.txt: c = 17 / 20 at 2^21 153.9 / 153.3 ms
+    // then fewer than the two additions per scalar they save (measured, profiles/r05/r05_sweep_window.txt: c = 17 / 20 at 2^21 153.9 / 153.3 ms
     // per proof, 2^22 300.6 / 287.3, 2^23 599.4 / 551.5; at 2^20 79.3 / 87.4 -- the other way round).  A window-sharded table keeps 17:
     // its rank accumulates only W / G rows into the same number of buckets.
     if (window_bits == 0) window_bits = (s->n >= (1u << 22) && wstep == 1) ? 20 : s->n >= (1u << 19) ? PRE_C + 1 : PRE_C;

@@ -235,7 +235,7 @@ MsmGeom make_geom(uint64_t n, int c_override, uint32_t max_c = 16) {
     if (c_override > 0) {
         c = (uint32_t)c_override;
     } else {
-        // per-window path: measured on MI355X over c = 9 .. 16 at every size (profiles/r02_notes.md, "window of the per-window
+        // per-window path: measured on MI355X over c = 9 .. 16 at every size (profiles/r02/r02_notes.md, "window of the per-window
         // path"): the bucket reduction (W * 2^(c-1) buckets) is what a large c pays for, and its kernels change shape with c, so
         // the best window is a step function of the size, not lg - 4 all the way (6.35 -> 5.04 ms at 2^20, 3.35 -> 2.23 at 2^18)
         uint32_t lg = ilog2_floor(n ? n : 1);

@@ -111,7 +111,7 @@ inline void pre_reduce_geom(const zk_ctx* c, PrePlan& pl) {
     // 64 chains (one wavefront per SIMD) per virtual window: segments of 8 buckets for windows of 512 (c = 16; measured against 4 / 16),
     // of 16 for windows of 1024 (c = 17; 64 x 16 measured against 128 x 8, and against 128 and 32 virtual windows)
     pl.gv.logG = pl.wide_red ? 2 : pl.gv.B >= 1024 ? 4 : 3;
-    if (!pl.wide_red) {                                   // tuning options "pre_vw" / "pre_logg" (profiles/r02_notes.md)
+    if (!pl.wide_red) {                                   // tuning options "pre_vw" / "pre_logg" (profiles/r02/r02_notes.md)
         if (c->tune.pre_vw) {
             const uint32_t v = (uint32_t)c->tune.pre_vw;
             if (v >= 8 && v <= 512 && (v & (v - 1)) == 0 && pl.g.B % v == 0) {
@@ -158,7 +158,7 @@ int pre_plan_geom(const zk_ctx* c, const zk_srs* s, size_t n, PrePlan& pl, bool 
     pl.chunk_l = PRE_CHUNK_L;
     while (pl.chunk_l > 16 && pl.nf / pl.chunk_l < 196608) pl.chunk_l >>= 1;
     bool tuned = false;
-    if (c->tune.chunk_l >= 8 && c->tune.chunk_l <= 1024) {          // tuning option "chunk_l" (profiles/r02_notes.md)
+    if (c->tune.chunk_l >= 8 && c->tune.chunk_l <= 1024) {          // tuning option "chunk_l" (profiles/r02/r02_notes.md)
         pl.chunk_l = (uint32_t)c->tune.chunk_l;
         tuned = true;
     }
@@ -168,7 +168,7 @@ int pre_plan_geom(const zk_ctx* c, const zk_srs* s, size_t n, PrePlan& pl, bool 
     // Two rounds become three where the chunks stay >= 32 references: the end of the launch, where CUs wait for their last
     // wavefronts, shortens with the chunk (2^20, c = 17: 60 -> 40 per lane, msm_accumulate -2.5 % per launch, msm_combine* +7
     // partials per bucket instead of 5, net +0.5 .. 0.8 % proofs/s; 30 and 24 per lane give the accumulation another 1 % and
-    // the combine more than that back: profiles/r03_notes.md).  A job that is not the last one of a merged launch has no end of
+    // the combine more than that back: profiles/r03/r03_notes.md).  A job that is not the last one of a merged launch has no end of
     // its own: one round (option "long_rounds": tuning hook), a third of the partials.
     pl.max_lanes = pl.n_lanes;
     {
@@ -427,7 +427,7 @@ int jac_to_affine(const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf);
 // coefficients in, Jacobian results out.  Every job has its own buffer set and every step is ONE launch per kernel
 // for all the jobs of the round (job = blockIdx.y, or a block range of the merged accumulation): the sort's placement
 // passes, the accumulation, the combine / segmented-reduction steps.  Everything stays on the ctx stream: overlapping
-// neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01_notes.md, r02_notes.md).
+// neighbouring jobs on a second stream was measured to cost more than it hides (profiles/r01/r01_notes.md, r02_notes.md).
 //
 // The batch comes in pieces so that a round may be OPENED by several calls and closed by one
 // (zk_kzg_round_begin_dev / zk_kzg_round_end):

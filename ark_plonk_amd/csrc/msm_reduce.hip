@@ -504,7 +504,7 @@ int queue_reduce(zk_ctx* c, const RJobs& jobs, uint32_t n_jobs, uint32_t nb, con
             hipLaunchKernelGGL((msm_combine<F, 4>), dim3(blocks, n_jobs), dim3(T), 0, st, jobs, nb);
         }
     } else {
-        // lanes per small bucket when the launch has many jobs.  Option "combine_sg": tuning hook (profiles/r03_notes.md)
+        // lanes per small bucket when the launch has many jobs.  Option "combine_sg": tuning hook (profiles/r03/r03_notes.md)
         const int sg = c->tune.combine_sg ? c->tune.combine_sg : 1;
         if (sg == 4) {
             unsigned blocks = (unsigned)(((uint64_t)nb * 4 + T - 1) / T);

@@ -215,7 +215,7 @@ class ProofSchedule:
         #                        into the collective's send buffer; all-gathered (32 KiB per job); added element-wise by one kernel; ONE
         #                        host wait, the combine per job on the host pool (zk_kzg_round_end_winsums_dev / zk_g1_sum_winsums_dev)
         #   "host" (default)     window sums to the host, host combine, H2D, all-gather of 3L-limb Jacobians, D2H, host sum
-        # Default = the faster on ONE card (profiles/r05_sim_rank.txt: "host" by 1-2 % over "winsums"); on a node the device form saves
+        # Default = the faster on ONE card (profiles/r05/r05_sim_rank.txt: "host" by 1-2 % over "winsums"); on a node the device form saves
         # a host round trip before and after every collective -- bench.py times both there.  `partials_on_device=True` without
         # `exchange` selects "winsums".  (A third form -- one point per job formed by a further dependent launch -- measured last on one
         # card in round 5 and was retired in round 6: profiles/design_history_msm.md.)

@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # The kernel is integer-VALU bound (SURVEY.md 8d asks for the u32-MAC rate next to the HBM fraction).
 # Instruction counts of the mixed-addition path of msm_accumulate (gfx950 ISA of this build, BLS12-381:
 # 6 products + 2 squares + 1 double product of 13 signed 30-bit limbs, csrc/fields.cuh) and the measured issue
-# costs of profiles/r01_ubench_valu.txt.
+# costs of profiles/r01/r01_ubench_valu.txt.
 MADD_MADS = 3055            # v_mad_i64_i32 per mixed addition
 MADD_OTHER_VALU = 1299      # 64-bit shift / add, mul_lo, digit and carry-step instructions around them
 CLOCK_HZ = 2.4e9            # MI355X max engine clock (MI355X_MICROARCH.md chip table)
@@ -57,7 +57,7 @@ LANES = 256 * 4 * 64        # CUs x SIMDs x lanes
 MAD_CYCLES_FULL = 3.99      # cycles per wave-instruction per SIMD at >= 4 waves/SIMD
 # issue cycles of one mixed addition at the kernel's 2 waves/SIMD (215 VGPRs): mad 4.77, mul_lo 4.70, 64-bit shift/add 4.45, rest 2.64
 MADD_CYCLES_2WAVES = 3055 * 4.77 + 117 * 4.70 + 492 * 4.45 + 690 * 2.64
-# measured on MI355X (tools/experiments/clock_probe.hip, profiles/r02_clock_probe.txt): what a stream of nothing but independent
+# measured on MI355X (tools/experiments/clock_probe.hip, profiles/r02/r02_clock_probe.txt): what a stream of nothing but independent
 # v_mad_u64_u32 reaches, by HIP events, at 2 and at 8 waves per SIMD -- the nominal 16 lanes x 1024 SIMDs x 2.4 GHz is 3.93e13
 PURE_MAD_RATE_2_WAVES = 2.66e13
 PURE_MAD_RATE_8_WAVES = 3.41e13
@@ -199,7 +199,7 @@ class PowerSampler:
     """Socket power and shader clock of the card the process runs on, from the amdgpu hwmon files (plain sysfs reads, no GPU call),
     sampled by a thread while a leg runs.  A box shows the hwmon of every card of its host -- other tenants' cards too: the card is
     the one whose PCI address is `bdf` (the sysfs `device` link of the card names it); only without a match, the one whose power
-    moved most (rounds 1-4's heuristic: wrong whenever a neighbour's job starts or stops meanwhile -- profiles/r05_notes.md).  Used by
+    moved most (rounds 1-4's heuristic: wrong whenever a neighbour's job starts or stops meanwhile -- profiles/r05/r05_notes.md).  Used by
     the `power` leg only -- never inside the timed region of `value`."""
 
     WANT = ("power1_average", "power1_input", "freq1_input", "temp2_input")
@@ -277,7 +277,7 @@ class FirmwareThrottlers:
     """The throttler residency accumulators of the card's power-management firmware (gpu_metrics v1.6+: accumulation_counter and the
     PPT / socket-thermal / VR-thermal / HBM-thermal / PROCHOT residencies), read through AMD SMI (`amdsmi_get_violation_status`: sysfs
     underneath, no GPU call) for the card with PCI address `bdf`.  between(a, b) = the share of firmware iterations each limiter was
-    ACTIVE between two snapshots: the one that is non-zero NAMES what holds the clock below its peak (profiles/r05_notes.md)."""
+    ACTIVE between two snapshots: the one that is non-zero NAMES what holds the clock below its peak (profiles/r05/r05_notes.md)."""
 
     KEYS = {"ppt": "acc_ppt_pwr", "socket_thermal": "acc_socket_thrm", "vr_thermal": "acc_vr_thrm", "hbm_thermal": "acc_hbm_thrm", "prochot": "acc_prochot_thrm"}
 
@@ -518,7 +518,7 @@ def parse_args():
     ap.add_argument("--drop-in-callers", type=int, default=4, help="drop_in leg: host threads calling the host-pointer entry points at once")
     ap.add_argument("--exchange", default="host", choices=["winsums", "host"],
                     help="sharded MSMs, what the ranks all-gather per group of PC calls (default 'host': the faster of the two on ONE card with a "
-                         "stand-in collective, profiles/r05_sim_rank.txt -- by 1-2 %% over 'winsums', which removes a host round trip before and "
+                         "stand-in collective, profiles/r05/r05_sim_rank.txt -- by 1-2 %% over 'winsums', which removes a host round trip before and "
                          "after every collective that a one-card run cannot see; an N > 1 run times BOTH, legs msm_sharded and "
                          "msm_sharded_winsums): 'winsums' = every job's 2 VW virtual-window sums as "
                          "the last reduction kernel of the single-GPU path leaves them on the device (32 KiB per job), added element-wise by one "
@@ -969,8 +969,8 @@ def main():
                 "mads_vs_measured_pure_mad_stream_at_2_waves_per_simd": mac_s / PURE_MAD_RATE_2_WAVES,
                 "mads_vs_measured_pure_mad_stream_at_8_waves_per_simd": mac_s / PURE_MAD_RATE_8_WAVES,
                 "note": "the kernel issues 1299 other vector instructions per 3055 multiply-adds on top of this rate, and at two waves per SIMD a 64-bit "
-                        "shift or add costs what a multiply-add costs (profiles/r01_ubench_valu.txt): the count that matters is all of them "
-                        "(profiles/r03_notes.md)"}
+                        "shift or add costs what a multiply-add costs (profiles/r01/r01_ubench_valu.txt): the count that matters is all of them "
+                        "(profiles/r03/r03_notes.md)"}
     kp = r["steps_profiled"]            # proofs seen by the profiled zk_ctx (= K unless --streams > 1)
     S = r["streams"]
     if world == 1:
@@ -1155,7 +1155,7 @@ def main():
                         "what": "amdgpu hwmon of THIS card (matched by PCI address; power1_average|power1_input, freq1_input = sclk) every ~4 ms over a "
                                 "run of the headline schedule, and the firmware's own throttler residencies over the same run: the socket power "
                                 "limit (PPT) is what holds the clock below 2.4 GHz under msm_accumulate -- no thermal limiter is ever active "
-                                "(profiles/r05_notes.md)"})
+                                "(profiles/r05/r05_notes.md)"})
             return out
         leg("power", power_leg)
     if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):

@@ -113,7 +113,7 @@ int zk_ctx_set_staging(zk_ctx* ctx, int mode);
  * most max_vector_bytes (named by a keyed 256-bit digest of the bytes the caller receives) and zk_ntt / zk_kzg_commit_batch / zk_kzg_open
  * digest every input of at most that size on the ctx's host pool and use the resident copy on a match; a miss uploads into a fresh
  * entry, so a second use of any vector hits too (the prover key's sigma polynomials, proof after proof).  A digest runs at ~190 GB/s
- * against PCIe's 56, so a hit costs a third of an upload and a miss a third more (profiles/r05_notes.md).  WHAT IS GUARANTEED: results
+ * against PCIe's 56, so a hit costs a third of an upload and a miss a third more (profiles/r05/r05_notes.md).  WHAT IS GUARANTEED: results
  * are identical to the uncached calls UNLESS two different vectors of one length collide under the keyed 256-bit non-cryptographic
  * digest (per-process key from the operating system) -- a hit is taken on equality of (length, digest) of the caller's CURRENT bytes,
  * the contents are not compared: the trust model of zk_srs_register's registry below.  Option "cache_verify" = 1 compares them (and

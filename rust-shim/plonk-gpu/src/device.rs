@@ -343,23 +343,27 @@ fn resident_map() -> &'static Mutex<ResidentMap> {
     unsafe { RESIDENT.as_ref().expect("initialised by call_once") }
 }
 
+/// Fingerprint of the WHOLE vector (a sample of ~65 elements let a second prover key of the same size at the same
+/// address, differing only in unsampled rows, reuse the first key's device copy -- every later proof silently invalid).  Four
+/// interleaved FNV-1a lanes over the limbs, folded: a pass over 32 MiB takes a few milliseconds once per proof and column, against
+/// the 12 ms upload it saves; the key is still (address, length), so a hit also needs the same allocation.
 fn fingerprint(v: &[Fr]) -> u64 {
     let words = unsafe { core::slice::from_raw_parts(fr_ptr(v), v.len() * FR_LIMBS) };
-    let mut h: u64 = 0xcbf2_9ce4_8422_2325 ^ (v.len() as u64);
-    let step = core::cmp::max(v.len() / 64, 1);
-    let mut i = 0;
-    while i < v.len() {
-        for k in 0..FR_LIMBS {
-            h = (h ^ words[i * FR_LIMBS + k]).wrapping_mul(0x0000_0100_0000_01b3);
-        }
-        i += step;
-    }
-    if let Some(last) = v.len().checked_sub(1) {
-        for k in 0..FR_LIMBS {
-            h = (h ^ words[last * FR_LIMBS + k]).wrapping_mul(0x0000_0100_0000_01b3);
+    const P: u64 = 0x0000_0100_0000_01b3;
+    let mut h = [0xcbf2_9ce4_8422_2325u64 ^ (v.len() as u64), 0x8422_2325_cbf2_9ce4, 0x9ce4_8422_2325_cbf2, 0x2325_cbf2_9ce4_8422];
+    for chunk in words.chunks_exact(4) {
+        for k in 0..4 {
+            h[k] = (h[k] ^ chunk[k]).wrapping_mul(P);
         }
     }
-    h
+    for (k, w) in words.chunks_exact(4).remainder().iter().enumerate() {
+        h[k] = (h[k] ^ *w).wrapping_mul(P);
+    }
+    let mut out = h[0];
+    for k in 1..4 {
+        out = (out.rotate_left(23) ^ h[k]).wrapping_mul(P);
+    }
+    out
 }
 
 /// A shared handle to a resident vector.

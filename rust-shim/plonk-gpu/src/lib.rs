@@ -125,7 +125,7 @@ thread_local! {
 /// With `ARK_PLONK_AMD_CTX_PER_THREAD=1` every thread that calls a hook gets its own context (its own HIP stream, staging buffers and
 /// caches; the registered SRS and its window table belong to the GPU and are shared): a service that runs `Prover::prove` in T worker
 /// threads then has one thread's PCIe transfers under the other threads' kernels -- 5.7 proofs/s with one caller, 9.4-9.8 with four,
-/// 11.0 with eight on one MI355X at n = 2^20 (profiles/r05_drop_in_callers.txt).  Meant for callers that drive the prover from a few
+/// 11.0 with eight on one MI355X at n = 2^20 (profiles/r05/r05_drop_in_callers.txt).  Meant for callers that drive the prover from a few
 /// long-lived threads (prover.rs calls every hook from the thread that called `prove`), not from a large work-stealing pool.
 pub fn ctx() -> *mut sys::ZkCtx {
     INIT.call_once(|| {

@@ -50,7 +50,7 @@ def test_msm_kernels_registers_and_spills():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
 @pytest.mark.parametrize("tool", ["affine_probe.hip", "energy_probe.hip"])
 def test_measurement_tools_still_build(tool, tmp_path):
-    """The standalone probes behind profiles/r04_notes.md (they include the library's field / group-law headers) compile for gfx950."""
+    """The standalone probes behind profiles/r04/r04_notes.md (they include the library's field / group-law headers) compile for gfx950."""
     out = tmp_path / tool.replace(".hip", "")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "ark_plonk_amd", "csrc"), os.path.join(ROOT, "tools", tool),
                         "-o", str(out)], capture_output=True, text=True, timeout=600)

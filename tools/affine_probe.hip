@@ -1,5 +1,5 @@
 // Would pairwise AFFINE additions with a shared inversion (Montgomery's trick) beat msm_accumulate's XYZZ mixed additions on this card?
-// A measurement, not a product path (nothing under ark_plonk_amd/ uses it).  profiles/r04_notes.md holds the numbers and the verdict.
+// A measurement, not a product path (nothing under ark_plonk_amd/ uses it).  profiles/r04/r04_notes.md holds the numbers and the verdict.
 //
 // The idea: the references of a bucket are sorted next to each other, so a level of a pairwise reduction tree is a list of INDEPENDENT
 // additions P + Q.  In affine coordinates one of them costs lambda = (y2 - y1) / (x2 - x1), x3 = lambda^2 - x1 - x2,

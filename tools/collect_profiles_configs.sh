@@ -1,4 +1,4 @@
-# Kernel traces of BASELINE configs 3 (2^22, one GPU) and 4 (BN254, 2^18); run on the GPU box, then tools/summarize_rocprof.py on the merged gpurun_out/prof_r04_cfgs/{n22,bn18} -> profiles/r04_bench_n22.{md,csv}, r04_bench_bn254_n18.{md,csv}
+# Kernel traces of BASELINE configs 3 (2^22, one GPU) and 4 (BN254, 2^18); run on the GPU box, then tools/summarize_rocprof.py on the merged gpurun_out/prof_r04_cfgs/{n22,bn18} -> profiles/r04/r04_bench_n22.{md,csv}, r04_bench_bn254_n18.{md,csv}
 set -u
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

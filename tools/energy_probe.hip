@@ -1,4 +1,4 @@
-// Energy per vector instruction under the card's sustained power limit (profiles/r04_notes.md: the prover's step is energy-bound).
+// Energy per vector instruction under the card's sustained power limit (profiles/r04/r04_notes.md: the prover's step is energy-bound).
 // Runs ONE instruction stream -- nothing but independent chains of one instruction -- on every SIMD of the chip at a chosen occupancy
 // for a few seconds and prints how many lane-instructions it issued in how long; tools/power_probe.py around it samples the socket
 // power and the shader clock meanwhile:  python tools/power_probe.py out.txt -- tools/bin/energy_probe mad 2 3.0

@@ -1,5 +1,5 @@
 // Probe: rate of random 128-byte row gathers (one row per lane, 8 x dwordx4 -- the access shape of msm_accumulate's
-// table reads) as a function of the table size.  Question behind it (profiles/r03_notes.md): would a window table with a
+// table reads) as a function of the table size.  Question behind it (profiles/r03/r03_notes.md): would a window table with a
 // row for EVERY bit position (256 rows instead of 16: 34 GB per 2^20 BLS12-381 points) still feed the kernel, or do
 // TLB misses over tens of GB throttle the gathers?  msm_accumulate needs ~7e9 rows/s (0.9 TB/s).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/gather_probe.hip -o tools/bin/gather_probe

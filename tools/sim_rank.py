@@ -3,7 +3,7 @@ of W with a stand-in for torch.distributed whose all_gather returns W copies of 
 No communication is timed -- this shows where a rank's time goes (NTT replica, MSM shard, reductions) for both shard axes
 (points: SRS[0, n/W) and that slice of every polynomial; windows: the whole SRS, the table rows 0, W, 2W, ...) and the two forms of the
 exchange (winsums: the jobs' virtual-window sums, zk_kzg_round_end_winsums_dev + zk_g1_sum_winsums_dev; host: Jacobian partials through
-the host).  Round 5 also timed a third form, one device-resident point per job: last of the three (profiles/r05_sim_rank.txt), retired.
+the host).  Round 5 also timed a third form, one device-resident point per job: last of the three (profiles/r05/r05_sim_rank.txt), retired.
 AN ESTIMATE, NOT A MEASUREMENT of N GPUs.
 
 usage: python tools/sim_rank.py [W ...]

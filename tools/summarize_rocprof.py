@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy a rocprofv3 --kernel-trace --stats run into profiles/ as a small per-kernel summary (CSV + md).
-usage: tools/summarize_rocprof.py gpurun_out/prof3 profiles/r01_bench_n20 "command line that was profiled"
+usage: tools/summarize_rocprof.py gpurun_out/prof3 profiles/r01/r01_bench_n20 "command line that was profiled"
 """
 import csv
 import glob

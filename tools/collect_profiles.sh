@@ -34,3 +34,5 @@ python3 tools/summarize_sq.py "$out/pmc_sq" "$dir/${tag}_pmc_sq.md" "python3 $PM
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_clk" -o p -- python3 $PMCB > "$out/pmc_clk.log" 2>&1
 python3 tools/summarize_clock.py "$out/pmc_clk" "$dir/${tag}_pmc_clock.md" > "$out/clk_summary.txt" 2>&1
 tail -n 30 "$out/trace_summary.txt"; cat "$out/pmc_summary.txt" | head -12; head -8 "$out/sq_summary.txt"; cat "$out/clk_summary.txt" | head -12
+# profiles/ does not travel back from the GPU box; gpurun_out/ does
+mkdir -p "$out/profiles_out" && cp "$dir/${tag}"_bench_n20.md "$dir/${tag}"_bench_n20.csv "$dir/${tag}"_pmc_hbm.md "$dir/${tag}"_pmc_sq.md "$dir/${tag}"_pmc_clock.md profiles/pmc_msm_accumulate.json profiles/pmc_ntt.json "$out/profiles_out/"

@@ -17,14 +17,20 @@ sums, 32 KiB each, straight out of the last reduction kernel, or host Jacobians 
 world, the backend, the (host, PCI address) of the card each rank drove, how many of those are distinct and an all-reduced sum of
 ones; with backend nccl the run refuses to start when ranks share a card.  `--rehearse` walks the N > 1 control flow without a GPU.
 
-N = 1 adds, also never part of `value`:
+N = 1 adds, also never part of `value` (wall seconds of every leg: `leg_s`):
   concurrent_streams  the same GPU with 4 proofs in flight (one thread + zk_ctx + HIP stream each, ONE shared SRS);
+  blocking_calls      every one of the reference's eleven PC calls blocking, as an unchanged Prover::prove issues them;
+  power               socket power, clock and the firmware's throttler residencies over the schedule (which limiter holds the clock);
   drop_in             the same schedule through the host-pointer calls a Rust shim binds (zk_ntt, zk_kzg_commit_batch,
                       zk_kzg_open on pageable buffers, SRS registered once): the unchanged-caller number, with the
                       PCIe bytes it moves; `with_residency_cache` = the library keeps what it produced, `concurrent_callers` = four
                       such callers (threads) at once, one's transfers under the others' kernels;
   dedup               the schedule with the library's content-addressed commitment cache (SURVEY.md 8f N3);
-  no_precompute       the per-window MSM path (no window table), for the table's cost/benefit.
+  no_precompute       the per-window MSM path (no window table), for the table's cost/benefit;
+  configs             BASELINE.json's other configurations through the same code path with default options: config 3's size on one
+                      card (2^22), config 4 (BN254, 2^18), config 5's size point (2^25, deferred form) -- proofs/s, roofline fraction,
+                      commitments digest, job-set memory, and at 2^22 / 2^18 a KZG identity check of one commitment by Python integers.
+`--extra-legs all` adds three legs outside SURVEY.md section 8's hot path (tools/bench_extra_legs.py).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate) with the
 algorithmic bytes of SURVEY.md 8d (128 B per point) over its HIP-event-timed launches;
@@ -1109,16 +1115,6 @@ def main():
                     "what": "the same 29 MSMs with every one of the eleven PC calls blocking (zk_kzg_round_batch_dev per call), as an unchanged Prover::prove issues them",
                     "commitments_match": (rb["digest"] == r["digest"]) if args.check else None}
         leg("blocking_calls", blocking_leg)
-    if world == 1 and S == 1 and extra_all and args.data == "uniform" and not (args.dedup or args.grand_products or args.quotient):
-        def benchcircuit_leg():
-            # SURVEY.md 8d config 2's "realistic" vector on this very binary: wire columns as benches/plonk.rs' BenchCircuit builds them
-            # (composer.rs:493-548: periodic {6, 7, -20, 1} / {-20, 6, 7, 0} rows + 3 blinding rows, zero-padded) -- data-independence
-            k2 = 3
-            rc_ = timed_region(False, 1, k2, warmup=1, data="benchcircuit")
-            return {"proofs_per_s": k2 / rc_["dt"], "ms_per_proof": rc_["dt"] / k2 * 1e3, "steps": k2, "accumulate_ms_per_msm": acc_per_msm(rc_),
-                    "vs_uniform": (k2 / rc_["dt"]) / value, "commitments_sha256": rc_["digest"],
-                    "what": "--data benchcircuit: the same schedule over BenchCircuit-shaped wire columns (benches/plonk.rs:53-62); other inputs as in the headline"}
-        leg("data_benchcircuit", benchcircuit_leg)
     if world == 1 and S == 1 and extra:
         def power_leg():
             # what bounds the step: socket power and shader clock while the headline schedule runs (hwmon, sampled by a host thread;
@@ -1173,101 +1169,15 @@ def main():
                         "how": "zk_ctx_set_commit_cache(1): 256-bit device digest of every coefficient vector; prover.rs:569-607 re-commits 12 polynomials",
                         "commitments_match": (r3["digest"] == r["digest"]) if args.check else None}
             leg("dedup", dedup_leg)
-    if world == 1 and S == 1 and extra_all and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
-        def glue_leg():
-            k2 = max(2, min(steps, 3))
-            r5 = timed_region(False, 1, k2, warmup=1, glue=True)
-            return {"proofs_per_s": k2 / r5["dt"], "ms_per_proof": r5["dt"] / k2 * 1e3,
-                    "quotient_ms_per_proof": r5["prof"]["quotient"][0] / max(r5["kb"], 1), "grand_product_ms_per_proof": r5["prof"]["grand_product"][0] / max(r5["kb"], 1),
-                    "evaluations_ms_per_proof": r5["prof"]["poly_evaluate"][0] / max(r5["kb"], 1),
-                    "linearisation_ms_per_proof": r5["prof"]["poly_lincomb"][0] / max(r5["kb"], 1),
-                    "lookup_round2_ms_per_proof": (r5["prof"]["lookup_query"][0] + r5["prof"]["lookup_combine_split"][0]) / max(r5["kb"], 1),
-                    "what": "SURVEY.md 8f N1 + N2 and the O(n) work of rounds 2 and 5 inside the step: the compressed table / query columns and "
-                            "h_1, h_2 (zk_lookup_query_dev, zk_lookup_combine_split_dev; prover.rs:228-317), z and z2 built on the device (zk_perm_product_dev / "
-                            "zk_lookup_product_dev), the 4n quotient evaluations computed on the device (zk_quotient_evals_dev) from the 12 coset-fft "
-                            "outputs, the 23 evaluations of the proof (zk_poly_evaluate_dev) and the 19-term linearisation polynomial "
-                            "(zk_poly_lincomb_dev; linearisation_poly.rs:164-350) -- instead of synthetic inputs / a stand-in polynomial"}
-        leg("with_device_glue", glue_leg)
-        def full_proof_leg():
-            # a REAL proof: a satisfied circuit (arithmetic, range, logic, ECC and lookup gates, public inputs, copy constraints) built on the device, proved by
-            # ark_plonk_amd/prover.py -- Prover::prove_with_preprocessed's five rounds with every O(n) step through the C ABI, challenges from
-            # the library's merlin transcript -- and serialised; self-check: the verifier's identity lin(z) = -r_0 on the result
-            from ark_plonk_amd import prover, transcript
-            n = 1 << log_n
-            pk, wires, pub = prover.example_circuit(log_n, cv, ctx)
-            ckp = zk.CommitterKey(build_srs(ctx, cv, n, 0, n, torch), cv, ctx)
-            ckp.precompute(args.table_window)
-            pre = transcript.seed_transcript(transcript.Transcript(b"bench", cv), pk.verifier_key(ckp), n)   # Circuit::compile's part of the transcript
-            one = zk.curves.fr_to_mont(cv, [1])[0]
-            a = (pk, ckp, wires, pub, pre, one, one)
-            prover.prove(*a)
-            torch.cuda.synchronize()
-            k2 = max(2, min(steps, 5))
-            t0 = time.perf_counter()
-            for _ in range(k2):
-                proof = prover.prove(*a)
-            torch.cuda.synchronize()
-            dtp = time.perf_counter() - t0
-            ok = prover.check_identity(pk, proof, pub)
-            data = proof.to_bytes()
-            nbytes = len(data)
-            prover.prove(*a, lean=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k2):
-                lean = prover.prove(*a, lean=True)
-            torch.cuda.synchronize()
-            dtl = time.perf_counter() - t0
-            same = lean.to_bytes() == data
-            # the same lean proofs, three in flight (a thread + zk_ctx + HIP stream each over ONE prover key, SRS and window table)
-            import threading
-            S3 = 3
-            lanes3 = []
-            for i in range(S3):
-                cx = ctx if i == 0 else new_ctx(dev)
-                st3 = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
-                lanes3.append((cx, st3, (pk if i == 0 else pk.with_ctx(cx), ckp if i == 0 else ckp.with_ctx(cx)) + a[2:]))
-            for cx, st3, a3 in lanes3[1:]:
-                with torch.cuda.stream(st3):
-                    prover.prove(*a3, lean=True)
-            torch.cuda.synchronize()
-            gate, errs3, outs3 = threading.Barrier(S3 + 1), [], [None] * S3
-
-            def lane3(i):
-                cx, st3, a3 = lanes3[i]
-                try:
-                    with torch.cuda.stream(st3):
-                        gate.wait()
-                        for _ in range(k2):
-                            outs3[i] = prover.prove(*a3, lean=True)
-                        st3.synchronize()
-                except Exception as e:
-                    errs3.append(e)
-                    gate.abort()
-            th3 = [threading.Thread(target=lane3, args=(i,)) for i in range(S3)]
-            for t in th3:
-                t.start()
-            gate.wait()
-            t0 = time.perf_counter()
-            for t in th3:
-                t.join()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t0
-            if errs3:
-                raise errs3[0]
-            same3 = all(o.to_bytes() == data for o in outs3)
-            for cx, _, _ in lanes3[1:]:
-                cx.close()
-            ckp.close()
-            return {"proofs_per_s": k2 / dtp, "ms_per_proof": dtp / k2 * 1e3, "proof_bytes": nbytes, "verifier_identity_holds": bool(ok),
-                    "lean": {"proofs_per_s": k2 / dtl, "ms_per_proof": dtl / k2 * 1e3, "msms": 15, "same_proof_bytes": bool(same),
-                             "three_in_flight": {"proofs_per_s": S3 * k2 / dt3, "ms_per_proof_aggregate": dt3 / (S3 * k2) * 1e3, "same_proof_bytes": bool(same3)},
-                             "how": "the 14 commitments of prover.rs:579,606 are used by nobody (SonicKZG10's open does not read them, the Proof holds none but z's, "
-                                    "the verifier rebuilds them): 15 MSMs in 5 calls instead of 29 in 11, identical bytes"},
-                    "what": "a satisfied circuit of 2^%d rows proved end to end on the device (31 NTTs, 29 MSMs, round-2 lookup multisets, both grand "
-                            "products, the pointwise quotient, 23 evaluations, the linearisation polynomial, merlin transcript, proof bytes); "
-                            "tests/test_prover_gpu.py checks such proofs against the reference verifier's equations" % log_n}
-        leg("full_proof", full_proof_leg)
+    if world == 1 and S == 1 and extra_all and not (args.dedup or args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
+        # legs outside SURVEY.md section 8's hot path: tools/bench_extra_legs.py
+        from types import SimpleNamespace
+        from tools import bench_extra_legs as xl
+        E = SimpleNamespace(args=args, zk=zk, torch=torch, ctx=ctx, cv=cv, log_n=log_n, steps=steps, value=value, r=r, dev=dev,
+                            timed_region=timed_region, acc_per_msm=acc_per_msm, build_srs=build_srs, new_ctx=new_ctx)
+        leg("data_benchcircuit", lambda: xl.data_benchcircuit(E))
+        leg("with_device_glue", lambda: xl.with_device_glue(E))
+        leg("full_proof", lambda: xl.full_proof(E))
     if world == 1 and S == 1 and extra and not (args.grand_products or args.quotient or args.fuse_round5 or args.data != "uniform"):
         if not args.no_precompute:
             def nopre_leg():

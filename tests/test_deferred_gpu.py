@@ -397,3 +397,39 @@ def test_round_under_a_memory_budget_device_exchange_forms(ctx):
     assert ck2.sum_winsums_dev(buf.reshape(1, -1), 1, 6) == want
     ctx2.close()
     ck.close()
+
+
+def test_round_budget_by_the_device_free_memory_rule(ctx):
+    """The same early close through the REAL rule -- hipMemGetInfo minus option "mem_reserve_mb" -- instead of the test hook: the reserve
+    is set so that about three buffer sets of a 2^18-point job still fit beside it, on a fresh ctx that owns none yet."""
+    cv = zk.get_curve(0)
+    n = 1 << 18
+    ck = _ck(ctx, cv, n, seed=65).precompute()
+    p = _polys(n, 8, 66)
+    want = ck.commit_batch(p)
+    ctx1 = zk.Context(ctx.device)
+    ctx1.use_torch_stream()
+    ck1 = ck.with_ctx(ctx1)
+    ck1.commit_begin(p)
+    assert ck1.round_end() == want
+    per_set = ctx1.round_mem_stats()["set_bytes"] // 8
+    ctx1.close()
+    import torch
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    ctx2 = zk.Context(ctx.device)
+    ctx2.use_torch_stream()
+    ck2 = ck.with_ctx(ctx2)
+    free = ctx2.round_mem_stats()["device_free"]
+    assert free > 4 * per_set
+    ctx2.set_option("mem_reserve_mb", int((free - 3.5 * per_set) // (1 << 20)))
+    for t in p:
+        ck2.commit_begin([t])
+    assert ck2.round_pending() == 8
+    got = ck2.round_end()
+    st = ctx2.round_mem_stats()
+    assert got == want
+    assert st["early_closes"] >= 1 and st["set_bytes"] <= 4.5 * per_set, (st, per_set)
+    ctx2.set_option("mem_reserve_mb", 1024)
+    ctx2.close()
+    ck.close()

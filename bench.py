@@ -201,125 +201,7 @@ def cpu_baseline(log_n: int, cid: int = 0, bits: int = 255, budget_s: float = 45
     return out
 
 
-class PowerSampler:
-    """Socket power and shader clock of the card the process runs on, from the amdgpu hwmon files (plain sysfs reads, no GPU call),
-    sampled by a thread while a leg runs.  A box shows the hwmon of every card of its host -- other tenants' cards too: the card is
-    the one whose PCI address is `bdf` (the sysfs `device` link of the card names it); only without a match, the one whose power
-    moved most (rounds 1-4's heuristic: wrong whenever a neighbour's job starts or stops meanwhile -- profiles/r05/r05_notes.md).  Used by
-    the `power` leg only -- never inside the timed region of `value`."""
-
-    WANT = ("power1_average", "power1_input", "freq1_input", "temp2_input")
-
-    def __init__(self, period_s: float = 0.004, bdf: str | None = None):
-        import glob
-        self.hw = []
-        self.matched_bdf = False
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-            files = {k: os.path.join(d, k) for k in self.WANT + ("power1_cap",) if os.path.exists(os.path.join(d, k))}
-            if "freq1_input" in files and ("power1_average" in files or "power1_input" in files):
-                self.hw.append((d, files))
-        if bdf:
-            mine = [(d, f) for d, f in self.hw if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))).lower().startswith(bdf.lower())]
-            if mine:
-                self.hw, self.matched_bdf = mine[:1], True
-        self.period = period_s
-        self.rows = []
-        self._stop = None
-        self._th = None
-
-    @staticmethod
-    def _read(path):
-        try:
-            with open(path) as f:
-                return int(f.read().strip())
-        except (OSError, ValueError):
-            return None
-
-    def __enter__(self):
-        import threading
-        self._stop = threading.Event()
-
-        def loop():
-            while not self._stop.is_set():
-                row = [time.perf_counter()]
-                for _, files in self.hw:
-                    pw = self._read(files.get("power1_average", files.get("power1_input", "")))
-                    row += [pw, self._read(files["freq1_input"]), self._read(files["temp2_input"]) if "temp2_input" in files else None]
-                self.rows.append(row)
-                time.sleep(self.period)
-
-        self._th = threading.Thread(target=loop, daemon=True)
-        self._th.start()
-        return self
-
-    def __exit__(self, *a):
-        self._stop.set()
-        self._th.join()
-
-    def summary(self, t0: float, t1: float):
-        if not self.hw or not self.rows:
-            return None
-        best, span = None, -1.0
-        for h in range(len(self.hw)):
-            v = [r[1 + 3 * h] for r in self.rows if r[1 + 3 * h] is not None]
-            if v and max(v) - min(v) > span:
-                best, span = h, max(v) - min(v)
-        if best is None:
-            return None
-        sel = [r for r in self.rows if t0 <= r[0] <= t1]
-        pw = sorted(r[1 + 3 * best] / 1e6 for r in sel if r[1 + 3 * best] is not None)
-        fq = sorted(r[2 + 3 * best] / 1e6 for r in sel if r[2 + 3 * best] is not None)
-        tj = [r[3 + 3 * best] / 1e3 for r in sel if r[3 + 3 * best] is not None]
-        if not pw or not fq:
-            return None
-        cap = self._read(self.hw[best][1].get("power1_cap", ""))
-        return {"socket_power_w": {"mean": sum(pw) / len(pw), "median": pw[len(pw) // 2], "max": pw[-1]},
-                "sclk_mhz": {"mean": sum(fq) / len(fq), "median": fq[len(fq) // 2], "min": fq[0], "max": fq[-1]},
-                "junction_c_max": max(tj) if tj else None, "power_cap_w": cap / 1e6 if cap else None, "samples": len(sel),
-                "hwmon": self.hw[best][0], "card_matched_by_pci_address": self.matched_bdf}
-
-
-class FirmwareThrottlers:
-    """The throttler residency accumulators of the card's power-management firmware (gpu_metrics v1.6+: accumulation_counter and the
-    PPT / socket-thermal / VR-thermal / HBM-thermal / PROCHOT residencies), read through AMD SMI (`amdsmi_get_violation_status`: sysfs
-    underneath, no GPU call) for the card with PCI address `bdf`.  between(a, b) = the share of firmware iterations each limiter was
-    ACTIVE between two snapshots: the one that is non-zero NAMES what holds the clock below its peak (profiles/r05/r05_notes.md)."""
-
-    KEYS = {"ppt": "acc_ppt_pwr", "socket_thermal": "acc_socket_thrm", "vr_thermal": "acc_vr_thrm", "hbm_thermal": "acc_hbm_thrm", "prochot": "acc_prochot_thrm"}
-
-    def __init__(self, bdf: str):
-        self.smi, self.h, self.error = None, None, None
-        try:
-            sys.path.insert(0, "/opt/rocm/share/amd_smi")
-            import amdsmi
-            amdsmi.amdsmi_init()
-            for h in amdsmi.amdsmi_get_processor_handles():
-                if amdsmi.amdsmi_get_gpu_device_bdf(h).lower().startswith(bdf.lower()):
-                    self.smi, self.h = amdsmi, h
-            if self.h is None:
-                self.error = f"no AMD SMI processor with PCI address {bdf}"
-        except Exception as e:
-            self.error = repr(e)
-
-    def snapshot(self):
-        if self.h is None:
-            return None
-        try:
-            v = self.smi.amdsmi_get_violation_status(self.h)
-            return {k: v.get(k) for k in ("acc_counter",) + tuple(self.KEYS.values())}
-        except Exception as e:
-            self.error = repr(e)
-            return None
-
-    def between(self, a, b):
-        if not a or not b or not isinstance(a.get("acc_counter"), int) or not isinstance(b.get("acc_counter"), int) or b["acc_counter"] <= a["acc_counter"]:
-            return None
-        it = b["acc_counter"] - a["acc_counter"]
-        shares = {name: (b[k] - a[k]) / it for name, k in self.KEYS.items() if isinstance(a.get(k), int) and isinstance(b.get(k), int)}
-        active = {k: v for k, v in shares.items() if v > 0.02}
-        return {"firmware_iterations": it, "active_share": shares, "limiter": max(active, key=active.get) if active else None,
-                "source": "AMD SMI amdsmi_get_violation_status (gpu_metrics throttler residency accumulators): share of firmware iterations "
-                          "each limiter was active during the sampled run"}
+from tools.power_sampler import FirmwareThrottlers, PowerSampler  # noqa: E402  (the `power` leg: hwmon + firmware throttler residencies)
 
 
 def free_port() -> int:
@@ -645,7 +527,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
     import ark_plonk_amd as zk
-    from ark_plonk_amd.prover_schedule import DropInSchedule, ProofSchedule
+    from ark_plonk_amd.prover_schedule import ProofSchedule
 
     options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
 
@@ -810,123 +692,9 @@ def main():
         return res
 
     def drop_in_region(k: int, log_n: int = args.log_n):
-        """K proofs through the host-pointer entry points, pageable numpy buffers, SRS registered once."""
-        n = 1 << log_n
-        srs = build_srs(ctx, cv, n, 0, n, torch).cpu().numpy().view(np.uint64)
-        t0 = time.perf_counter()
-        ck = zk.CommitterKey(srs, cv, ctx)                  # zk_srs_register: upload + digest
-        t_reg = time.perf_counter() - t0
-        if not args.no_precompute:
-            ck.precompute(args.table_window)
-        t0 = time.perf_counter()
-        ck2 = zk.CommitterKey(srs, cv, ctx)                 # PC::trim on the next gen_proof: a cache hit
-        t_hit = time.perf_counter() - t0
-        sched = DropInSchedule(log_n, ctx, ck2, cv)
-        sched.run_once()
-        ctx.io_stats(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(k):
-            sched.run_once()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        io = ctx.io_stats()
-        pts = sched.run_once(proof_id=0) if args.check else None
-        # the same caller with the library's commitment cache switched on (one call in the shim, INTEGRATION.md section 3)
-        ctx.set_commit_cache(True)
-        sched.run_once()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            sched.run_once()
-        torch.cuda.synchronize()
-        dt_cache = time.perf_counter() - t0
-        ctx.set_commit_cache(False)
-        # the same caller with the library's residency cache switched on (one more call in the shim): vectors the library produced or has
-        # seen are not uploaded again -- every proof has its own witness, so the evaluation vectors still miss, as they would in production
-        res = None
-        try:
-            ctx.set_residency_cache(True)
-            for _ in range(5):                  # until the cache has reached its capacity: from then on evicted buffers are reused and
-                sched.run_once()                # no call allocates device memory any more (the steady state of a proving service)
-            ctx.io_stats(reset=True)
-            st0 = ctx.residency_cache_stats()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                sched.run_once()
-            torch.cuda.synchronize()
-            dt_res = time.perf_counter() - t0
-            io_r = ctx.io_stats()
-            st1 = ctx.residency_cache_stats()
-            pts_r = sched.run_once(proof_id=0) if args.check else None
-            res = {"proofs_per_s": k / dt_res, "ms_per_proof": dt_res / k * 1e3, "h2d_bytes_per_proof": io_r["h2d_bytes"] // k,
-                   "d2h_bytes_per_proof": io_r["d2h_bytes"] // k, "hits_per_proof": (st1["hits"] - st0["hits"]) / k,
-                   "misses_per_proof": (st1["misses"] - st0["misses"]) / k, "resident_bytes": st1["bytes"],
-                   "same_points_as_uncached": (digest(pts_r) == digest(pts)) if args.check else None,
-                   "how": "zk_ctx_set_residency_cache(ctx, 1, 0, 0): zk_ntt keeps the device copy of every output of at most 64 MiB under a keyed 256-bit "
-                          "digest of the bytes the caller receives; zk_ntt / zk_kzg_commit_batch / zk_kzg_open digest their inputs on the host pool and "
-                          "use the resident copy on a match (prover.rs:196-213,569-618: an ifft output goes back up as a commit, coset_fft and "
-                          "opening input)"}
-        except Exception as e:
-            res = {"error": repr(e)}
-        finally:
-            ctx.set_residency_cache(False)
-        # T unchanged callers at once (a proving service running `Prover::prove` in T worker threads): one zk_ctx, one proof and one set
-        # of pageable vectors per thread, ONE resident SRS; a caller's transfers run under the other callers' kernels
-        callers = None
-        try:
-            import threading
-            T = args.drop_in_callers
-            ctxs = [zk.Context(ctx.device) for _ in range(T)]
-            cks = [zk.CommitterKey(srs, cv, c) for c in ctxs]
-            scheds = [DropInSchedule(log_n, c, ckc, cv) for c, ckc in zip(ctxs, cks)]
-            for s_ in scheds:
-                s_.run_once()
-            bar = threading.Barrier(T + 1)
-            errs = []
-
-            def caller(s_):
-                try:
-                    bar.wait()
-                    for _ in range(k):
-                        s_.run_once()
-                    torch.cuda.synchronize()
-                except Exception as e:      # noqa: BLE001
-                    errs.append(repr(e))
-                finally:
-                    bar.wait()
-            ths = [threading.Thread(target=caller, args=(s_,)) for s_ in scheds]
-            for t_ in ths:
-                t_.start()
-            bar.wait()
-            t0 = time.perf_counter()
-            bar.wait()
-            dt_c = time.perf_counter() - t0
-            for t_ in ths:
-                t_.join()
-            same = all(digest(s_.run_once(proof_id=0)) == digest(pts) for s_ in scheds) if args.check else None
-            callers = {"callers": T, "proofs_per_s": T * k / dt_c, "ms_per_proof_per_caller": dt_c / k * 1e3, "proofs_each": k,
-                       "same_points_as_one_caller": same, "errors": errs or None,
-                       "how": "T host threads, each with its own zk_ctx, proof and pageable vectors, all calling zk_ntt / zk_kzg_commit_batch / zk_kzg_open "
-                              "against one GPU and one resident SRS (residency cache off); tools/drop_in_callers.py sweeps T = 1..8"}
-            for ckc in cks:
-                ckc.close()
-            for c in ctxs:
-                c.close()
-            del scheds
-        except Exception as e:
-            callers = {"error": repr(e)}
-        out = {"proofs_per_s": k / dt, "proofs_per_s_with_commit_cache": k / dt_cache, "with_residency_cache": res, "concurrent_callers": callers,
-               "ms_per_proof": dt / k * 1e3, "steps": k,
-               "h2d_bytes_per_proof": io["h2d_bytes"] // k, "d2h_bytes_per_proof": io["d2h_bytes"] // k,
-               "pcie_GBps_over_whole_proof": (io["h2d_bytes"] + io["d2h_bytes"]) / dt / 1e9,
-               "srs_register_ms_first": t_reg * 1e3, "srs_register_ms_cached": t_hit * 1e3, "srs_cache": zk.srs_cache_stats(),
-               "calls": "31 zk_ntt (in place on caller vectors) + 9 zk_kzg_commit_batch (4|1|1|1|1|1|4|7|7 polynomials) + 2 zk_kzg_open per proof; "
-                        "pageable host buffers, reused across proofs",
-               "digest": digest(pts) if args.check else None}
-        ck2.close()
-        ck.close()
-        zk.srs_cache_config(0)          # drop the resident copy before the next leg
-        zk.srs_cache_config(32 << 30)
-        return out
+        from types import SimpleNamespace
+        from tools import bench_drop_in
+        return bench_drop_in.drop_in_region(SimpleNamespace(args=args, zk=zk, torch=torch, ctx=ctx, cv=cv, build_srs=build_srs, digest=digest), k, log_n)
 
     main_sharded = mode == "shard"
     log_n = args.log_n

@@ -209,7 +209,9 @@ int zk_srs_register_dev(zk_ctx* ctx, int curve_id, const void* d_bases_xy, const
  * Default window: c = 16 (16 rows) below 2^19 points, c = 17 from there on -- 15 rows for the 255-bit scalars of BLS12-381,
  * because a scalar k > (r - 1) / 2 is treated as -(r - k): one mixed addition per scalar fewer, 2^16 buckets instead of 2^15;
  * from 2^22 points on, c = 20 (13 rows, 2^19 buckets): two more additions per scalar saved outweigh the wider bucket reduction there
- * (the device-resident exchange forms below are not available on such a table: ZK_ERR_UNSUPPORTED, use the host form). */
+ * (the device-resident exchange below -- zk_kzg_round_end_winsums_dev -- needs window_bits <= 17: for an SRS or shard of 2^22 points
+ * and more that is meant for it, call zk_srs_precompute_ex(ctx, srs, 17) instead; on a 20-bit table those calls return
+ * ZK_ERR_UNSUPPORTED before anything is queued and the host form closes the round). */
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs);
 /* Same with the table's window c chosen: 16 (default; 16 rows, 2^15 shared buckets) .. 21.  A larger window means fewer
  * rows (15 at c = 17, 13 at c = 20: mixed additions per scalar, table rows) but 2^(c-1) buckets to reduce.
@@ -225,7 +227,7 @@ int zk_srs_table_info(zk_srs* srs, uint32_t* window_bits, uint32_t* windows);
  * window_stride, ... (g, g + G, ...: ceil((W - g) / G) of the W rows), i.e. about 1/G of the table.  Every MSM entry point over such
  * an SRS then returns the rank's PARTIAL sum_i sum_{w owned} d_{i,w} 2^(c w) P_i -- all N scalars, the owned digits only, the rank's
  * own bucket set -- and the ranks' partials add up to the MSM (zk_g1_sum_partials*, after the same all-gather as the point-sharded
- * form: zk_kzg_round_end_partial(_dev)).  A vector too short for the table path is computed whole by the owner of window 0 and is
+ * form: zk_kzg_round_end_partial, or the window-sum form on the device).  A vector too short for the table path is computed whole by the owner of window 0 and is
  * the point at infinity on the other ranks.  (first_window, window_stride) = (0, 1) is zk_srs_precompute_ex.  The first precompute
  * of an SRS wins, as above; a later call must name the same rows.  The plain SRS stays resident next to the rows. */
 int zk_srs_precompute_rows(zk_ctx* ctx, zk_srs* srs, uint32_t window_bits, uint32_t first_window, uint32_t window_stride);

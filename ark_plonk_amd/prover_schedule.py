@@ -47,8 +47,8 @@ def all_gather_partials(dist, parts: np.ndarray, world: int, device) -> np.ndarr
 
 def all_gather_partials_dev(dist, mine, world: int):
     """The same exchange with the partials never leaving the device: `mine` is the int64 device tensor the last
-    reduction kernel of the round wrote (jobs x partial words, zk_kzg_round_end_partial_dev), the result the (world, jobs x words)
-    device tensor zk_g1_sum_partials_dev reads.  RCCL (backend "nccl") gathers device tensors directly: no host copy between the
+    reduction kernel of the round wrote (jobs x window-sum words, zk_kzg_round_end_winsums_dev), the result the (world, jobs x words)
+    device tensor zk_g1_sum_winsums_dev reads.  RCCL (backend "nccl") gathers device tensors directly: no host copy between the
     last kernel and the collective.  gloo has no device all_gather: the rehearsal backend stages through the CPU here."""
     import torch
     flat = mine.reshape(-1)

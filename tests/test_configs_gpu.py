@@ -141,6 +141,9 @@ def test_config5_deferred_schedule_2_25(ctx):
     import torch
     from ark_plonk_amd.prover_schedule import ProofSchedule
     from test_deferred_gpu import _ck
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                      # this test needs 255 of the card's 288 GiB: nothing cached by earlier tests may linger
     cv = zk.get_curve(0)
     log_n = 25
     ck = _ck(ctx, cv, 1 << log_n, seed=2525).precompute()

@@ -144,6 +144,9 @@ def test_config5_deferred_schedule_2_25(ctx):
     import gc
     gc.collect()
     torch.cuda.empty_cache()                      # this test needs 255 of the card's 288 GiB: nothing cached by earlier tests may linger
+    free, total = torch.cuda.mem_get_info()
+    if free < 258 << 30:                          # a smaller card, or one shared with another tenant: the size point does not fit at all
+        pytest.skip(f"n = 2^25 needs 255 GiB of device memory; {free >> 30} of {total >> 30} GiB free")
     cv = zk.get_curve(0)
     log_n = 25
     ck = _ck(ctx, cv, 1 << log_n, seed=2525).precompute()

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--proofs", type=int, default=2, help="timed proofs per visit of a configuration (after one untimed)")
     ap.add_argument("--block-every-call", action="store_true")
+    ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     args = ap.parse_args()
     import torch
     import ark_plonk_amd as zk
@@ -41,7 +42,7 @@ def main():
     keys = sorted({k for c in cfgs for k in c})
     ctx = zk.Context(0)
     ctx.use_torch_stream()
-    cv = zk.get_curve("bls12_381")
+    cv = zk.get_curve(args.curve)
     n = 1 << args.log_n
     srs = build_srs(ctx, cv, n, 0, n, torch)
     ck = zk.CommitterKey(srs, cv, ctx)
@@ -76,7 +77,7 @@ def main():
                 sched.run_once()
             torch.cuda.synchronize()
             times[i].append((time.perf_counter() - t0) / args.proofs * 1e3)
-    print(f"n = 2^{args.log_n}, {args.pairs} visits x {args.proofs} proofs per configuration, alternating; ms per proof")
+    print(f"{args.curve} n = 2^{args.log_n}, {args.pairs} visits x {args.proofs} proofs per configuration, alternating; ms per proof")
     for i, c in enumerate(args.configs):
         t = times[i]
         d = [a - b for a, b in zip(t, times[0])]
